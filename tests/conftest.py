@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "bayesian-neural-network_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """Lazy view of a golden .npz with '/'-separated keys."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name))
+        self.keys = list(self.z.keys())
+
+    def case(self, prefix):
+        prefix = prefix.rstrip("/") + "/"
+        return {k[len(prefix):]: self.z[k] for k in self.keys if k.startswith(prefix)}
+
+    def cases(self, prefix):
+        prefix = prefix.rstrip("/") + "/"
+        names = sorted({k[len(prefix):].split("/")[0] for k in self.keys if k.startswith(prefix)})
+        return [prefix + n for n in names]
+
+
+@pytest.fixture(scope="session")
+def g_layers():
+    return Golden("layers.npz")
+
+
+@pytest.fixture(scope="session")
+def g_c1():
+    return Golden("net_c1.npz")
+
+
+@pytest.fixture(scope="session")
+def g_c2():
+    return Golden("net_c2.npz")
+
+
+@pytest.fixture(scope="session")
+def g_beta():
+    return Golden("beta.npz")

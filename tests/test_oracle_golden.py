@@ -1,0 +1,205 @@
+"""The CPU oracle (oracle/bnn_oracle.py) against vectors recorded from the REAL reference
+(oracle/make_golden.py).  This is what pins the oracle: SURVEY §8(c) G1-G9."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn_oracle as O
+from bnn_hip import synth
+
+RTOL = 1e-6   # fp32 restatement vs fp32 reference, same op order
+torch.set_num_threads(1)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=RTOL, atol=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def run_bbb(c):
+    prior = O.Prior.from_init(list(c["prior_init"]), bool(c["mixture"]))
+    train, sample, clp = bool(c["train"]), bool(c["sample"]), bool(c["clp"])
+    do_sample = train or sample
+    want = train or clp
+    return O.bbb_linear(t(c["x"]), t(c["weight_mu"]), t(c["weight_rho"]), t(c["bias_mu"]), t(c["bias_rho"]),
+                        t(c["eps_w"]) if do_sample else None, t(c["eps_b"]) if do_sample else None, prior, want)
+
+
+def check_bbb(c):
+    y, lp, lq = run_bbb(c)
+    close(y.numpy(), c["y"], rtol=2e-6, atol=1e-6)
+    if int(c["log_prior_is_int"]):
+        assert lp == 0 and lq == 0
+    else:
+        close(float(lp), c["log_prior"])
+        close(float(lq), c["log_q"])
+
+
+def run_lr(c):
+    return O.lr_linear(t(c["x"]), t(c["weight_mu"]), t(c["weight_rho"]), t(c["bias_mu"]), t(c["bias_rho"]),
+                       t(c["eps_act"]), t(c["eps_b"]), float(c["sigma_p"]), bool(c["train"]) or bool(c["clp"]))
+
+
+def test_g1_gaussian_prior(g_layers):
+    for name in g_layers.cases("G1"):
+        check_bbb(g_layers.case(name))
+
+
+def test_g2_mixture_prior(g_layers):
+    for name in g_layers.cases("G2"):
+        check_bbb(g_layers.case(name))
+
+
+def test_g3_mode_truth_table(g_layers):
+    names = g_layers.cases("G3")
+    assert len(names) == 8
+    n_int = 0
+    for name in names:
+        c = g_layers.case(name)
+        check_bbb(c)
+        n_int += int(c["log_prior_is_int"])
+    assert n_int == 2          # eval & not calculate_log_probs, sample in {F,T}
+
+
+def test_g4_lr_layer(g_layers):
+    for name in g_layers.cases("G4"):
+        c = g_layers.case(name)
+        y, kw, kb = run_lr(c)
+        close(y.numpy(), c["y"], rtol=2e-6, atol=1e-6)
+        if bool(c["train"]) or bool(c["clp"]):
+            close(float(kw), c["weight_kl"])
+            close(float(kb), c["bias_kl"])
+            close(float(kw + kb), c["kl"])
+        else:                                  # stale attributes: reference left its init value 0
+            assert kw is None and float(c["kl"]) == 0.0
+
+
+def test_g7_odd_shapes(g_layers):
+    names = g_layers.cases("G7")
+    assert len(names) == 21
+    for name in names:
+        c = g_layers.case(name)
+        if "lr" in name.split("/")[-1]:
+            y, kw, kb = run_lr(c)
+            close(y.numpy(), c["y"], rtol=1e-5, atol=1e-5)
+            close(float(kw + kb), c["kl"])
+        else:
+            y, lp, lq = run_bbb(c)
+            close(y.numpy(), c["y"], rtol=1e-5, atol=1e-4)   # K up to 1200: fp32 sum-order noise
+            close(float(lp), c["log_prior"])
+            close(float(lq), c["log_q"])
+
+
+def test_g8_rho_extremes(g_layers):
+    c = g_layers.case("G8")
+    sig = O.softplus_naive(t(c["rho"]))
+    close(sig.numpy(), c["sigma"])
+    assert math.isinf(float(sig[-1])) and float(sig[-1]) > 0          # rho = 89 overflows, as in the reference
+    w = O.sample_gaussian(t(c["mu"]), t(c["rho"]), t(c["eps"]))
+    np.testing.assert_allclose(w.numpy()[:6], c["w"][:6], rtol=RTOL)
+    lq = O.log_q(w[:6], t(c["mu"])[:6], t(c["rho"])[:6])
+    close(float(lq), c["log_q_sum_finite"], rtol=2e-6)
+
+
+def build_net(g, lr, B, mixture=False, dims=(1, 50, 1), mode="regression"):
+    sd = synth.synth_state_dict(dims[0], dims[1], dims[2], lr)
+    prior = O.Prior.from_init([0.5, 0.0, -6.0], True) if mixture else O.Prior.from_init([1.0], False)
+    return O.NetParams.from_state_dict(sd, mode, dims[0], lr, prior)
+
+
+def net_eps(p, B, S):
+    return [[t(a) for a in synth.synth_eps(p.eps_shapes(B), s)] for s in range(S)]
+
+
+@pytest.mark.parametrize("variant", ["bbb", "lr", "mix"])
+def test_g5_c1_elbo_and_grads(g_c1, variant):
+    lr = variant == "lr"
+    n_checked = 0
+    for Bname in g_c1.cases(f"G5/{variant}"):
+        B = int(Bname.split("/")[-1][1:])
+        for Sname in g_c1.cases(Bname):
+            S = int(Sname.split("/")[-1][1:])
+            for bname in g_c1.cases(Sname):
+                c = g_c1.case(bname)
+                p = build_net(g_c1, lr, B, mixture=(variant == "mix"))
+                for lay in p.layers:
+                    for q in lay:
+                        q.requires_grad_(True)
+                x, y = synth.synth_batch("regression", B, 1, 1)
+                fn = O.sample_elbo_lr if lr else O.sample_elbo
+                tup = fn(p, t(x), t(y), float(c["beta"]), S, 0.1, eps=net_eps(p, B, S))
+                assert [v.dim() for v in tup] == list(c["t_shapes"])
+                for i, v in enumerate(tup):
+                    close(v.detach().numpy(), c[f"t{i}"], rtol=2e-6)
+                if "grad/l1.weight_mu" in c:
+                    tup[0].backward()
+                    names = [f"l{li+1}.{n}" for li in range(3) for n in synth.PARAM_NAMES]
+                    flat = [q for lay in p.layers for q in lay]
+                    for n, q in zip(names, flat):
+                        gref = c[f"grad/{n}"]
+                        np.testing.assert_allclose(q.grad.numpy(), gref, rtol=2e-5,
+                                                   atol=2e-6 * float(np.abs(gref).max()))
+                    n_checked += 1
+    assert n_checked >= 2
+
+
+@pytest.mark.parametrize("variant", ["bbb", "mix", "lr"])
+def test_g6_c2_full_size(g_c2, variant):
+    torch.set_num_threads(8)
+    try:
+        lr = variant == "lr"
+        p = build_net(g_c2, lr, 128, mixture=(variant == "mix"), dims=(784, 1200, 10), mode="classification")
+        x, y = synth.synth_batch("classification", 128, 784, 10)
+        xt, yt = t(x), t(y)
+        c = g_c2.case(f"G6/{variant}/S1")
+        eps = net_eps(p, 128, 2)
+        logits, a, b = O.network_forward(p, xt, eps[0])
+        close(logits[:2].numpy(), c["logits_s0_rows01"], rtol=1e-4, atol=2e-4)   # K=1200 fp32 sum order (threads)
+        close(float(O.nll(logits, yt, "classification")), c["nll_s0"], rtol=1e-5)
+        for S in (1, 2):
+            c = g_c2.case(f"G6/{variant}/S{S}")
+            fn = O.sample_elbo_lr if lr else O.sample_elbo
+            tup = fn(p, xt, yt, 0.5, S, eps=eps[:S])
+            for i, v in enumerate(tup):
+                close(v.numpy(), c[f"t{i}"], rtol=3e-6)
+    finally:
+        torch.set_num_threads(1)
+
+
+def test_g9_beta_schedule(g_beta):
+    c = g_beta.case("G9")
+    M = int(c["M"])
+    for i, idx in enumerate(c["idx"]):
+        b = O.beta_schedule(M, int(idx))
+        assert b == float(c["beta"][i])
+        got = float((b * torch.tensor(7.4e6, dtype=torch.float32)).item())
+        assert got == float(c["beta_times_7p4e6_f32"][i])
+    assert float(c["beta_times_7p4e6_f32"][4]) == 0.0      # idx 149: complexity term is exactly 0 in fp32
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    r = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_normal_moments():
+    e = O.philox_normal(2026, O.tensor_id(1, 0), 3, 300, 1201)
+    assert e.shape == (300, 1201) and e.dtype == np.float32
+    assert abs(float(e.mean())) < 5e-3 and abs(float(e.std()) - 1.0) < 5e-3
+    # sample/tensor/seed separate the streams; the map does not depend on how rows are tiled
+    e2 = O.philox_normal(2026, O.tensor_id(1, 0), 4, 300, 1201)
+    assert abs(float(np.corrcoef(e.ravel(), e2.ravel())[0, 1])) < 5e-3
+    sub = O.philox_normal(2026, O.tensor_id(1, 0), 3, 7, 1201)
+    np.testing.assert_array_equal(sub, e[:7])
