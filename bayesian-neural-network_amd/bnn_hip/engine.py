@@ -1,0 +1,260 @@
+"""Batched-samples launcher: what replaces the reference's serial MC loop
+(networks.py:199-203, :217-220).  All locally owned MC samples of an ELBO evaluation go
+through ONE launch per layer plus one finalize launch; with sample sharding enabled the
+S global samples are split over the ranks of the default process group and the only
+collective is a sum all-reduce of three scalars (RCCL over xGMI on a GPU node).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .functional import AllReduceSumFn, BBBLinearFn, LayerCall, LRLinearFn, NLLFn
+from .runtime import state, take_samples
+
+
+def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of global sample indices owned by `rank`: [first, first+count).
+    The first (n_samples % world) ranks own one extra sample."""
+    base, extra = divmod(int(n_samples), int(world))
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def dist_info() -> Tuple[int, int]:
+    """(rank, world) of the default group when sample sharding is on, else (0, 1)."""
+    if state.shard_samples:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _host_eps(shapes: Sequence[Tuple[int, ...]], n_samples: int, device) -> List[torch.Tensor]:
+    """eps drawn from torch's CPU generator in the reference's order (per sample: layer
+    1..3, weight-shaped then bias-shaped; networks.py:42, :75-76, :123-124), stacked per
+    tensor over samples and copied H2D."""
+    per = [[torch.randn(s) for s in shapes] for _ in range(n_samples)]
+    return [torch.stack([per[i][j] for i in range(n_samples)]).to(device) for j in range(len(shapes))]
+
+
+class LayerSpec:
+    """What the engine needs to know about one stochastic layer."""
+
+    def __init__(self, module, layer_id: int, local_reparam: bool, relu: bool):
+        self.m, self.layer_id, self.lr, self.relu = module, layer_id, local_reparam, relu
+
+    @property
+    def in_out(self) -> Tuple[int, int]:
+        w = self.m.weight_mu
+        return (w.shape[0], w.shape[1]) if self.lr else (w.shape[1], w.shape[0])
+
+
+def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first_sample: int, *,
+               want_stats: bool, sample: bool, injected: Optional[List[torch.Tensor]] = None,
+               differentiable: bool):
+    """Push `n_local` MC samples through the stack.  Returns (logits[S,B,C] fp32,
+    per-layer stats).  Stats are (log_prior[S], log_q[S]) or kl3[3] tensors on the
+    differentiable path and raw workspaces on the forward-only path."""
+    math_mode = state.math
+    hidden_dtype = torch.float32 if (differentiable or math_mode == L.MATH_F32) else torch.bfloat16
+    h = x
+    stats = []
+    for i, sp in enumerate(layers):
+        last = i == len(layers) - 1
+        if not sample:
+            eps_mode, e_w, e_b = L.EPS_ZERO, None, None
+        elif injected is not None:
+            eps_mode, e_w, e_b = L.EPS_MEMORY, injected[2 * i], injected[2 * i + 1]
+        else:
+            eps_mode, e_w, e_b = L.EPS_PHILOX, None, None
+        call = LayerCall(n_samples=n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
+                         eps_mode=eps_mode, seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
+                         want_stats=want_stats, y_dtype=torch.float32 if last else hidden_dtype)
+        p = (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)
+        if differentiable:
+            if sp.lr:
+                h, kl3 = LRLinearFn.apply(h, *p, e_w, e_b, call)
+                stats.append(kl3)
+            else:
+                h, lp, lq = BBBLinearFn.apply(h, *p, e_w, e_b, call)
+                stats.append((lp, lq))
+        else:
+            pd = tuple(t.detach() for t in p)
+            if sp.lr:
+                out = ops.lr_linear_fwd(h, *pd, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
+                                        relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_act=e_w, eps_b=e_b,
+                                        seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
+                                        want_kl=want_stats)
+            else:
+                out = ops.bbb_linear_fwd(h, *pd, n_samples=n_local, prior=call.prior, math_mode=math_mode,
+                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_w=e_w, eps_b=e_b,
+                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
+                                         want_stats=want_stats)
+            h = out["y"]
+            stats.append(out["workspace"])
+    return h, stats
+
+
+def eps_shapes(layers: Sequence[LayerSpec], batch: int) -> List[Tuple[int, ...]]:
+    shapes = []
+    for sp in layers:
+        fin, fout = sp.in_out
+        shapes += [(batch, fout) if sp.lr else (fout, fin), (fout,)]
+    return shapes
+
+
+def collect_injected(layers: Sequence[LayerSpec], batch: int, n_samples: int, device):
+    """Identical-eps seam.  If any layer's `.normal` attribute was replaced (the way the
+    reference's draws are stubbed, networks.py:35/:100) call it in the reference's order and
+    stack per tensor; if BNN_HIP_EPS=host draw from torch's CPU generator; else None
+    (on-chip Philox)."""
+    stubbed = any(sp.m._eps_stubbed() for sp in layers)
+    if not stubbed and not state.host_eps:
+        return None
+    shapes = eps_shapes(layers, batch)
+    if not stubbed:
+        return _host_eps(shapes, n_samples, device)
+    per_sample = []
+    for _ in range(n_samples):
+        row = []
+        for i, sp in enumerate(layers):
+            row += sp.m._draw_eps(shapes[2 * i], shapes[2 * i + 1])
+        per_sample.append(row)
+    return [torch.stack([per_sample[s][j].float() for s in range(n_samples)]).to(device).contiguous()
+            for j in range(len(shapes))]
+
+
+def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tensor, samples: int, *, mode: str,
+               sigma: float, local_reparam: bool):
+    """The per-evaluation sums every ELBO variant needs, sharded over ranks when enabled.
+
+    Returns (sum_a, sum_b, sum_nll, n_total) as 0-dim fp32 tensors with
+    sum_a = sum_s log p (BBB) or sum_s KL (LR), sum_b = sum_s log q (BBB) or 0."""
+    rank, world = dist_info()
+    first_global = take_samples(samples)
+    lo, n_local = shard_range(samples, rank, world)
+    dev = x.device
+    differentiable = torch.is_grad_enabled() and any(
+        p.requires_grad for sp in layers for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    if n_local == 0:
+        sums = torch.stack([zero, zero, zero])
+    else:
+        B = x.shape[0]
+        injected = collect_injected(layers, B, samples, dev)
+        if injected is not None and world > 1:
+            injected = [t[lo:lo + n_local].contiguous() for t in injected]
+        logits, stats = run_layers(layers, x, n_local, first_global + lo, want_stats=True, sample=True,
+                                   injected=injected, differentiable=differentiable)
+        if differentiable:
+            nll = NLLFn.apply(logits, target, mode, float(sigma))
+            if local_reparam:
+                kl = stats[0][0]
+                for k3 in stats[1:]:
+                    kl = kl + k3[0]                       # networks.py:181: l1 + l2 + l3
+                a, b = kl * n_local, zero
+            else:
+                lp = stats[0][0]
+                lq = stats[0][1]
+                for (p_, q_) in stats[1:]:
+                    lp, lq = lp + p_, lq + q_              # networks.py:174-178
+                a, b = lp.sum(), lq.sum()
+            sums = torch.stack([a, b, nll.sum()])
+        else:
+            fin = ops.elbo_finalize(workspaces=stats, layer_in=[sp.in_out[0] for sp in layers],
+                                    layer_out=[sp.in_out[1] for sp in layers], local_reparam=local_reparam,
+                                    prior=layers[0].m._prior_spec, n_samples=n_local, logits=logits, target=target,
+                                    mode=mode, nll_sigma=float(sigma))
+            if local_reparam:
+                sums = torch.stack([fin["kl"].sum(), zero, fin["nll"].sum()])
+            else:
+                sums = torch.stack([fin["log_prior"].sum(), fin["log_q"].sum(), fin["nll"].sum()])
+    if world > 1:
+        sums = AllReduceSumFn.apply(sums)
+    return sums[0], sums[1], sums[2], samples
+
+
+class GraphedElbo:
+    """One forward-only ELBO evaluation (all local MC samples: one launch per layer + the
+    finalize launch) captured once as a hipGraph and replayed.  The Philox sample index has
+    a device-resident part (`counter`) that the finalize kernel advances by the GLOBAL
+    sample count, so every replay draws fresh epsilon without re-capturing.
+
+    `replay()` returns the static float32[4] tensor {sum log p | sum KL, sum log q | 0,
+    sum nll, n_local}: the vector a sharded job all-reduces."""
+
+    def __init__(self, net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0,
+                 capture: bool = True):
+        self.net, self.samples, self.sigma = net, int(samples), float(sigma)
+        self.rank, self.world = dist_info()
+        self.lo, self.n_local = shard_range(self.samples, self.rank, self.world)
+        if self.n_local <= 0:
+            raise ops.BnnHipError("GraphedElbo: this rank owns no MC sample (samples < world size)")
+        self.specs = net._specs()
+        self.lr = bool(net.local_reparam)
+        dev = x.device
+        self.x = net._flat(x).contiguous()
+        self.target = target.contiguous()
+        first = take_samples(0)
+        self.counter = torch.tensor([first], dtype=torch.int32, device=dev)
+        S = self.n_local
+        B = self.x.shape[0]
+        math_mode = state.math
+        hid = torch.float32 if math_mode == L.MATH_F32 else torch.bfloat16
+        self.bufs, self.ws = [], []
+        for i, sp in enumerate(self.specs):
+            fin, fout = sp.in_out
+            last = i == len(self.specs) - 1
+            self.bufs.append(torch.empty((S, B, fout), dtype=torch.float32 if last else hid, device=dev))
+            self.ws.append(ops.lr_workspace(fout, dev) if self.lr else ops.bbb_workspace(S, fout, dev))
+        keys = ("kl",) if self.lr else ("log_prior", "log_q")
+        self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
+        self.sums = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.graph = None
+        self._enqueue()                      # warm-up (also validates arguments eagerly)
+        torch.cuda.synchronize()
+        if capture:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self._enqueue()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = g
+
+    def _enqueue(self):
+        math_mode = state.math
+        h = self.x
+        for i, sp in enumerate(self.specs):
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
+                          eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
+                          sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i])
+            if self.lr:
+                ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, **common)
+            else:
+                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, **common)
+            h = self.bufs[i]
+        ops.elbo_finalize(workspaces=self.ws, layer_in=[sp.in_out[0] for sp in self.specs],
+                          layer_out=[sp.in_out[1] for sp in self.specs], local_reparam=self.lr,
+                          prior=self.specs[0].m._prior_spec, n_samples=self.n_local, logits=h, target=self.target,
+                          mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                          sample_counter_inc=self.samples, out=self.out, sums=self.sums)
+
+    def replay(self) -> torch.Tensor:
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        take_samples(self.samples)           # keep the host-side counter in step
+        return self.sums
+
+    @property
+    def logits(self) -> torch.Tensor:
+        return self.bufs[-1]

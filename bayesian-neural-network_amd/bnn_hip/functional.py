@@ -1,0 +1,224 @@
+"""autograd bridges for the hot path.
+
+Forward = the HIP kernels (K1/K3/K4).  Backward = the closed-form gradients of
+SURVEY A.5, evaluated with device tensor ops on eps REGENERATED from the Philox counter
+map (nothing weight-sized is kept alive between forward and backward except in the
+identical-eps parity mode).  Hand-written backward kernels are the next scope row (F1);
+the formulas here are the ones they will implement and are pinned by golden G5 grads.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import PriorSpec
+
+
+@dataclass(frozen=True)
+class LayerCall:
+    """Static (non-tensor) description of one layer launch."""
+    n_samples: int
+    prior: PriorSpec
+    math_mode: int
+    relu: bool
+    eps_mode: int
+    seed: int
+    layer_id: int
+    sample_offset: int
+    want_stats: bool
+    y_dtype: torch.dtype = torch.float32
+
+
+def _naive_softplus(rho):
+    return torch.log1p(torch.exp(rho))
+
+
+class BBBLinearFn(torch.autograd.Function):
+    """(x, w_mu, w_rho, b_mu, b_rho, eps_w|None, eps_b|None) -> (y[S,B,N], log_prior[S], log_q[S])."""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, call: LayerCall):
+        out = ops.bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, n_samples=call.n_samples, prior=call.prior,
+                                 math_mode=call.math_mode, relu=call.relu, y_dtype=call.y_dtype,
+                                 eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
+                                 layer_id=call.layer_id, sample_offset=call.sample_offset,
+                                 want_stats=call.want_stats, want_scalars=call.want_stats)
+        y = out["y"]
+        ctx.call = call
+        ctx.save_for_backward(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, y if call.relu else None)
+        if call.want_stats:
+            return y, out["log_prior"], out["log_q"]
+        z1 = torch.zeros(call.n_samples, dtype=torch.float32, device=y.device)
+        z2 = torch.zeros(call.n_samples, dtype=torch.float32, device=y.device)
+        ctx.mark_non_differentiable(z1, z2)
+        return y, z1, z2
+
+    @staticmethod
+    def backward(ctx, gy, glp, glq):
+        call: LayerCall = ctx.call
+        x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, y = ctx.saved_tensors
+        S = call.n_samples
+        N, K = w_mu.shape
+        dev = w_mu.device
+        if call.eps_mode == L.EPS_PHILOX:
+            eps_w = ops.philox_normal(call.seed, call.layer_id * 4 + 0, call.sample_offset, S, N, K, dev)
+            eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)
+        elif call.eps_mode == L.EPS_ZERO:
+            eps_w = torch.zeros((S, N, K), device=dev)
+            eps_b = torch.zeros((S, N), device=dev)
+        else:
+            eps_w, eps_b = eps_w.view(S, N, K), eps_b.view(S, N)
+        g = gy.float()
+        if call.relu:
+            g = g * (y > 0).to(g.dtype)
+        sig_w, sig_b = _naive_softplus(w_rho), _naive_softplus(b_rho)
+        W = w_mu + sig_w * eps_w                                   # [S,N,K]
+        bvec = b_mu + sig_b * eps_b                                # [S,N]
+        x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
+        gW = torch.matmul(g.transpose(1, 2), x3)                   # [S,N,K]
+        gb = g.sum(1)                                              # [S,N]
+        if call.want_stats and glp is not None:
+            pr = call.prior
+            if pr.mixture:
+                def dlogp(w):
+                    n1 = pr.pi * torch.exp(-w * w / (2 * pr.sigma1 ** 2)) / pr.sigma1
+                    n2 = (1 - pr.pi) * torch.exp(-w * w / (2 * pr.sigma2 ** 2)) / pr.sigma2
+                    return -w * (n1 / pr.sigma1 ** 2 + n2 / pr.sigma2 ** 2) / (n1 + n2)
+            else:
+                def dlogp(w):
+                    return -w / (pr.sigma_p ** 2)
+            gW = gW + glp.view(S, 1, 1) * dlogp(W)
+            gb = gb + glp.view(S, 1) * dlogp(bvec)
+        g_wmu = gW.sum(0)
+        g_wsig = (gW * eps_w).sum(0)
+        g_bmu = gb.sum(0)
+        g_bsig = (gb * eps_b).sum(0)
+        if call.want_stats and glq is not None:
+            c = glq.sum()
+            g_wsig = g_wsig - c / sig_w                            # d(log q)/d(sigma) = -1/sigma
+            g_bsig = g_bsig - c / sig_b
+        g_wrho = g_wsig * torch.sigmoid(w_rho)
+        g_brho = g_bsig * torch.sigmoid(b_rho)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(g, W)                                # [S,B,K]
+            if x.dim() == 2:
+                gx = gx.sum(0)
+            gx = gx.to(x.dtype)
+        return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
+
+
+class LRLinearFn(torch.autograd.Function):
+    """(x, M[in,out], rho, b_mu, b_rho, eps_act|None, eps_b|None) -> (y[S,B,N], kl3[3])."""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, call: LayerCall):
+        out = ops.lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, n_samples=call.n_samples,
+                                sigma_p=call.prior.sigma_p, math_mode=call.math_mode, relu=call.relu,
+                                y_dtype=call.y_dtype, eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b,
+                                seed=call.seed, layer_id=call.layer_id, sample_offset=call.sample_offset,
+                                want_kl=call.want_stats, want_scalars=call.want_stats)
+        y = out["y"]
+        ctx.call = call
+        ctx.save_for_backward(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y if call.relu else None)
+        if call.want_stats:
+            return y, out["kl3"]
+        z = torch.zeros(3, dtype=torch.float32, device=y.device)
+        ctx.mark_non_differentiable(z)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, gy, gkl3):
+        call: LayerCall = ctx.call
+        x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y = ctx.saved_tensors
+        S = call.n_samples
+        K, N = w_mu.shape
+        dev = w_mu.device
+        x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
+        B = x3.shape[1]
+        if call.eps_mode == L.EPS_PHILOX:
+            eps_act = ops.philox_normal(call.seed, call.layer_id * 4 + 2, call.sample_offset, S, B, N, dev)
+            eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)
+        elif call.eps_mode == L.EPS_ZERO:
+            eps_act = torch.zeros((S, B, N), device=dev)
+            eps_b = torch.zeros((S, N), device=dev)
+        else:
+            eps_act, eps_b = eps_act.view(S, B, N), eps_b.view(S, N)
+        g = gy.float()
+        if call.relu:
+            g = g * (y > 0).to(g.dtype)
+        sig_w, sig_b = _naive_softplus(w_rho), _naive_softplus(b_rho)
+        s2 = sig_w * sig_w
+        xsq = x3 * x3
+        sd = torch.sqrt(torch.matmul(xsq, s2))                    # [S,B,N]
+        h = torch.where(sd > 0, g * eps_act / (2 * sd), torch.zeros_like(g))
+        g_M = torch.matmul(x3.transpose(1, 2), g).sum(0)          # [K,N]
+        g_s2 = torch.matmul(xsq.transpose(1, 2), h).sum(0)
+        g_sig = 2 * sig_w * g_s2
+        gsum = g.sum(1)                                           # [S,N]
+        g_bmu = gsum.sum(0)
+        g_bsig = (gsum * eps_b).sum(0)
+        if call.want_stats and gkl3 is not None:
+            sp2 = call.prior.sigma_p ** 2
+            # kl3 = (kl, weight_kl, bias_kl): weights see kl + weight_kl, biases kl + bias_kl
+            cw = gkl3[0] + gkl3[1]
+            cb = gkl3[0] + gkl3[2]
+            g_M = g_M + cw * w_mu / sp2
+            g_sig = g_sig + cw * (sig_w / sp2 - 1 / sig_w)
+            g_bmu = g_bmu + cb * b_mu / sp2
+            g_bsig = g_bsig + cb * (sig_b / sp2 - 1 / sig_b)
+        g_rho = g_sig * torch.sigmoid(w_rho)
+        g_brho = g_bsig * torch.sigmoid(b_rho)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(g, w_mu.t()) + 2 * x3 * torch.matmul(h, s2.t())
+            if x.dim() == 2:
+                gx = gx.sum(0)
+            gx = gx.to(x.dtype)
+        return gx, g_M, g_rho, g_bmu, g_brho, None, None, None
+
+
+class NLLFn(torch.autograd.Function):
+    """logits[S,B,C], target -> nll[S] via K4 (networks.py:183-190)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mode: str, sigma: float):
+        S = logits.shape[0]
+        out = ops.elbo_finalize(workspaces=[], layer_in=[], layer_out=[], local_reparam=False,
+                                prior=PriorSpec(), n_samples=S, logits=logits, target=target, mode=mode,
+                                nll_sigma=sigma)
+        ctx.mode, ctx.sigma = mode, sigma
+        ctx.save_for_backward(logits, target)
+        return out["nll"]
+
+    @staticmethod
+    def backward(ctx, gnll):
+        logits, target = ctx.saved_tensors
+        S = logits.shape[0]
+        if ctx.mode == "classification":
+            p = torch.softmax(logits.float(), dim=-1)
+            onehot = torch.zeros_like(p[0]).scatter_(1, target.view(-1, 1).to(torch.int64), 1.0)
+            g = (p - onehot.unsqueeze(0)) * gnll.view(S, 1, 1)
+        else:
+            g = (logits.float() - target.float().view(1, *logits.shape[1:])) / (ctx.sigma ** 2) * gnll.view(S, 1, 1)
+        return g.to(logits.dtype), None, None, None
+
+
+class AllReduceSumFn(torch.autograd.Function):
+    """Sum all-reduce of a small tensor over the default process group (RCCL on GPUs).  The
+    adjoint of y = sum_r x_r w.r.t. the local x_r is the identity on the (replicated) grad."""
+
+    @staticmethod
+    def forward(ctx, t):
+        import torch.distributed as dist
+        out = t.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g

@@ -1,0 +1,257 @@
+"""Thin tensor-level wrappers over the C ABI.  torch is used only for device memory and
+the current HIP stream; every operation here is one or two kernels of libbnn_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import BnnHipError
+
+
+@dataclass(frozen=True)
+class PriorSpec:
+    """Prior of a layer: Gaussian N(0, sigma_p) or the scale mixture of networks.py:14-27."""
+    mixture: bool = False
+    sigma_p: float = 1.0
+    pi: float = 0.5
+    sigma1: float = 1.0
+    sigma2: float = 1.0
+
+    @staticmethod
+    def from_init(prior_init: Sequence[float], mixture: bool) -> "PriorSpec":
+        if mixture:
+            assert len(prior_init) == 3, "Scale Mixture Prior requires three values in prior initialisation"
+            return PriorSpec(True, 1.0, float(prior_init[0]), math.exp(prior_init[1]), math.exp(prior_init[2]))
+        assert len(prior_init) == 1, "Gaussian Prior requires one value in prior initialisation"
+        return PriorSpec(False, float(prior_init[0]))
+
+    def c(self) -> L.Prior:
+        return L.Prior(L.PRIOR_MIXTURE if self.mixture else L.PRIOR_GAUSS, self.sigma_p, self.pi,
+                       self.sigma1, self.sigma2)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise BnnHipError(
+                "bnn_hip: the Bayes-by-backprop hot path runs on a ROCm device only (tensor is on "
+                f"{t.device}); there is no CPU fallback.  Move the module and its inputs to DEVICE.")
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise BnnHipError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise BnnHipError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _x3(x: torch.Tensor, n_samples: int):
+    """Returns (contiguous x, batch, in_features, per_sample)."""
+    if x.dim() == 2:
+        xs = x if x.is_contiguous() else x.contiguous()
+        return xs, x.shape[0], x.shape[1], 0
+    if x.dim() == 3:
+        if x.shape[0] != n_samples:
+            raise BnnHipError(f"x has {x.shape[0]} samples, expected {n_samples}")
+        xs = x if x.is_contiguous() else x.contiguous()
+        return xs, x.shape[1], x.shape[2], 1
+    raise BnnHipError(f"x must be [batch,in] or [samples,batch,in], got {tuple(x.shape)}")
+
+
+def bbb_workspace(n_samples: int, out_features: int, device) -> torch.Tensor:
+    nbytes = L.load().bnn_bbb_linear_fwd_workspace_bytes(n_samples, out_features)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def lr_workspace(out_features: int, device) -> torch.Tensor:
+    nbytes = L.load().bnn_lr_linear_fwd_workspace_bytes(out_features)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int,
+                   relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
+                   layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
+                   want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
+                   out=None):
+    """K1.  Returns dict(y, workspace, log_prior, log_q, eps_w, eps_b)."""
+    lib = L.load()
+    require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
+    w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
+    b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
+    N, K = w_mu.shape
+    xs, B, Kx, per_sample = _x3(x, n_samples)
+    if Kx != K or tuple(w_rho.shape) != (N, K) or tuple(b_mu.shape) != (N,) or tuple(b_rho.shape) != (N,):
+        raise BnnHipError(f"shape mismatch: x[...,{Kx}] weight {tuple(w_mu.shape)} bias {tuple(b_mu.shape)}")
+    dev = xs.device
+    y = out if out is not None else torch.empty((n_samples, B, N), dtype=y_dtype, device=dev)
+    if want_stats and workspace is None:
+        workspace = bbb_workspace(n_samples, N, dev)
+    lp = torch.empty(n_samples, dtype=torch.float32, device=dev) if want_scalars else None
+    lq = torch.empty(n_samples, dtype=torch.float32, device=dev) if want_scalars else None
+    if eps_mode == L.EPS_MEMORY:
+        eps_w, eps_b = _f32c(eps_w, "eps_w"), _f32c(eps_b, "eps_b")
+        if eps_w.numel() != n_samples * N * K or eps_b.numel() != n_samples * N:
+            raise BnnHipError("eps_w/eps_b must be [samples,out,in] / [samples,out]")
+    dw = torch.empty((n_samples, N, K), dtype=torch.float32, device=dev) if dump_eps else None
+    db = torch.empty((n_samples, N), dtype=torch.float32, device=dev) if dump_eps else None
+    a = L.BbbFwdArgs()
+    a.struct_bytes = C.sizeof(L.BbbFwdArgs)
+    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+    a.x, a.x_dtype, a.x_per_sample = xs.data_ptr(), _dt(xs), per_sample
+    a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+    a.eps_mode, a.math = eps_mode, math_mode
+    a.eps_w, a.eps_b = _ptr(eps_w) if eps_mode == L.EPS_MEMORY else None, _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
+    a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
+    a.sample_counter = _ptr(sample_counter)
+    a.eps_w_dump, a.eps_b_dump = _ptr(dw), _ptr(db)
+    a.prior = prior.c()
+    a.want_stats, a.relu = int(want_stats), int(relu)
+    a.workspace = _ptr(workspace) if want_stats else None
+    a.workspace_bytes = workspace.numel() * 4 if (want_stats and workspace is not None) else 0
+    a.log_prior, a.log_q = _ptr(lp), _ptr(lq)
+    a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
+    return dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
+
+
+def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
+                  y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
+                  sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
+                  dump_eps: bool = False, workspace=None, sample_counter=None, out=None):
+    """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
+    lib = L.load()
+    require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
+    w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
+    b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
+    K, N = w_mu.shape
+    xs, B, Kx, per_sample = _x3(x, n_samples)
+    if Kx != K or tuple(w_rho.shape) != (K, N) or tuple(b_mu.shape) != (N,) or tuple(b_rho.shape) != (N,):
+        raise BnnHipError(f"shape mismatch: x[...,{Kx}] weight {tuple(w_mu.shape)} bias {tuple(b_mu.shape)}")
+    dev = xs.device
+    y = out if out is not None else torch.empty((n_samples, B, N), dtype=y_dtype, device=dev)
+    if want_kl and workspace is None:
+        workspace = lr_workspace(N, dev)
+    kl3 = torch.empty(3, dtype=torch.float32, device=dev) if want_scalars else None
+    if eps_mode == L.EPS_MEMORY:
+        eps_act, eps_b = _f32c(eps_act, "eps_act"), _f32c(eps_b, "eps_b")
+        if eps_act.numel() != n_samples * B * N or eps_b.numel() != n_samples * N:
+            raise BnnHipError("eps_act/eps_b must be [samples,batch,out] / [samples,out]")
+    da = torch.empty((n_samples, B, N), dtype=torch.float32, device=dev) if dump_eps else None
+    db = torch.empty((n_samples, N), dtype=torch.float32, device=dev) if dump_eps else None
+    a = L.LrFwdArgs()
+    a.struct_bytes = C.sizeof(L.LrFwdArgs)
+    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+    a.x, a.x_dtype, a.x_per_sample = xs.data_ptr(), _dt(xs), per_sample
+    a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+    a.eps_mode, a.math = eps_mode, math_mode
+    a.eps_act = _ptr(eps_act) if eps_mode == L.EPS_MEMORY else None
+    a.eps_b = _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
+    a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
+    a.sample_counter = _ptr(sample_counter)
+    a.eps_act_dump, a.eps_b_dump = _ptr(da), _ptr(db)
+    a.sigma_p, a.want_kl, a.relu = float(sigma_p), int(want_kl), int(relu)
+    a.workspace = _ptr(workspace) if want_kl else None
+    a.workspace_bytes = workspace.numel() * 4 if (want_kl and workspace is not None) else 0
+    a.kl_out = _ptr(kl3)
+    a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    L.check(lib.bnn_lr_linear_fwd(C.byref(a), _stream()), "bnn_lr_linear_fwd")
+    return dict(y=y, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db)
+
+
+def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tensor:
+    """K2.  Returns float32[4] = (KL, sum log sigma, sum sigma^2, sum mu^2) on the device."""
+    lib = L.load()
+    require_device(mu, rho)
+    mu, rho = _f32c(mu, "mu"), _f32c(rho, "rho")
+    if mu.numel() != rho.numel():
+        raise BnnHipError("mu and rho must have the same number of elements")
+    n = mu.numel()
+    ws = torch.empty(lib.bnn_gauss_kl_workspace_bytes(n) // 4, dtype=torch.float32, device=mu.device)
+    out = torch.empty(4, dtype=torch.float32, device=mu.device)
+    L.check(lib.bnn_gauss_kl(mu.data_ptr(), rho.data_ptr(), n, float(sigma_p), ws.data_ptr(), ws.numel() * 4,
+                             out.data_ptr(), _stream()), "bnn_gauss_kl")
+    return out
+
+
+def elbo_finalize(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
+                  logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
+                  nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None):
+    """K4.  Returns dict(log_prior, log_q, kl, nll): float32[n_samples] tensors (or None)."""
+    lib = L.load()
+    n_layers = len(workspaces)
+    dev = logits.device if logits is not None else workspaces[0].device
+    a = L.FinalizeArgs()
+    a.struct_bytes = C.sizeof(L.FinalizeArgs)
+    a.n_layers, a.local_reparam, a.n_samples = n_layers, int(local_reparam), n_samples
+    for i, (w, ki, ko) in enumerate(zip(workspaces, layer_in, layer_out)):
+        require_device(w)
+        a.layer_workspace[i] = w.data_ptr()
+        a.layer_in[i], a.layer_out[i] = ki, ko
+    a.prior = prior.c()
+    out = dict(out) if out is not None else dict(log_prior=None, log_q=None, kl=None, nll=None)
+    preset = {k for k, v in out.items() if v is not None}
+    if n_layers:
+        for key in (("kl",) if local_reparam else ("log_prior", "log_q")):
+            if key not in preset:
+                out[key] = torch.empty(n_samples, dtype=torch.float32, device=dev)
+    keep = []
+    if logits is not None:
+        require_device(logits, target)
+        lg = _f32c(logits, "logits")
+        S, B, Cc = lg.shape
+        if S != n_samples:
+            raise BnnHipError("logits must be [samples,batch,classes]")
+        if mode == "classification":
+            tg = target.to(torch.int64).contiguous()
+            if tg.numel() != B:
+                raise BnnHipError("classification target must have `batch` elements")
+            a.nll_mode = L.NLL_CLASSIFICATION
+        elif mode == "regression":
+            tg = _f32c(target.to(torch.float32), "target")
+            if tg.numel() != B * Cc:
+                raise BnnHipError("regression target must match the output shape")
+            a.nll_mode = L.NLL_REGRESSION
+        else:
+            raise Exception("Training mode must be either 'regression' or 'classification'")
+        keep += [lg, tg]
+        a.batch, a.classes = B, Cc
+        a.logits, a.target, a.nll_sigma = lg.data_ptr(), tg.data_ptr(), float(nll_sigma)
+        if "nll" not in preset:
+            out["nll"] = torch.empty(n_samples, dtype=torch.float32, device=dev)
+    a.sample_counter, a.sample_counter_inc = _ptr(sample_counter), int(sample_counter_inc)
+    a.sums = _ptr(sums)
+    a.log_prior, a.log_q, a.kl, a.nll = _ptr(out["log_prior"]), _ptr(out["log_q"]), _ptr(out["kl"]), _ptr(out["nll"])
+    L.check(lib.bnn_elbo_finalize(C.byref(a), _stream()), "bnn_elbo_finalize")
+    return out
+
+
+def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int, rows: int, cols: int,
+                  device) -> torch.Tensor:
+    """The on-chip epsilon stream, materialised: float32[n_samples, rows, cols]."""
+    lib = L.load()
+    if torch.device(device).type != "cuda":
+        raise BnnHipError("bnn_hip.philox_normal needs a ROCm device")
+    eps = torch.empty((n_samples, rows, cols), dtype=torch.float32, device=device)
+    L.check(lib.bnn_philox_normal(eps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, tensor_id, sample_offset & 0xFFFFFFFF,
+                                  n_samples, rows, cols, _stream()), "bnn_philox_normal")
+    return eps

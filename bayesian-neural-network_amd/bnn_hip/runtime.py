@@ -1,0 +1,72 @@
+"""Process-wide knobs of the HIP path.  The reference's constructors take no such
+arguments (networks.py:50, :92, :142), so build-side settings live here and in env vars:
+
+  BNN_HIP_MATH   bf16 (default; bf16 MFMA operands, fp32 accumulate, fp32 statistics)
+                 f32  (exact fp32 MFMA; the parity mode)
+  BNN_HIP_SEED   64-bit Philox key (default 2026)
+  BNN_HIP_EPS    device (default; on-chip Philox)  |  host (draw eps with torch's CPU
+                 generator in the reference's order, networks.py:42, then copy H2D)
+"""
+from __future__ import annotations
+
+import os
+import threading
+
+from . import _lib as L
+
+_lock = threading.Lock()
+
+
+class _State:
+    def __init__(self):
+        self.math = L.MATH_F32 if os.environ.get("BNN_HIP_MATH", "bf16").lower() in ("f32", "fp32", "float32") \
+            else L.MATH_BF16
+        self.seed = int(os.environ.get("BNN_HIP_SEED", "2026"))
+        self.host_eps = os.environ.get("BNN_HIP_EPS", "device").lower() == "host"
+        self.counter = 0            # next unused GLOBAL MC sample index
+        self.shard_samples = False  # split MC samples over torch.distributed ranks
+
+
+state = _State()
+
+
+def set_math(mode: str):
+    """'bf16' or 'f32'."""
+    m = mode.lower()
+    if m in ("bf16", "bfloat16"):
+        state.math = L.MATH_BF16
+    elif m in ("f32", "fp32", "float32"):
+        state.math = L.MATH_F32
+    else:
+        raise ValueError(f"unknown math mode {mode!r}")
+
+
+def get_math() -> str:
+    return "bf16" if state.math == L.MATH_BF16 else "f32"
+
+
+def manual_seed(seed: int, counter: int = 0):
+    """Re-key the on-chip epsilon stream and rewind the global MC sample counter."""
+    with _lock:
+        state.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        state.counter = int(counter)
+
+
+def take_samples(n: int) -> int:
+    """Reserve n consecutive global MC sample indices; returns the first.  Every rank of a
+    sharded job calls this with the same GLOBAL n so the counters stay in step."""
+    with _lock:
+        first = state.counter
+        state.counter = (state.counter + int(n)) & 0xFFFFFFFF
+        return first
+
+
+def set_host_eps(flag: bool):
+    state.host_eps = bool(flag)
+
+
+def shard_samples(flag: bool = True):
+    """Split the MC samples of sample_elbo*/predict over the ranks of the default
+    torch.distributed group (RCCL on GPUs); the only collective is a sum all-reduce of the
+    ELBO scalars."""
+    state.shard_samples = bool(flag)

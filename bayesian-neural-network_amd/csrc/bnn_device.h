@@ -1,0 +1,103 @@
+// Device-side building blocks shared by the gfx950 kernels: Philox4x32-10 + Box-Muller
+// (the frozen epsilon map of include/bnn_hip.h), fp32 softplus/log on the hardware
+// transcendental units, wave64 and block reductions, MFMA fragment types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bnn {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+constexpr int kWave = 64;
+constexpr float kC0 = -0.918938533204672742f;  // -log(sqrt(2 pi)), networks.py:46
+constexpr float kLn2 = 0.693147180559945309f;
+constexpr float kLog2e = 1.442695040888963407f;
+
+// ---------------------------------------------------------------------------- Philox
+// One round = two 32x32->64 multiplies (v_mad_u64_u32 / v_mul_hi_u32 + v_mul_lo_u32) and
+// four xors; the key schedule is wave-uniform and lives on the scalar unit.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)c.x * 0xD2511F53u;
+    const uint64_t p1 = (uint64_t)c.z * 0xCD9E8D57u;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// uint32 -> (0,1]: one v_cvt_f32_u32 + one v_fma_f32.
+__device__ __forceinline__ float u01(uint32_t r) {
+  return __builtin_fmaf((float)r, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+
+// Box-Muller on the transcendental unit: v_log_f32 is log2, v_sin/v_cos_f32 take their
+// argument in revolutions, so 2*pi*u needs no multiply.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = u01(a), u2 = u01(b);
+  const float rad = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// The four N(0,1) values of epsilon group `group` (see include/bnn_hip.h).
+__device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample, uint32_t tensor_id,
+                                               uint32_t k0, uint32_t k1, float out[4]) {
+  const uint4 r = philox4x32_10(make_uint4(group, gsample, tensor_id, 0u), k0, k1);
+  box_muller(r.x, r.y, out[0], out[1]);
+  box_muller(r.z, r.w, out[2], out[3]);
+}
+
+// ---------------------------------------------------------------------------- math
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+
+// sigma = log1p(exp(rho)) (networks.py:39), no threshold trick: +inf once exp overflows,
+// 0 once it underflows, like the reference.  log1p(e) = log(u) * e / (u - 1), u = 1 + e,
+// recovers the bits that forming 1 + e drops when e is small (rho ~ -5).
+__device__ __forceinline__ float softplus(float rho) {
+  const float e = fast_exp(rho);
+  const float u = 1.0f + e;
+  const float d = u - 1.0f;
+  const float lg = fast_log(u);
+  float s = lg * (e * __builtin_amdgcn_rcpf(d));
+  s = (d == 0.0f) ? e : s;
+  s = (u > 3.0e38f) ? u : s;   // exp overflowed: +inf (d = inf would give inf * (inf/inf))
+  return s;
+}
+
+// ---------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Sum `v` over the block; result valid in thread 0.  `scratch` holds >= blockDim.x/64 Ts.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  T tot = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) tot += scratch[w];
+  return tot;
+}
+
+}  // namespace bnn

@@ -1,0 +1,256 @@
+/*
+ * bnn_hip.h — C ABI of libbnn_hip.so: the MI355X (gfx950) kernels behind the
+ * Bayes-by-backprop hot path of tennisonliu/bayesian-neural-network.
+ *
+ * The reference has no FFI of its own: its boundary is the Python nn.Module surface of
+ * networks.py.  This header is the build-side boundary underneath that surface; every
+ * entry point names the reference lines (paths relative to the reference tree) whose
+ * arithmetic it replaces.  Callers: bayesian-neural-network_amd/bnn_hip/_lib.py (ctypes).
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *   - Return int: 0 = BNN_OK, <0 = argument error (enum below), >0 = a hipError_t.
+ *   - Every pointer is a caller-owned DEVICE pointer (contiguous, row-major, fp32 unless a
+ *     dtype field says otherwise).  The library never allocates, frees, copies, synchronises
+ *     or retains a pointer: launch functions only enqueue kernels on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream), so they are hipGraph-capturable.
+ *   - Workspaces are caller-allocated; sizes come from the *_workspace_bytes queries.
+ *   - Re-entrant for distinct streams/buffers; no global mutable state.
+ *   - Structs start with `struct_bytes` = sizeof(the struct) as the caller compiled it;
+ *     a mismatch returns BNN_ERR_ABI.
+ *
+ * Epsilon generator (frozen; results must not depend on tiling, launch shape or #GPUs)
+ *   Philox4x32-10 (Salmon et al. 2011; the generator behind rocRAND's PHILOX4_32_10) keyed
+ *   by the 64-bit seed.  For an epsilon tensor of logical shape [rows, cols] belonging to
+ *   GLOBAL MC sample index g (= sample_offset + local sample), tensor id
+ *   t = 4*layer_id + kind  (kind 0: BBB weight eps [out,in]; 1: bias eps [1,out];
+ *   2: LR activation eps [batch,out]):
+ *       group  = row * ceil(cols/4) + (col >> 2)           (uint32)
+ *       counter = (group, g, t, 0), key = (seed_lo, seed_hi)
+ *       (r0,r1,r2,r3) = Philox4x32-10(counter, key)
+ *       u(r) = fma((float)r, 2^-32, 2^-33)                  in (0,1]
+ *       slot 0,1 = sqrt(-2 ln u(r0)) * {cos, sin}(2 pi u(r1)); slot 2,3 likewise from r2,r3
+ *       eps[row, col] = slot (col & 3)
+ *   oracle/bnn_oracle.py:philox_normal restates this on the CPU.
+ */
+#ifndef BNN_HIP_H_
+#define BNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNN_HIP_ABI_VERSION 1
+
+enum bnn_status {
+  BNN_OK = 0,
+  BNN_ERR_NULL = -1,        /* required pointer is NULL */
+  BNN_ERR_SHAPE = -2,       /* non-positive or unsupported dimension */
+  BNN_ERR_ENUM = -3,        /* unknown dtype / mode / prior kind */
+  BNN_ERR_WORKSPACE = -4,   /* workspace missing or too small */
+  BNN_ERR_ABI = -5,         /* struct_bytes mismatch */
+  BNN_ERR_ALIGN = -6        /* pointer not aligned to its element type */
+};
+
+enum bnn_dtype { BNN_F32 = 0, BNN_BF16 = 1 };
+
+/* Arithmetic of the matmul.  BNN_MATH_F32: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, a
+ * k-ordered fmaf chain) — the parity mode.  BNN_MATH_BF16: operands rounded to bf16 (RNE),
+ * fp32 accumulate (v_mfma_f32_16x16x32_bf16) — the throughput mode.  Statistics (log-probs,
+ * KL) are always formed in fp32 from the un-rounded fp32 weights. */
+enum bnn_math { BNN_MATH_F32 = 0, BNN_MATH_BF16 = 1 };
+
+enum bnn_eps_mode {
+  BNN_EPS_PHILOX = 0,   /* generated on chip (map above); never touches HBM */
+  BNN_EPS_MEMORY = 1,   /* read from eps_* buffers: identical-eps parity with the reference */
+  BNN_EPS_ZERO = 2      /* eps = 0: w = mu (networks.py:78-79, eval & sample=False) */
+};
+
+enum bnn_prior_kind {
+  BNN_PRIOR_GAUSS = 0,    /* Normal(0, sigma_p)                 networks.py:67-68 */
+  BNN_PRIOR_MIXTURE = 1   /* pi N(0,sigma1) + (1-pi) N(0,sigma2) networks.py:14-27 */
+};
+
+enum bnn_nll_mode { BNN_NLL_REGRESSION = 0, BNN_NLL_CLASSIFICATION = 1 };
+
+typedef struct bnn_prior {
+  int32_t kind;      /* bnn_prior_kind */
+  float sigma_p;     /* Gaussian prior scale (prior_init[0])            */
+  float pi;          /* mixture weight       (prior_init[0] if mixture) */
+  float sigma1;      /* exp(prior_init[1])                              */
+  float sigma2;      /* exp(prior_init[2])                              */
+} bnn_prior;
+
+/* ------------------------------------------------------------------------------------
+ * K1  bnn_bbb_linear_fwd — BayesianLinear.forward for n_samples MC samples in ONE launch.
+ * Replaces networks.py:73-88 (+ :39-46 GaussianNode, :14-27 / :67-68 priors) and the
+ * serial MC loop over it (networks.py:199-200) for one layer:
+ *     w_s = mu + softplus(rho) * eps_s       (per weight and bias, never stored)
+ *     y_s = x_s . w_s^T + b_s  [-> ReLU]     (networks.py:88, :169-171)
+ *     stats partials for log p(w_s), log q(w_s)   (networks.py:82-83)
+ * Shapes: x [x_samples, batch, in] (x_samples = n_samples if x_per_sample else 1);
+ * w_mu,w_rho [out,in]; b_mu,b_rho [out]; eps_w [n_samples,out,in]; eps_b [n_samples,out];
+ * y [n_samples, batch, out].
+ *
+ * Stats workspace (want_stats != 0): float[n_samples][T][4], T = ceil(out/16); entry
+ * (s,t) holds for the 16 output features of tile t (weights + their biases):
+ *   [0] sum eps^2   [1] sum w^2 (Gaussian prior) or sum log p_mix(w) (mixture prior)
+ *   [2] sum log sigma (only in s = 0; it does not depend on eps)   [3] 0
+ * If log_prior/log_q are non-NULL a second tiny kernel reduces the partials to the
+ * layer's per-sample scalars float[n_samples] (the values BayesianLinear stores in
+ * self.log_prior / self.log_variational_posterior).
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_bbb_fwd_args {
+  uint32_t struct_bytes;
+  int32_t n_samples, batch, in_features, out_features;
+  const void* x;
+  int32_t x_dtype;          /* bnn_dtype */
+  int32_t x_per_sample;     /* 0: one x for all samples, 1: x[s] */
+  const float* w_mu;
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  int32_t eps_mode;         /* bnn_eps_mode */
+  int32_t math;             /* bnn_math */
+  const float* eps_w;       /* BNN_EPS_MEMORY only */
+  const float* eps_b;
+  uint64_t seed;            /* BNN_EPS_PHILOX */
+  uint32_t layer_id;
+  uint32_t sample_offset;   /* global MC index of local sample 0 (multi-GPU shards) */
+  const uint32_t* sample_counter; /* optional DEVICE word added to sample_offset at run time, so a
+                               captured hipGraph draws fresh eps on every replay (see K4) */
+  float* eps_w_dump;        /* optional: the eps actually used, [n_samples,out,in] */
+  float* eps_b_dump;        /* optional: [n_samples,out] */
+  bnn_prior prior;
+  int32_t want_stats;
+  int32_t relu;             /* fuse ReLU (networks.py:161,163) */
+  void* workspace;          /* stats partials, see above */
+  size_t workspace_bytes;
+  float* log_prior;         /* optional [n_samples] */
+  float* log_q;             /* optional [n_samples] */
+  void* y;
+  int32_t y_dtype;          /* bnn_dtype */
+  int32_t reserved;
+} bnn_bbb_fwd_args;
+
+size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
+int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  bnn_lr_linear_fwd — BayesianLinearLR.forward (networks.py:116-138) for n_samples
+ * MC samples in one launch: two MFMA GEMMs sharing the x tile,
+ *     m = x . M,   v = x^2 . softplus(rho)^2          (networks.py:120-121)
+ *     y = m + sqrt(v) * eps_act + (b_mu + softplus(b_rho) * eps_b)   (:123-128)
+ * with the closed-form KL(q||p) partial sums (networks.py:109-114, :134-136) taken from
+ * the same pass over (M, rho).  Weights are [in, out] (networks.py:95-96).
+ * eps_act [n_samples,batch,out], eps_b [n_samples,out].
+ * KL workspace (want_kl != 0): float[T][4], T = ceil(out/16):
+ *   [0] sum log sigma  [1] sum sigma^2  [2] sum mu^2  [3] 0   (weights + biases of tile t)
+ * kl_out (optional, float[3]) = {weight_kl + bias_kl, weight_kl, bias_kl}.
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_lr_fwd_args {
+  uint32_t struct_bytes;
+  int32_t n_samples, batch, in_features, out_features;
+  const void* x;
+  int32_t x_dtype;
+  int32_t x_per_sample;
+  const float* w_mu;        /* [in,out] */
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  int32_t eps_mode;
+  int32_t math;
+  const float* eps_act;
+  const float* eps_b;
+  uint64_t seed;
+  uint32_t layer_id;
+  uint32_t sample_offset;
+  const uint32_t* sample_counter; /* optional device word, as in bnn_bbb_fwd_args */
+  float* eps_act_dump;
+  float* eps_b_dump;
+  float sigma_p;            /* prior_init[0]; prior mean is 0 (networks.py:103-104) */
+  int32_t want_kl;
+  int32_t relu;
+  int32_t reserved;
+  void* workspace;
+  size_t workspace_bytes;
+  float* kl_out;
+  void* y;
+  int32_t y_dtype;
+  int32_t reserved2;
+} bnn_lr_fwd_args;
+
+size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
+int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  bnn_gauss_kl — one streaming pass over (mu, rho)[n]: the eps-independent sums of
+ * log q (networks.py:46, the -log sigma term) and the closed-form KL against
+ * Normal(0, sigma_p) (networks.py:113).  out = float[4]:
+ *   [0] KL = 0.5*sum(2 log(sigma_p/sigma) - 1 + (sigma/sigma_p)^2 + (mu/sigma_p)^2)
+ *   [1] sum log sigma   [2] sum sigma^2   [3] sum mu^2
+ * 8 algorithmic bytes per element; wavefront-shuffle + LDS block reduction, one partial
+ * per block, fp64 final sum by a second one-block kernel (no float atomics: bitwise
+ * reproducible).
+ * ---------------------------------------------------------------------------------- */
+size_t bnn_gauss_kl_workspace_bytes(int64_t n);
+int bnn_gauss_kl(const float* mu, const float* rho, int64_t n, float sigma_p, void* workspace,
+                 size_t workspace_bytes, float* out4, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  bnn_elbo_finalize — per-sample scalars of one ELBO evaluation in one launch:
+ * sums the stats partials of up to 8 BBB layers into log p / log q
+ * (networks.py:174-178), or the KL partials of LR layers (networks.py:180-181), and the
+ * NLL of the logits (networks.py:183-190: CrossEntropyLoss(reduction='sum') or the
+ * Gaussian NLL with scale nll_sigma).  Outputs float[n_samples] each; any may be NULL.
+ * For LR layers kl[] receives the same (eps-independent) value for every sample.
+ * target: int64[batch] (classification) or float[batch,classes] (regression).
+ * sample_counter: the launch functions bake their arguments into a captured hipGraph; the
+ * Philox sample index therefore has a device-resident part that the layer kernels read and
+ * this kernel (the last of an evaluation, stream-ordered after them) advances.
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_finalize_args {
+  uint32_t struct_bytes;
+  int32_t n_layers;                 /* 0..8 */
+  int32_t local_reparam;            /* 0: BBB stats workspaces, 1: LR KL workspaces */
+  int32_t n_samples, batch, classes;
+  const void* layer_workspace[8];
+  int32_t layer_in[8];
+  int32_t layer_out[8];
+  bnn_prior prior;
+  const float* logits;              /* [n_samples,batch,classes] fp32, or NULL */
+  const void* target;
+  int32_t nll_mode;                 /* bnn_nll_mode */
+  float nll_sigma;
+  float* log_prior;                 /* BBB */
+  float* log_q;                     /* BBB */
+  float* kl;                        /* LR  */
+  float* nll;
+  uint32_t* sample_counter;         /* optional device word: += sample_counter_inc when done */
+  uint32_t sample_counter_inc;      /* normally the GLOBAL number of MC samples of the evaluation */
+  uint32_t reserved;
+  float* sums;                      /* optional float[4]: sums over the n_samples local samples of
+                                       {log p | KL, log q | 0, nll, n_samples}: the vector a sharded
+                                       job all-reduces (one extra one-block kernel, fixed order) */
+} bnn_finalize_args;
+
+int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into
+ * eps[n_samples, rows, cols]: used by the backward pass to regenerate eps instead of
+ * storing it, and by tests to check the frozen counter->element map.
+ * ---------------------------------------------------------------------------------- */
+int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sample_offset,
+                      int32_t n_samples, int32_t rows, int32_t cols, void* stream);
+
+int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
+const char* bnn_status_string(int status); /* static string for a negative status */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNN_HIP_H_ */

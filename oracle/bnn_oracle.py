@@ -338,8 +338,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def _u01(r: np.ndarray) -> np.ndarray:
-    """uint32 -> (0,1]: r * 2^-32 + 2^-33 evaluated in fp32 (one fma on the device)."""
-    return (r.astype(np.float64) * 2.0 ** -32 + 2.0 ** -33).astype(np.float32)
+    """uint32 -> (0,1]: the device's v_cvt_f32_u32 (round to nearest even) followed by one
+    fp32 fma(r, 2^-32, 2^-33): the product+sum is exact in float64, then rounded once."""
+    return (r.astype(np.float32).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33).astype(np.float32)
 
 
 def box_muller(r0, r1):

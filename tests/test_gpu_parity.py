@@ -1,0 +1,384 @@
+"""GPU parity: the HIP path (through the drop-in networks.py and the C ABI) against
+(i) the golden vectors recorded from the real reference and (ii) the CPU oracle on
+identical epsilon.  Tolerances (fp32 path): outputs and scalars rtol 2e-5 — the target
+the north star states is rtol 1e-4 for KL/ELBO.  bf16-operand math: logits 3e-2 of the
+output scale, NLL 1e-3, complexity scalars (always fp32) 2e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bnn_hip
+from bnn_hip import _lib as L
+from bnn_hip import ops, synth
+from oracle import bnn_oracle as O
+
+F32_RTOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _f32_math():
+    bnn_hip.set_math("f32")
+    yield
+    bnn_hip.set_math("bf16")
+
+
+class Replay:
+    def __init__(self, arrays):
+        self.q = [torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a for a in arrays]
+
+    def sample(self, size):
+        t = self.q.pop(0)
+        assert tuple(t.shape) == tuple(size)
+        return t
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=F32_RTOL, atol=0.0):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    np.testing.assert_allclose(a, np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def make_bbb(c, dev):
+    import networks
+    fout, fin = c["weight_mu"].shape
+    layer = networks.BayesianLinear(fin, fout, [-0.2, 0.2], [-5, -4], list(c["prior_init"]), bool(c["mixture"]))
+    layer.load_state_dict({k: t(c[k]) for k in synth.PARAM_NAMES})
+    layer.to(dev)
+    layer.train(bool(c["train"]))
+    layer.weight.normal = Replay([c["eps_w"]])
+    layer.bias.normal = Replay([c["eps_b"]])
+    return layer
+
+
+def make_lr(c, dev):
+    import networks
+    fin, fout = c["weight_mu"].shape
+    layer = networks.BayesianLinearLR(fin, fout, [-0.2, 0.2], [-5, -4], [float(c["sigma_p"])])
+    layer.load_state_dict({k: t(c[k]) for k in synth.PARAM_NAMES})
+    layer.to(dev)
+    layer.train(bool(c["train"]))
+    layer.normal = Replay([c["eps_act"], c["eps_b"]])
+    return layer
+
+
+def run_bbb_case(c, dev, y_rtol=F32_RTOL, y_atol=2e-5, s_rtol=F32_RTOL):
+    layer = make_bbb(c, dev)
+    with torch.no_grad():
+        y = layer(t(c["x"]).to(dev), bool(c["sample"]), bool(c["clp"]))
+    close(y, c["y"], rtol=y_rtol, atol=y_atol)
+    if int(c["log_prior_is_int"]):
+        assert isinstance(layer.log_prior, int) and layer.log_prior == 0
+        assert isinstance(layer.log_variational_posterior, int) and layer.log_variational_posterior == 0
+    else:
+        assert layer.log_prior.dim() == 0 and layer.log_variational_posterior.dim() == 0
+        close(layer.log_prior, c["log_prior"], rtol=s_rtol)
+        close(layer.log_variational_posterior, c["log_q"], rtol=s_rtol)
+
+
+# ------------------------------------------------------------------ epsilon generator
+def test_philox_matches_cpu_restatement(dev):
+    for (tid, s0, S, rows, cols) in [(0, 0, 2, 5, 37), (9, 1000, 1, 16, 8), (2, 7, 3, 1, 10), (4, 0, 1, 130, 1201)]:
+        e = ops.philox_normal(2026, tid, s0, S, rows, cols, dev).cpu().numpy()
+        for s in range(S):
+            np.testing.assert_allclose(e[s], O.philox_normal(2026, tid, s0 + s, rows, cols), atol=5e-5, rtol=0)
+    big = ops.philox_normal(12345678901234567, 5, 0, 1, 1200, 1200, dev)
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1.0) < 3e-3
+    assert torch.isfinite(big).all()
+
+
+# ------------------------------------------------------------------ K1 against the reference's vectors
+def test_k1_g1_g2_gaussian_and_mixture(g_layers, dev):
+    for g in ("G1", "G2"):
+        for name in g_layers.cases(g):
+            run_bbb_case(g_layers.case(name), dev)
+
+
+def test_k1_g3_mode_truth_table(g_layers, dev):
+    for name in g_layers.cases("G3"):
+        run_bbb_case(g_layers.case(name), dev)
+
+
+def test_k1_g7_odd_shapes(g_layers, dev):
+    names = [n for n in g_layers.cases("G7") if "lr" not in n.split("/")[-1]]
+    assert len(names) == 14
+    for name in names:
+        run_bbb_case(g_layers.case(name), dev, y_rtol=1e-4, y_atol=2e-4)
+
+
+def test_k1_bf16_math_tolerance(g_layers, dev):
+    bnn_hip.set_math("bf16")
+    for name in g_layers.cases("G7"):
+        if "lr" in name.split("/")[-1]:
+            continue
+        c = g_layers.case(name)
+        scale = float(np.abs(c["y"]).max())
+        layer = make_bbb(c, dev)
+        with torch.no_grad():
+            y = layer(t(c["x"]).to(dev))
+        close(y, c["y"], rtol=0, atol=3e-2 * scale)
+        close(layer.log_prior, c["log_prior"])                       # statistics stay fp32
+        close(layer.log_variational_posterior, c["log_q"])
+
+
+def test_k1_identity_input_catches_transposes(dev):
+    """x = I (asymmetric W): y must equal W^T + b exactly in fp32 math."""
+    import networks
+    fin, fout = 48, 40
+    layer = networks.BayesianLinear(fin, fout, [-1.0, 2.0], [-5, -4], [1.0], False).to(dev).eval()
+    with torch.no_grad():
+        y = layer(torch.eye(fin, device=dev))                         # eval & sample=False: w = mu
+    close(y, (layer.weight_mu.t() + layer.bias_mu).cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_k1_philox_mode_dump_and_oracle(dev):
+    """On-chip eps: the kernel's dumped eps equals the Philox map, and the outputs equal
+    the oracle evaluated on that dumped eps."""
+    rs = np.random.RandomState(3)
+    S, B, K, N = 3, 20, 72, 37
+    wmu, wrho = rs.uniform(-0.5, 0.5, (N, K)).astype(np.float32), rs.uniform(-5, -2, (N, K)).astype(np.float32)
+    bmu, brho = rs.uniform(-0.5, 0.5, N).astype(np.float32), rs.uniform(-5, -2, N).astype(np.float32)
+    x = rs.uniform(-1, 1, (B, K)).astype(np.float32)
+    prior = ops.PriorSpec(False, 0.8)
+    out = ops.bbb_linear_fwd(t(x).to(dev), t(wmu).to(dev), t(wrho).to(dev), t(bmu).to(dev), t(brho).to(dev),
+                             n_samples=S, prior=prior, math_mode=L.MATH_F32, relu=True, y_dtype=torch.float32,
+                             eps_mode=L.EPS_PHILOX, seed=99, layer_id=1, sample_offset=5, want_stats=True,
+                             want_scalars=True, dump_eps=True)
+    ew, eb = out["eps_w"].cpu().numpy(), out["eps_b"].cpu().numpy()
+    for s in range(S):
+        np.testing.assert_allclose(ew[s], O.philox_normal(99, O.tensor_id(1, 0), 5 + s, N, K), atol=5e-5, rtol=0)
+        np.testing.assert_allclose(eb[s], O.philox_normal(99, O.tensor_id(1, 1), 5 + s, 1, N)[0], atol=5e-5, rtol=0)
+        y, lp, lq = O.bbb_linear(t(x), t(wmu), t(wrho), t(bmu), t(brho), t(ew[s]), t(eb[s]), O.Prior(False, 0.8))
+        close(out["y"][s], torch.relu(y).numpy(), atol=2e-5)
+        close(out["log_prior"][s], float(lp))
+        close(out["log_q"][s], float(lq))
+    fill = ops.philox_normal(99, O.tensor_id(1, 0), 5, S, N, K, dev)
+    assert torch.equal(fill, out["eps_w"])                            # same code path, bitwise
+
+
+# ------------------------------------------------------------------ K3 / K2
+def test_k3_g4_lr_layer(g_layers, dev):
+    for name in g_layers.cases("G4"):
+        c = g_layers.case(name)
+        layer = make_lr(c, dev)
+        with torch.no_grad():
+            y = layer(t(c["x"]).to(dev), bool(c["sample"]), bool(c["clp"]))
+        close(y, c["y"], atol=2e-6)
+        if bool(c["train"]) or bool(c["clp"]):
+            close(layer.kl_cost, c["kl"])
+            close(layer.weight_kl_cost, c["weight_kl"])
+            close(layer.bias_kl_cost, c["bias_kl"], rtol=1e-4)
+        else:
+            assert layer.kl_cost == 0                                  # stale, as in the reference
+
+
+def test_k3_g7_odd_shapes(g_layers, dev):
+    names = [n for n in g_layers.cases("G7") if "lr" in n.split("/")[-1]]
+    assert len(names) == 7
+    for name in names:
+        c = g_layers.case(name)
+        layer = make_lr(c, dev)
+        with torch.no_grad():
+            y = layer(t(c["x"]).to(dev))
+        close(y, c["y"], rtol=1e-4, atol=1e-4)
+        close(layer.kl_cost, c["kl"])
+
+
+def test_k3_eval_mean_path(dev):
+    import networks
+    layer = networks.BayesianLinearLR(33, 21, [-1.0, 2.0], [-5, -4], [1.0]).to(dev).eval()
+    x = torch.rand(9, 33, device=dev)
+    with torch.no_grad():
+        y = layer(x)
+    close(y, (x @ layer.weight_mu + layer.bias_mu).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_k2_gauss_kl(dev):
+    rs = np.random.RandomState(11)
+    for n, sp in ((1, 1.0), (1027, 0.5), (1200 * 784, 1.0), (4096 * 4096 + 3, 2.0)):
+        mu = rs.uniform(-0.2, 0.2, n).astype(np.float32)
+        rho = rs.uniform(-5, -4, n).astype(np.float32)
+        out = ops.gauss_kl(t(mu).to(dev), t(rho).to(dev), sp).cpu().numpy()
+        sig = np.log1p(np.exp(rho.astype(np.float64)))
+        kl = 0.5 * np.sum(2 * np.log(sp / sig) - 1 + (sig / sp) ** 2 + (mu.astype(np.float64) / sp) ** 2)
+        np.testing.assert_allclose(out[0], kl, rtol=2e-6)
+        np.testing.assert_allclose(out[1], np.log(sig).sum(), rtol=2e-6)
+        np.testing.assert_allclose(out[2], (sig ** 2).sum(), rtol=2e-6)
+        np.testing.assert_allclose(out[3], (mu.astype(np.float64) ** 2).sum(), rtol=2e-6)
+    # against the fp32 oracle formula too (networks.py:113)
+    mu, rho = rs.uniform(-0.2, 0.2, 5000).astype(np.float32), rs.uniform(-5, -4, 5000).astype(np.float32)
+    ref = float(O.kl_closed_form(t(mu), O.softplus_naive(t(rho)), 0.0, 1.0))
+    np.testing.assert_allclose(ops.gauss_kl(t(mu).to(dev), t(rho).to(dev), 1.0).cpu().numpy()[0], ref, rtol=2e-6)
+
+
+def test_rho_extremes_g8(g_layers, dev):
+    c = g_layers.case("G8")
+    rho, mu, eps = c["rho"], c["mu"], c["eps"]
+    n = rho.size
+    # one output feature per rho value, in_features = 1, x = 1: y = w + b with b = 0 -> y = w
+    out = ops.bbb_linear_fwd(torch.ones(1, 1, device=dev), t(mu).view(n, 1).to(dev), t(rho).view(n, 1).to(dev),
+                             torch.zeros(n, device=dev), torch.full((n,), -200.0, device=dev), n_samples=1,
+                             prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_F32, relu=False,
+                             y_dtype=torch.float32, eps_mode=L.EPS_MEMORY, eps_w=t(eps).view(1, n, 1).to(dev),
+                             eps_b=torch.zeros(1, n, device=dev), want_stats=False)
+    w = out["y"][0, 0].cpu().numpy()
+    np.testing.assert_allclose(w[:6], c["w"][:6], rtol=2e-6)
+    assert np.isinf(w[6]) and w[6] > 0                                # rho = 89: naive softplus overflows
+
+
+# ------------------------------------------------------------------ whole network, C1 (golden G5)
+def build_net(dev, lr, dims, mode, prior_init=(1.0,), mixture=False, B=128):
+    import networks
+    mp = dict(input_shape=dims[0], classes=dims[2], batch_size=B, hidden_units=dims[1], mode=mode,
+              mu_init=[-0.2, 0.2], rho_init=[-5, -4], prior_init=list(prior_init), mixture_prior=mixture,
+              local_reparam=lr)
+    net = networks.BayesianNetwork(mp)
+    sd = synth.synth_state_dict(dims[0], dims[1], dims[2], lr)
+    net.load_state_dict({k: t(v) for k, v in sd.items()})
+    return net.to(dev).train(), sd
+
+
+def install_eps(net, B, S, lr):
+    shapes = []
+    for l in (net.l1, net.l2, net.l3):
+        shapes += [(B, l.weight_mu.shape[1]) if lr else tuple(l.weight_mu.shape), tuple(l.bias_mu.shape)]
+    per = [synth.synth_eps(shapes, s) for s in range(S)]
+    for li, l in enumerate((net.l1, net.l2, net.l3)):
+        if lr:
+            l.normal = Replay([a for s in range(S) for a in (per[s][2 * li], per[s][2 * li + 1])])
+        else:
+            l.weight.normal = Replay([per[s][2 * li] for s in range(S)])
+            l.bias.normal = Replay([per[s][2 * li + 1] for s in range(S)])
+
+
+@pytest.mark.parametrize("variant", ["bbb", "lr", "mix"])
+def test_c1_regression_elbo_and_grads(g_c1, dev, variant):
+    lr = variant == "lr"
+    n_grad = 0
+    for Bname in g_c1.cases(f"G5/{variant}"):
+        B = int(Bname.split("/")[-1][1:])
+        for Sname in g_c1.cases(Bname):
+            S = int(Sname.split("/")[-1][1:])
+            for bname in g_c1.cases(Sname):
+                c = g_c1.case(bname)
+                net, _ = build_net(dev, lr, (1, 50, 1), "regression",
+                                   (0.5, 0.0, -6.0) if variant == "mix" else (1.0,), variant == "mix", B)
+                x, y = synth.synth_batch("regression", B, 1, 1)
+                install_eps(net, B, S, lr)
+                want_grad = "grad/l1.weight_mu" in c
+                net.zero_grad()
+                with torch.set_grad_enabled(want_grad):
+                    fn = net.sample_elbo_lr if lr else net.sample_elbo
+                    tup = fn(t(x).to(dev), t(y).to(dev), float(c["beta"]), S, 0.1)
+                assert [v.dim() for v in tup] == list(c["t_shapes"])
+                for i, v in enumerate(tup):
+                    close(v, c[f"t{i}"], rtol=3e-5)
+                if want_grad:
+                    tup[0].backward()
+                    for n, p in net.named_parameters():
+                        gref = c[f"grad/{n}"]
+                        np.testing.assert_allclose(p.grad.cpu().numpy(), gref, rtol=2e-4,
+                                                   atol=2e-5 * float(np.abs(gref).max()))
+                    n_grad += 1
+    assert n_grad >= 2
+
+
+# ------------------------------------------------------------------ whole network, C2 (golden G6)
+@pytest.mark.parametrize("variant", ["bbb", "mix", "lr"])
+@pytest.mark.parametrize("math_mode", ["f32", "bf16"])
+def test_c2_mnist_shape_elbo(g_c2, dev, variant, math_mode):
+    bnn_hip.set_math(math_mode)
+    lr = variant == "lr"
+    net, _ = build_net(dev, lr, (784, 1200, 10), "classification",
+                       (0.5, 0.0, -6.0) if variant == "mix" else (1.0,), variant == "mix")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    c1 = g_c2.case(f"G6/{variant}/S1")
+    f32 = math_mode == "f32"
+    # MC sample 0: logits, per-layer scalars, NLL
+    install_eps(net, 128, 1, lr)
+    with torch.no_grad():
+        logits = net(xd, sample=True)
+        nll0 = net.get_nll(logits, yd)
+    scale = float(c1["logits_s0_absmax"])
+    close(logits[:2], c1["logits_s0_rows01"], rtol=0, atol=(2e-5 if f32 else 3e-2) * scale)
+    close(nll0, c1["nll_s0"], rtol=2e-5 if f32 else 2e-3)
+    for li, l in enumerate((net.l1, net.l2, net.l3)):
+        if lr:
+            close(l.kl_cost, c1[f"l{li+1}/kl"])
+        else:
+            close(l.log_prior, c1[f"l{li+1}/log_prior"])
+            close(l.log_variational_posterior, c1[f"l{li+1}/log_q"])
+    for S in (1, 2):
+        c = g_c2.case(f"G6/{variant}/S{S}")
+        install_eps(net, 128, S, lr)
+        with torch.no_grad():
+            tup = (net.sample_elbo_lr if lr else net.sample_elbo)(xd, yd, 0.5, S)
+        nll_tol = 2e-5 if f32 else 2e-3
+        tols = [1e-4, F32_RTOL, nll_tol] if lr else [1e-4, F32_RTOL, F32_RTOL, nll_tol]   # ELBO: rtol 1e-4 (north star)
+        for i, v in enumerate(tup):
+            close(v, c[f"t{i}"], rtol=tols[i])
+
+
+# ------------------------------------------------------------------ size-independent properties
+def test_sample_offset_invariance_and_sharding(dev):
+    """MC sample g gives the same result whichever launch / shard computes it."""
+    net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+    bnn_hip.set_math("bf16")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd = t(x).to(dev).view(128, 784)
+    specs = net._specs()
+    from bnn_hip import engine
+    with torch.no_grad():
+        full, st_full = engine.run_layers(specs, xd, 8, 100, want_stats=True, sample=True, differentiable=False)
+        parts = [engine.run_layers(specs, xd, n, 100 + lo, want_stats=True, sample=True, differentiable=False)
+                 for lo, n in ((0, 3), (3, 1), (4, 4))]
+    got = torch.cat([p[0] for p in parts])
+    assert torch.equal(full, got)                                      # bitwise: no dependence on launch shape
+    fin = lambda st, n: ops.elbo_finalize(workspaces=st, layer_in=[784, 1200, 1200], layer_out=[1200, 1200, 10],
+                                          local_reparam=False, prior=ops.PriorSpec(False, 1.0), n_samples=n,
+                                          logits=None, target=None, mode=None)
+    a = fin(st_full, 8)
+    b = [fin(p[1], n) for p, n in zip(parts, (3, 1, 4))]
+    assert torch.equal(a["log_prior"], torch.cat([q["log_prior"] for q in b]))
+    assert torch.equal(a["log_q"], torch.cat([q["log_q"] for q in b]))
+
+
+def test_mc_mean_converges_to_mean_weights(dev):
+    """E_eps[y] = x.mu^T + b_mu: averaging many on-chip samples approaches the eval output."""
+    import networks
+    layer = networks.BayesianLinear(64, 32, [-0.2, 0.2], [-3, -2], [1.0], False).to(dev)
+    x = torch.rand(16, 64, device=dev)
+    out = ops.bbb_linear_fwd(x, layer.weight_mu.detach(), layer.weight_rho.detach(), layer.bias_mu.detach(),
+                             layer.bias_rho.detach(), n_samples=4096, prior=layer._prior_spec, math_mode=L.MATH_F32,
+                             relu=False, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX, seed=1, want_stats=True,
+                             want_scalars=True)
+    mean = out["y"].mean(0)
+    ref = x @ layer.weight_mu.detach().t() + layer.bias_mu.detach()
+    sd = out["y"].std(0).max().item()
+    assert (mean - ref).abs().max().item() < 6 * sd / math.sqrt(4096)
+    # E[sum eps^2] = count: log q mean is near its expectation
+    cnt = 64 * 32 + 32
+    sig_w = torch.log1p(torch.exp(layer.weight_rho.detach()))
+    sig_b = torch.log1p(torch.exp(layer.bias_rho.detach()))
+    exp_lq = cnt * O.C0 - float(torch.log(sig_w).sum() + torch.log(sig_b).sum()) - 0.5 * cnt
+    assert abs(out["log_q"].mean().item() - exp_lq) < 6 * math.sqrt(cnt / 2) / math.sqrt(4096) + 1e-3 * abs(exp_lq)
+
+
+def test_cpu_tensors_raise_no_fallback():
+    import networks
+    layer = networks.BayesianLinear(4, 3, [-0.2, 0.2], [-5, -4], [1.0], False)
+    with pytest.raises(bnn_hip.BnnHipError):
+        layer(torch.rand(2, 4))
