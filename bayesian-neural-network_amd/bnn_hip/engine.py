@@ -217,6 +217,7 @@ class GraphedElbo:
         self.sums = torch.zeros(4, dtype=torch.float32, device=dev)
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
+        take_samples(self.samples)
         torch.cuda.synchronize()
         if capture:
             side = torch.cuda.Stream()

@@ -208,7 +208,7 @@ def elbo_finalize(*, workspaces, layer_in, layer_out, local_reparam: bool, prior
         a.layer_workspace[i] = w.data_ptr()
         a.layer_in[i], a.layer_out[i] = ki, ko
     a.prior = prior.c()
-    out = dict(out) if out is not None else dict(log_prior=None, log_q=None, kl=None, nll=None)
+    out = {**dict(log_prior=None, log_q=None, kl=None, nll=None), **(out or {})}
     preset = {k for k, v in out.items() if v is not None}
     if n_layers:
         for key in (("kl",) if local_reparam else ("log_prior", "log_q")):

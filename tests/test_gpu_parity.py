@@ -140,7 +140,7 @@ def test_k1_identity_input_catches_transposes(dev):
     layer = networks.BayesianLinear(fin, fout, [-1.0, 2.0], [-5, -4], [1.0], False).to(dev).eval()
     with torch.no_grad():
         y = layer(torch.eye(fin, device=dev))                         # eval & sample=False: w = mu
-    close(y, (layer.weight_mu.t() + layer.bias_mu).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    close(y, (layer.weight_mu.t() + layer.bias_mu).detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_k1_philox_mode_dump_and_oracle(dev):
@@ -202,7 +202,7 @@ def test_k3_eval_mean_path(dev):
     x = torch.rand(9, 33, device=dev)
     with torch.no_grad():
         y = layer(x)
-    close(y, (x @ layer.weight_mu + layer.bias_mu).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    close(y, (x @ layer.weight_mu + layer.bias_mu).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_k2_gauss_kl(dev):
