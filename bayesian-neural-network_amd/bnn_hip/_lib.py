@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbnn_hip.so")
+LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
 ABI_VERSION = 1
 
 # enums of include/bnn_hip.h

@@ -1,23 +1,35 @@
 // K1  bbb_linear_fwd — BayesianLinear.forward (reference networks.py:73-88) for all locally
 // owned MC samples of one layer in one launch.
 //
-// Work decomposition (gfx950, wave64):
-//   grid  = (ceil(out/16), n_samples, ceil(batch/128))
-//   block = NW waves; every wave owns the SAME 16 output features and a strided set of
-//           32-deep k-steps (wave w takes k-steps w, w+NW, ...), so a block streams whole
-//           (mu, rho) rows with 128-byte segments per lane quad.
-//   lane (r = lane&15, q = lane>>4) of a wave holds, per k-step, the 8 consecutive weights
-//           W[n0+r][32t + 8q .. +7] — exactly the A-operand fragment of
-//           v_mfma_f32_16x16x32_bf16 — so mu/rho are read once as two 16-byte loads each,
-//           eps is generated in that layout (2 Philox calls = 8 normals), w = mu + sigma*eps
-//           is formed in registers, folded into the log-prob partial sums in fp32, rounded
-//           to bf16 and fed to the matrix core.  w never exists in memory.
-//   B operand = x[16m + r][32t + 8q .. +7] for the 8 batch tiles m of the block's 128 rows.
-//   D[row = out feature 4q+i][col = batch row r]: a lane ends with 4 consecutive output
-//           features of one batch row -> one 16-byte (fp32) / 8-byte (bf16) store.
-//   The NW partial accumulators meet in LDS (one 8 KiB slab per wave), then bias + ReLU +
-//   down-conversion run as the epilogue.  No cross-block reduction, no atomics: results are
-//   bitwise reproducible and independent of the grid.
+// Lane geometry (both kernels).  A wave owns a 16-row MFMA A-operand tile of sampled
+// weights.  Lane (r = lane&15, q = lane>>4) holds, per 32-deep k-step, the 8 consecutive
+// weights W[n][k0 + 8q .. +7] of ONE output feature n — exactly the A fragment of
+// v_mfma_f32_16x16x32_bf16 — so mu/rho arrive as two 16-byte loads each, eps is generated
+// in that layout (2 Philox calls = 8 normals), w = mu + sigma*eps is formed in registers,
+// folded into the fp32 log-prob partial sums, rounded to bf16 and fed to the matrix core.
+// w never exists in memory.  B operand = x[16m + r][k0 + 8q .. +7] for the 8 batch tiles m
+// of the block's 128 rows.  D[row][col = batch row r]: a lane ends with 4 consecutive output
+// features of one batch row -> one 16-byte (fp32) / 8-byte (bf16) store.
+//
+// `bbb_fwd_kernel<MATH, XDT, R, ALIGNED>`: grid (tiles, samples, ceil(batch/128)).
+//   * The 16 A rows are split into R k-range classes of F = 16/R features: row r carries
+//     feature f = r % F and k-range class c = r / F, i.e. the tile covers F features x R*32
+//     k per "super-step".  Per batch tile the wave issues R MFMAs, the c-th with the A rows
+//     of the other classes zeroed and the x fragment of k-range c.  The D rows of one
+//     feature are summed in the epilogue.  R > 1 makes tiles narrower (150 / 300 tiles for
+//     1200 features) so a single-sample launch still covers the chip WITHOUT any cross-block
+//     reduction (no atomics, no split-K slabs: bitwise reproducible for a given shape).
+//   * A block's NW waves split the super-steps (wave w owns w, w+NW, ...); NW is chosen so
+//     they divide evenly.  Per step a wave first issues its x-fragment loads (unconditional
+//     16-byte loads at clamped addresses, one batch), prefetches the NEXT step's (mu, rho),
+//     then runs softplus + Philox + Box-Muller + fma + stats, then the MFMAs.
+//   * The NW partial accumulators meet in LDS (8 KiB per wave), then bias + ReLU +
+//     down-conversion run as the epilogue.
+//   ALIGNED = false is the any-shape variant (odd K, K = 1, unaligned views): guarded loads.
+//
+// Stats workspace (opaque to callers): float4 ws[1 + S*T]; ws[0] = {T as int bits,0,0,0}
+// written by block 0, then entry (s, t) = {sum eps^2, sum w^2 | sum log p_mix(w),
+// sum log sigma (s = 0 only), 0} for the features of tile t.
 #include "bnn_device.h"
 #include "../../include/bnn_hip.h"
 
@@ -35,13 +47,32 @@ struct BbbK {
   float* eps_w_dump;
   float* eps_b_dump;
   void* y;
-  float* partial;   // [S][T][4]
+  float4* ws;       // stats workspace (see above) or nullptr
   int S, B, K, N;
-  int eps_mode, prior_kind, want_stats, relu, y_bf16;
+  int eps_mode, prior_kind, want_stats, relu, y_bf16, spb;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
   float inv2var1, c1, inv2var2, c2, pi;   // mixture: log N(w;0,s_i) = c_i - w^2 * inv2var_i
+#ifdef BNN_STAMPS
+  unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
+#endif
 };
+
+#ifdef BNN_STAMPS
+#define BNN_STAMP(i)                                                                              \
+  do {                                                                                            \
+    if (p.dbg && threadIdx.x == 0)                                                                \
+      p.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define BNN_STAMP_RT(i)                                                                           \
+  do {                                                                                            \
+    if (p.dbg && threadIdx.x == 0)                                                                \
+      p.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define BNN_STAMP(i)
+#define BNN_STAMP_RT(i)
+#endif
 
 template <bool ALIGNED>
 __device__ __forceinline__ void load8(const float* __restrict__ p, int valid, float v[8]) {
@@ -75,199 +106,93 @@ __device__ __forceinline__ void store8(float* __restrict__ p, int valid, const f
   }
 }
 
-// x fragment for one batch tile: 8 consecutive k of row `row`.
-template <int XDT, bool ALIGNED>
-__device__ __forceinline__ void load_x8(const void* __restrict__ xbase, long row_off, int valid, float v[8],
-                                        bf16x8& vb) {
+// x fragment for one batch tile: 8 consecutive k of one row, as bf16x8 (bf16 math) or 8 floats.
+template <int MATH, int XDT, bool ALIGNED>
+__device__ __forceinline__ void load_xfrag(const char* __restrict__ xs, long off, int valid, float xv[8], bf16x8& xb) {
   if (XDT == BNN_F32) {
-    load8<ALIGNED>(reinterpret_cast<const float*>(xbase) + row_off, valid, v);
+    load8<ALIGNED>(reinterpret_cast<const float*>(xs) + off, valid, xv);
+    if (MATH == BNN_MATH_BF16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] = (__bf16)xv[j];
+    }
   } else {
-    const __bf16* p = reinterpret_cast<const __bf16*>(xbase) + row_off;
+    const __bf16* p = reinterpret_cast<const __bf16*>(xs) + off;
     if (ALIGNED) {
       if (valid > 0) {
-        vb = *reinterpret_cast<const bf16x8*>(p);
+        xb = *reinterpret_cast<const bf16x8*>(p);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vb[j] = (__bf16)0.0f;
+        for (int j = 0; j < 8; ++j) xb[j] = (__bf16)0.0f;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vb[j] = (j < valid) ? p[j] : (__bf16)0.0f;
+      for (int j = 0; j < 8; ++j) xb[j] = (j < valid) ? p[j] : (__bf16)0.0f;
+    }
+    if (MATH == BNN_MATH_F32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = (float)xb[j];
     }
   }
 }
 
-template <int MATH, int XDT, bool ALIGNED>
-__global__ __launch_bounds__(512) void bbb_linear_fwd_kernel(const BbbK p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int nt = blockIdx.x, s = blockIdx.y, mb = blockIdx.z;
-  const int K = p.K, N = p.N, B = p.B;
-  const int n = nt * 16 + r;
-  const bool n_ok = n < N;
-  const int m0 = mb * 128;
-  const int mtiles = min(8, (B - m0 + 15) >> 4);
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
-  const bool do_stats = p.want_stats && mb == 0;
-  const bool do_ls = do_stats && s == 0;
-  const bool do_dump = mb == 0;
-  const int gpr = (K + 3) >> 2;                    // eps groups per weight row
-  const int ksteps = (K + 31) >> 5;
-  const char* xs = reinterpret_cast<const char*>(p.x) +
-                   (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+__device__ __forceinline__ float mix_logp(const BbbK& p, float w) {
+  const float w2 = w * w;
+  const float p1 = fast_exp(__builtin_fmaf(-w2, p.inv2var1, p.c1));
+  const float p2 = fast_exp(__builtin_fmaf(-w2, p.inv2var2, p.c2));
+  return fast_log(p.pi * p1 + (1.0f - p.pi) * p2);
+}
 
-  f32x4 acc[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-
-  for (int t = wave; t < ksteps; t += nw) {
-    const int k = t * 32 + q * 8;
-    const int valid = n_ok ? min(8, K - k) : 0;   // <= 0: nothing of this lane's 8 is real
-    const size_t woff = (size_t)n * K + k;
-
-    float mu[8], sg[8], e[8], w[8];
-    load8<ALIGNED>(p.w_mu + woff, valid, mu);
-    load8<ALIGNED>(p.w_rho + woff, valid, sg);
-    if (p.eps_mode == BNN_EPS_PHILOX) {
-      const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-      philox_normal4(g, gs, p.layer_id * 4u, p.k0, p.k1, e);
-      philox_normal4(g + 1u, gs, p.layer_id * 4u, p.k0, p.k1, e + 4);
-    } else if (p.eps_mode == BNN_EPS_MEMORY) {
-      load8<ALIGNED>(p.eps_w + ((size_t)s * N + n) * K + k, valid, e);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = 0.f;
-    }
-    if (p.eps_w_dump && do_dump) store8<ALIGNED>(p.eps_w_dump + ((size_t)s * N + n) * K + k, valid, e);
-
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = j < valid;
-      const float sig = softplus(sg[j]);
-      const float wj = ok ? __builtin_fmaf(sig, e[j], mu[j]) : 0.f;
-      w[j] = wj;
-      if (do_stats) {
-        s_e2 += ok ? e[j] * e[j] : 0.f;
-        if (p.prior_kind == BNN_PRIOR_GAUSS) {
-          s_a = __builtin_fmaf(wj, wj, s_a);
-        } else {
-          const float w2 = wj * wj;
-          const float p1 = fast_exp(__builtin_fmaf(-w2, p.inv2var1, p.c1));
-          const float p2 = fast_exp(__builtin_fmaf(-w2, p.inv2var2, p.c2));
-          const float lp = fast_log(p.pi * p1 + (1.0f - p.pi) * p2);
-          s_a += ok ? lp : 0.f;
-        }
-        if (do_ls) s_ls += ok ? fast_log(sig) : 0.f;
-      }
-    }
-
-    bf16x8 wa;
-    if (MATH == BNN_MATH_BF16) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wa[j] = (__bf16)w[j];
-    }
-
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < mtiles) {
-        const int row = m0 + m * 16 + r;
-        const int xvalid = (row < B) ? min(8, K - k) : 0;
-        float xv[8];
-        bf16x8 xb;
-        load_x8<XDT, ALIGNED>(xs, (long)row * K + k, xvalid, xv, xb);
-        if (MATH == BNN_MATH_BF16) {
-          if (XDT == BNN_F32) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xb[j] = (__bf16)xv[j];
-          }
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[m], 0, 0, 0);
-        } else {
-          if (XDT == BNN_BF16) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[j] = (float)xb[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], xv[j], acc[m], 0, 0, 0);
-        }
-      }
-    }
+// Sampled bias of feature n for global sample gs (+ its stats); returns b.
+// eps of the bias of feature n for global sample gs.
+__device__ __forceinline__ float bias_eps(const BbbK& p, int n, int s, uint32_t gs, bool dump) {
+  float e = 0.f;
+  if (p.eps_mode == BNN_EPS_PHILOX) {
+    float e4[4];
+    philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+    e = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+  } else if (p.eps_mode == BNN_EPS_MEMORY) {
+    e = p.eps_b[(size_t)s * p.N + n];
   }
+  if (p.eps_b_dump && dump) p.eps_b_dump[(size_t)s * p.N + n] = e;
+  return e;
+}
 
-  // ---- bias of the tile's 16 features: wave 0, lanes 0..15 (q == 0)
-  float* lds_bias = lds + (size_t)nw * 8 * 64 * 4;   // 16 floats
-  float* lds_red = lds_bias + 16;                    // 3 * nw floats
-  if (wave == 0 && q == 0) {
-    float b = 0.f;
-    if (n_ok) {
-      const float bmu = p.b_mu[n], sig = softplus(p.b_rho[n]);
-      float e = 0.f;
-      if (p.eps_mode == BNN_EPS_PHILOX) {
-        float e4[4];
-        philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
-        e = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
-      } else if (p.eps_mode == BNN_EPS_MEMORY) {
-        e = p.eps_b[(size_t)s * N + n];
-      }
-      if (p.eps_b_dump && do_dump) p.eps_b_dump[(size_t)s * N + n] = e;
-      b = __builtin_fmaf(sig, e, bmu);
-      if (do_stats) {
-        s_e2 += e * e;
-        if (p.prior_kind == BNN_PRIOR_GAUSS) {
-          s_a = __builtin_fmaf(b, b, s_a);
-        } else {
-          const float w2 = b * b;
-          const float p1 = fast_exp(__builtin_fmaf(-w2, p.inv2var1, p.c1));
-          const float p2 = fast_exp(__builtin_fmaf(-w2, p.inv2var2, p.c2));
-          s_a += fast_log(p.pi * p1 + (1.0f - p.pi) * p2);
-        }
-        if (do_ls) s_ls += fast_log(sig);
-      }
-    }
-    lds_bias[r] = b;
-  }
-
-  // ---- cross-wave reduction of the k-split accumulators through LDS
-  f32x4* slab = reinterpret_cast<f32x4*>(lds);
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = acc[m];
+__device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brho, float e, bool do_stats, bool do_ls,
+                                             float& s_e2, float& s_a, float& s_ls) {
+  const float sig = softplus(brho);
+  const float b = __builtin_fmaf(sig, e, bmu);
   if (do_stats) {
-    const float a = wave_sum(s_e2), b = wave_sum(s_a), c = wave_sum(s_ls);
-    if (lane == 0) {
-      lds_red[wave * 3 + 0] = a;
-      lds_red[wave * 3 + 1] = b;
-      lds_red[wave * 3 + 2] = c;
-    }
+    s_e2 = __builtin_fmaf(e, e, s_e2);
+    s_a += (p.prior_kind == BNN_PRIOR_GAUSS) ? b * b : mix_logp(p, b);
+    if (do_ls) s_ls += fast_log(sig);
   }
-  __syncthreads();
+  return b;
+}
 
-  if (do_stats && threadIdx.x == 0) {
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int wv = 0; wv < nw; ++wv) {
-      a += lds_red[wv * 3 + 0];
-      b += lds_red[wv * 3 + 1];
-      c += lds_red[wv * 3 + 2];
-    }
-    float4* out = reinterpret_cast<float4*>(p.partial) + ((size_t)s * gridDim.x + nt);
-    *out = make_float4(a, b, c, 0.f);
-  }
-
-  // ---- epilogue: sum slabs, + bias, ReLU, convert, store 4 consecutive features per item
+// Epilogue: sum the NW slabs (and the R k-range classes of a feature), + bias, ReLU,
+// convert, store 4 consecutive features per item.
+template <int R>
+__device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __restrict__ slab,
+                                               const float* __restrict__ lds_bias, int nw, int mtiles, int nt, int s,
+                                               int m0) {
+  constexpr int F = 16 / R, FG = F / 4;
+  const int N = p.N, B = p.B;
   const bool vec_ok = (N & 3) == 0;
-  for (int item = threadIdx.x; item < mtiles * 64; item += blockDim.x) {
-    const int m = item >> 6, l = item & 63;
-    f32x4 v = slab[m * 64 + l];
-    for (int wv = 1; wv < nw; ++wv) v += slab[(wv * 8 + m) * 64 + l];
-    const int brow = m0 + m * 16 + (l & 15);
-    const int f0 = (l >> 4) * 4;
-    const int nb = nt * 16 + f0;
+  for (int item = threadIdx.x; item < mtiles * 16 * FG; item += blockDim.x) {
+    const int m = item / (16 * FG);
+    const int rem = item - m * (16 * FG);
+    const int fg = rem >> 4, b = rem & 15;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int wv = 0; wv < nw; ++wv) {
+#pragma unroll
+      for (int c = 0; c < R; ++c) v += slab[(wv * 8 + m) * 64 + (c * FG + fg) * 16 + b];
+    }
+    const int brow = m0 + m * 16 + b;
+    const int nb = nt * F + fg * 4;
     if (brow >= B || nb >= N) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float o = v[i] + lds_bias[f0 + i];
+      float o = v[i] + lds_bias[fg * 4 + i];
       if (p.relu) o = fmaxf(o, 0.f);
       v[i] = o;
     }
@@ -297,16 +222,265 @@ __global__ __launch_bounds__(512) void bbb_linear_fwd_kernel(const BbbK p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// ALIGNED = true : K % 8 == 0 and 16-byte aligned bases; every load is an unconditional
+//                  16-byte access at a clamped address, issued in batches.
+// ALIGNED = false: any K / alignment (guarded scalar loads); R must be 1.
+template <int MATH, int XDT, int R, bool ALIGNED>
+__global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
+  constexpr int F = 16 / R;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int c = r / F, f = r % F;
+  const int nt = blockIdx.x, s = blockIdx.y, mb = blockIdx.z;
+  const int K = p.K, N = p.N, B = p.B;
+  const int n = nt * F + f;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 1);                     // clamped feature for unconditional loads
+  const int m0 = mb * 128;
+  const int mtiles = min(8, (B - m0 + 15) >> 4);
+  const int ssteps = (K + 32 * R - 1) / (32 * R);
+  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const bool do_stats = p.want_stats && mb == 0;
+  const bool do_ls = do_stats && s == 0;
+  const bool do_dump = mb == 0;
+  const int gpr = (K + 3) >> 2;
+  const uint32_t wid = p.layer_id * 4u;
+  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+
+  float* lds_bias = lds + (size_t)nw * 8 * 64 * 4;   // 16 floats
+  float* lds_red = lds_bias + 16;                    // 3 * nw floats
+  f32x4* slab = reinterpret_cast<f32x4*>(lds);
+
+  BNN_STAMP(0);
+  BNN_STAMP_RT(8);
+  f32x4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
+  if (do_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    p.ws[0] = make_float4(__int_as_float((int)gridDim.x), 0.f, 0.f, 0.f);
+
+  // (mu, rho) of this lane for super-step t: prefetched one step ahead.
+  float mu_n[8], rho_n[8];
+  auto load_params = [&](int t) {
+    const int k = (t * R + c) * 32 + q * 8;
+    if (ALIGNED) {
+      const size_t woff = (size_t)nc * K + min(k, K - 8);
+      load8<true>(p.w_mu + woff, 8, mu_n);
+      load8<true>(p.w_rho + woff, 8, rho_n);
+    } else {
+      const int valid = n_ok ? min(8, K - k) : 0;
+      const size_t woff = (size_t)n * K + k;
+      load8<false>(p.w_mu + woff, valid, mu_n);
+      load8<false>(p.w_rho + woff, valid, rho_n);
+    }
+  };
+  if (wave < ssteps) load_params(wave);
+  // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
+  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
+  if (wave == nw - 1 && lane < F && n_ok) {          // the last wave owns the fewest k-steps
+    bmu_pre = p.b_mu[n];
+    brho_pre = p.b_rho[n];
+    beps_pre = bias_eps(p, n, s, gs, do_dump);
+  }
+
+#pragma nounroll
+  for (int t = wave; t < ssteps; t += nw) {
+    const int k = (t * R + c) * 32 + q * 8;
+    const int valid = n_ok ? min(8, K - k) : 0;     // ALIGNED: 8 or <= 0
+    // ---- x fragments of the first batch-tile chunk, issued ahead of the generator work.
+    constexpr int FR = (XDT == BNN_F32) ? 2 : 1;                  // 16-byte loads per fragment
+    constexpr int MC = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));   // batch tiles staged at once
+    float4 xraw[MC * R * FR];
+    auto stage = [&](int ch) {
+#pragma unroll
+      for (int mm = 0; mm < MC; ++mm) {
+        const int row = m0 + (ch * MC + mm) * 16 + r;
+#pragma unroll
+        for (int cc = 0; cc < R; ++cc) {
+          const int xk = (t * R + cc) * 32 + q * 8;
+          if (ALIGNED) {
+            const size_t off = (size_t)min(row, B - 1) * K + min(xk, K - 8);
+            if (XDT == BNN_F32) {
+              const float4* px = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xs) + off);
+              xraw[(mm * R + cc) * 2 + 0] = px[0];
+              xraw[(mm * R + cc) * 2 + 1] = px[1];
+            } else {
+              xraw[mm * R + cc] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xs) + off);
+            }
+          } else {
+            const int xvalid = (row < B) ? min(8, K - xk) : 0;
+            const size_t off = (size_t)row * K + xk;
+            if (XDT == BNN_F32) {
+              float v[8];
+              load8<false>(reinterpret_cast<const float*>(xs) + off, xvalid, v);
+              xraw[(mm * R + cc) * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+              xraw[(mm * R + cc) * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              bf16x8 vb;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                vb[j] = (j < xvalid) ? (reinterpret_cast<const __bf16*>(xs) + off)[j] : (__bf16)0.0f;
+              xraw[mm * R + cc] = __builtin_bit_cast(float4, vb);
+            }
+          }
+        }
+      }
+    };
+    stage(0);
+
+    // ---- consume the prefetched (mu, rho), prefetch the next step's
+    float mu[8], sg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mu_n[j];
+      sg[j] = rho_n[j];
+    }
+    if (t + nw < ssteps) load_params(t + nw);
+    if (t == wave) { asm volatile("" :: "v"(mu[0]), "v"(sg[0])); BNN_STAMP(1); }
+
+    float e[8], w[8];
+    if (p.eps_mode == BNN_EPS_PHILOX) {
+      const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
+      philox_normal4(g, gs, wid, p.k0, p.k1, e);
+      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+    } else if (p.eps_mode == BNN_EPS_MEMORY) {
+      load8<ALIGNED>(p.eps_w + ((size_t)s * N + n) * K + k, valid, e);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    }
+    if (p.eps_w_dump && do_dump) store8<ALIGNED>(p.eps_w_dump + ((size_t)s * N + n) * K + k, valid, e);
+
+    // ALIGNED: a lane's 8 weights are all real or all padding (valid is 8 or <= 0), so one mask
+    // per step suffices: padded lanes compute on clamped (finite) data and are zeroed at the end.
+    float e2 = 0.f, a = 0.f, ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = ALIGNED ? true : (j < valid);
+      sg[j] = softplus(sg[j]);
+      w[j] = ok ? __builtin_fmaf(sg[j], e[j], mu[j]) : 0.f;
+      e2 += ok ? e[j] * e[j] : 0.f;
+    }
+    if (do_stats) {
+      if (p.prior_kind == BNN_PRIOR_GAUSS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (ALIGNED || j < valid) ? mix_logp(p, w[j]) : 0.f;
+      }
+      if (do_ls) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ls += (ALIGNED || j < valid) ? fast_log(sg[j]) : 0.f;
+      }
+      const bool lane_ok = !ALIGNED || valid > 0;
+      s_e2 += lane_ok ? e2 : 0.f;
+      s_a += lane_ok ? a : 0.f;
+      s_ls += lane_ok ? ls : 0.f;
+    }
+    if (ALIGNED && valid <= 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = 0.f;
+    }
+    if (t == wave) { asm volatile("" :: "v"(w[0]), "v"(w[7])); BNN_STAMP(2); }
+    bf16x8 wa, wz;
+    if (MATH == BNN_MATH_BF16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wa[j] = (__bf16)w[j];
+        wz[j] = (__bf16)0.f;
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 8 / MC; ++ch) {
+      if (ch * MC < mtiles) {                     // block-uniform
+#pragma unroll
+        for (int mm = 0; mm < MC; ++mm) {
+#pragma unroll
+          for (int cc = 0; cc < R; ++cc) {
+            const int m = ch * MC + mm;
+            if (MATH == BNN_MATH_BF16) {
+              bf16x8 xb;
+              if (XDT == BNN_F32) {
+                const float4 lo = xraw[(mm * R + cc) * 2], hi = xraw[(mm * R + cc) * 2 + 1];
+                xb[0] = (__bf16)lo.x; xb[1] = (__bf16)lo.y; xb[2] = (__bf16)lo.z; xb[3] = (__bf16)lo.w;
+                xb[4] = (__bf16)hi.x; xb[5] = (__bf16)hi.y; xb[6] = (__bf16)hi.z; xb[7] = (__bf16)hi.w;
+              } else {
+                xb = __builtin_bit_cast(bf16x8, xraw[mm * R + cc]);
+              }
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? wa : wz, xb, acc[m], 0, 0, 0);
+            } else {
+              float xv[8];
+              if (XDT == BNN_F32) {
+                const float4 lo = xraw[(mm * R + cc) * 2], hi = xraw[(mm * R + cc) * 2 + 1];
+                xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+                xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
+              } else {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, xraw[mm * R + cc]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = (float)xb[j];
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32((R == 1 || c == cc) ? w[j] : 0.f, xv[j], acc[m], 0, 0, 0);
+            }
+          }
+        }
+        if ((ch + 1) * MC < 8 && (ch + 1) * MC < mtiles) stage(ch + 1);
+      }
+    }
+  }
+
+  asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
+  BNN_STAMP(3);
+  // ---- bias of the tile's F features: wave 0, lanes 0..F-1
+  if (wave == nw - 1 && lane < 16) {
+    float b = 0.f;
+    if (lane < F && n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    lds_bias[lane] = b;
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = acc[m];
+  if (do_stats) {
+    const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
+    if (lane == 0) {
+      lds_red[wave * 3 + 0] = a;
+      lds_red[wave * 3 + 1] = b;
+      lds_red[wave * 3 + 2] = cc;
+    }
+  }
+  BNN_STAMP(4);
+  __syncthreads();
+  BNN_STAMP(5);
+  if (do_stats && threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+    for (int wv = 0; wv < nw; ++wv) {
+      a += lds_red[wv * 3 + 0];
+      b += lds_red[wv * 3 + 1];
+      cc += lds_red[wv * 3 + 2];
+    }
+    p.ws[1 + (size_t)s * gridDim.x + nt] = make_float4(a, b, cc, 0.f);
+  }
+  epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0);
+  BNN_STAMP(6);
+  BNN_STAMP_RT(9);
+}
+
 // Per-layer reduction of the stats partials into the scalars BayesianLinear stores
 // (networks.py:82-83).  One block per sample.
-__global__ void bbb_layer_scalars_kernel(const float* __restrict__ partial, int T, int K, int N, bnn_prior prior,
+__global__ void bbb_layer_scalars_kernel(const float4* __restrict__ ws, int K, int N, bnn_prior prior,
                                          float* __restrict__ log_prior, float* __restrict__ log_q) {
   __shared__ double scratch[16];
   const int s = blockIdx.x;
+  const int T = __float_as_int(ws[0].x);
   double e2 = 0, a = 0, ls = 0;
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)s * T + t];
-    const float4 v0 = reinterpret_cast<const float4*>(partial)[t];
+    const float4 v = ws[1 + (size_t)s * T + t];
+    const float4 v0 = ws[1 + t];
     e2 += v.x;
     a += v.y;
     ls += v0.z;
@@ -334,10 +508,54 @@ using namespace bnn;
 
 extern "C" size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features) {
   if (n_samples <= 0 || out_features <= 0) return 0;
-  return (size_t)n_samples * (size_t)((out_features + 15) / 16) * 4 * sizeof(float);
+  return (1 + (size_t)n_samples * (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+namespace {
+struct Plan {
+  int R, nw, tiles;
+};
+
+// Launch geometry.  Depends only on the problem shape (and optional env overrides), never on
+// pointers: the same shape always runs the same summation order.
+Plan make_plan(int S, int B, int K, int N, bool aligned) {
+  Plan pl{};
+  const int mbs = (B + 127) / 128;
+  const int forceR = env_int("BNN_HIP_BBB_R", 0);
+  const int forceNw = env_int("BNN_HIP_BBB_WAVES", 0);
+  int R = 1;
+  if (aligned) {
+    // narrower tiles (more k-range classes per MFMA tile) until the launch covers the chip
+    while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * S * mbs < 120) R *= 2;
+    if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
+  }
+  const int F = 16 / R;
+  const int ssteps = (K + 32 * R - 1) / (32 * R);
+  int spw = 1;                                       // super-steps per wave; waves divide them evenly
+  while ((ssteps + spw - 1) / spw > 12) ++spw;
+  int nw = (ssteps + spw - 1) / spw;
+  if (forceNw > 0) nw = forceNw > 12 ? 12 : forceNw;
+  if (nw > ssteps) nw = ssteps;
+  pl.R = R;
+  pl.nw = nw < 1 ? 1 : nw;
+  pl.tiles = (N + F - 1) / F;
+  return pl;
+}
+
+template <typename KernelT>
+hipError_t allow_big_lds(KernelT kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024);
+}
+}  // namespace
 
 extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   if (!a) return BNN_ERR_NULL;
@@ -349,7 +567,6 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
       (unsigned)a->prior.kind > 1u)
     return BNN_ERR_ENUM;
   if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
-  const int T = (a->out_features + 15) / 16;
   if (a->want_stats) {
     if (!a->workspace || a->workspace_bytes < bnn_bbb_linear_fwd_workspace_bytes(a->n_samples, a->out_features))
       return BNN_ERR_WORKSPACE;
@@ -364,12 +581,18 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_w = a->eps_w; k.eps_b = a->eps_b; k.eps_w_dump = a->eps_w_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
-  k.partial = reinterpret_cast<float*>(a->workspace);
+  k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = a->want_stats ? 1 : 0;
   k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
+#ifdef BNN_STAMPS
+  {
+    const char* v = getenv("BNN_HIP_DBG_PTR");
+    k.dbg = v ? reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0)) : nullptr;
+  }
+#endif
   const double c0 = -0.91893853320467274178;
   k.pi = a->prior.pi;
   if (a->prior.kind == BNN_PRIOR_MIXTURE) {
@@ -391,29 +614,40 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
 
-  const int ksteps = (K + 31) / 32;
-  int nw = ksteps / 3;
-  nw = nw < 1 ? 1 : (nw > 8 ? 8 : nw);
-  const dim3 grid(T, a->n_samples, (a->batch + 127) / 128), block(nw * 64);
-  const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+  const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al);
+  k.spb = 1;
+  const dim3 grid(pl.tiles, a->n_samples, (a->batch + 127) / 128), block(pl.nw * 64);
+  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+  hipError_t err = hipSuccess;
+  const int xdt = a->x_dtype, math = a->math;
 
-#define BNN_LAUNCH(MATH, XDT, AL) \
-  hipLaunchKernelGGL((bbb_linear_fwd_kernel<MATH, XDT, AL>), grid, block, lds, stream, k)
-  const int xdt = a->x_dtype;
-  if (a->math == BNN_MATH_BF16) {
-    if (xdt == BNN_F32) { if (al) BNN_LAUNCH(BNN_MATH_BF16, BNN_F32, true); else BNN_LAUNCH(BNN_MATH_BF16, BNN_F32, false); }
-    else                { if (al) BNN_LAUNCH(BNN_MATH_BF16, BNN_BF16, true); else BNN_LAUNCH(BNN_MATH_BF16, BNN_BF16, false); }
+#define BNN_GO(MATH, XDT, RR, AL)                                                              \
+  do {                                                                                         \
+    err = allow_big_lds(bbb_fwd_kernel<MATH, XDT, RR, AL>, lds);                               \
+    if (err == hipSuccess)                                                                     \
+      hipLaunchKernelGGL((bbb_fwd_kernel<MATH, XDT, RR, AL>), grid, block, lds, stream, k);    \
+  } while (0)
+#define BNN_GO_R(MATH, XDT)                                   \
+  do {                                                        \
+    if (!al) BNN_GO(MATH, XDT, 1, false);                     \
+    else if (pl.R == 1) BNN_GO(MATH, XDT, 1, true);           \
+    else if (pl.R == 2) BNN_GO(MATH, XDT, 2, true);           \
+    else BNN_GO(MATH, XDT, 4, true);                          \
+  } while (0)
+  if (math == BNN_MATH_BF16) {
+    if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_BF16, BNN_F32); else BNN_GO_R(BNN_MATH_BF16, BNN_BF16);
   } else {
-    if (xdt == BNN_F32) { if (al) BNN_LAUNCH(BNN_MATH_F32, BNN_F32, true); else BNN_LAUNCH(BNN_MATH_F32, BNN_F32, false); }
-    else                { if (al) BNN_LAUNCH(BNN_MATH_F32, BNN_BF16, true); else BNN_LAUNCH(BNN_MATH_F32, BNN_BF16, false); }
+    if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_F32, BNN_F32); else BNN_GO_R(BNN_MATH_F32, BNN_BF16);
   }
-#undef BNN_LAUNCH
-  hipError_t err = hipGetLastError();
+#undef BNN_GO
+#undef BNN_GO_R
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
 
   if (a->log_prior || a->log_q) {
-    hipLaunchKernelGGL(bbb_layer_scalars_kernel, dim3(a->n_samples), dim3(256), 0, stream, k.partial, T, K,
-                       a->out_features, a->prior, a->log_prior, a->log_q);
+    hipLaunchKernelGGL(bbb_layer_scalars_kernel, dim3(a->n_samples), dim3(256), 0, stream, k.ws, K, a->out_features,
+                       a->prior, a->log_prior, a->log_q);
     err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }

@@ -59,18 +59,17 @@ __device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample,
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
 
-// sigma = log1p(exp(rho)) (networks.py:39), no threshold trick: +inf once exp overflows,
-// 0 once it underflows, like the reference.  log1p(e) = log(u) * e / (u - 1), u = 1 + e,
-// recovers the bits that forming 1 + e drops when e is small (rho ~ -5).
+// sigma = log1p(exp(rho)) (networks.py:39), no threshold trick: +inf once exp overflows, 0 once
+// it underflows, like the reference.  With u = fl(1 + e) and d = u - 1 (exact),
+//   log1p(e) = log(u) + log1p((e - d)/u) = log(u) + (e - d) * (1 + O(d)),
+// so adding back the rounding residue (e - d) restores the bits that forming 1 + e drops when
+// e is small (rho ~ -5), without a division: 7 VALU ops + the overflow select.
 __device__ __forceinline__ float softplus(float rho) {
   const float e = fast_exp(rho);
   const float u = 1.0f + e;
   const float d = u - 1.0f;
-  const float lg = fast_log(u);
-  float s = lg * (e * __builtin_amdgcn_rcpf(d));
-  s = (d == 0.0f) ? e : s;
-  s = (u > 3.0e38f) ? u : s;   // exp overflowed: +inf (d = inf would give inf * (inf/inf))
-  return s;
+  const float s = __builtin_fmaf(__builtin_amdgcn_logf(u), kLn2, e - d);
+  return (e > 3.0e38f) ? e : s;   // exp overflowed: +inf (e - d would be inf - inf)
 }
 
 // ---------------------------------------------------------------------------- reductions

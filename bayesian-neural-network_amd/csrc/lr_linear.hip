@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
       b += lds_red[wv * 3 + 1];
       c += lds_red[wv * 3 + 2];
     }
-    reinterpret_cast<float4*>(p.partial)[nt] = make_float4(a, b, c, 0.f);
+    reinterpret_cast<float4*>(p.partial)[1 + nt] = make_float4(a, b, c, 0.f);
+    if (nt == 0) reinterpret_cast<float4*>(p.partial)[0] = make_float4(__int_as_float((int)gridDim.x), 0.f, 0.f, 0.f);
   }
 
   const bool vec_ok = (N & 3) == 0;
@@ -240,13 +241,14 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
 // weights and biases together (the network only needs the total); the bias term is small
 // (N elements) and is recomputed here so that weight_kl_cost / bias_kl_cost can be
 // reported separately.  out3 = {kl, weight_kl, bias_kl}.
-__global__ void lr_layer_kl_kernel(const float* __restrict__ partial, int T, int K, int N, float sigma_p,
+__global__ void lr_layer_kl_kernel(const float* __restrict__ partial, int K, int N, float sigma_p,
                                    const float* __restrict__ b_mu, const float* __restrict__ b_rho,
                                    float* __restrict__ out3) {
   __shared__ double scratch[16];
   double ls = 0, s2 = 0, m2 = 0, bls = 0, bs2 = 0, bm2 = 0;
+  const int T = __float_as_int(reinterpret_cast<const float4*>(partial)[0].x);
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(partial)[t];
+    const float4 v = reinterpret_cast<const float4*>(partial)[1 + t];
     ls += v.x;
     s2 += v.y;
     m2 += v.z;
@@ -279,7 +281,7 @@ using namespace bnn;
 
 extern "C" size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features) {
   if (out_features <= 0) return 0;
-  return (size_t)((out_features + 15) / 16) * 4 * sizeof(float);
+  return (1 + (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
 }
 
 extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
@@ -330,7 +332,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->kl_out) {
-    hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.partial, T, a->in_features,
+    hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.partial, a->in_features,
                        a->out_features, a->sigma_p, a->b_mu, a->b_rho, a->kl_out);
     err = hipGetLastError();
     if (err != hipSuccess) return (int)err;

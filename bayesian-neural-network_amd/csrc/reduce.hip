@@ -110,93 +110,128 @@ struct FinK {
   uint32_t sample_counter_inc;
 };
 
-__global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p) {
-  __shared__ double scratch[16];
-  const int s = blockIdx.x;
-  const double c0 = -0.91893853320467274178;
-  // ---- complexity terms
-  if (p.local_reparam) {
-    if (p.kl) {
-      double kl = 0;
-      for (int l = 0; l < p.n_layers; ++l) {
-        const int T = (p.lout[l] + 15) >> 4;
-        double ls = 0, s2 = 0, m2 = 0;
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-          const float4 v = reinterpret_cast<const float4*>(p.ws[l])[t];
-          ls += v.x;
-          s2 += v.y;
-          m2 += v.z;
+// grid = n_samples blocks (one sample each), or ONE block looping over all samples when
+// `single` (small n_samples): then the block also writes the 4-vector of sums, in sample order.
+// Latency-lean: every global load is issued before anything waits (headers, then partials and
+// logits together), partial sums go through fp32 wave shuffles (each thread holds at most a
+// few partials) and fp64 only across the 4 waves; all transcendental constants of the priors
+// arrive precomputed from the host.
+struct FinC {
+  double cnt_c0[8];      // count * c0                                  (log q constant)
+  double lp_const[8];    // count * (c0 - log sigma_p)                  (Gaussian log p constant)
+  double kl_const[8];    // 0.5 * (2 count log sigma_p - count)         (LR)
+  double inv2var;        // 1 / (2 sigma_p^2)
+  double reg_const;      // log(nll_sigma) - c0                          (regression NLL per element)
+  double reg_inv2var;    // 1 / (2 nll_sigma^2)
+};
+
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums) {
+  constexpr int NV = 25;                       // 3 sums x 8 layers + nll
+  __shared__ float part[4 * NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int T[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l)
+    T[l] = (l < p.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(p.ws[l])[0].x) : 0;
+  const int s_begin = single ? 0 : blockIdx.x, s_end = single ? p.S : blockIdx.x + 1;
+  double tot_a = 0, tot_b = 0, tot_n = 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l < p.n_layers) {
+        const float4* ws = reinterpret_cast<const float4*>(p.ws[l]);
+        for (int t = threadIdx.x; t < T[l]; t += blockDim.x) {
+          if (p.local_reparam) {
+            const float4 q = ws[1 + t];
+            v[3 * l + 0] += q.x;                // sum log sigma
+            v[3 * l + 1] += q.y;                // sum sigma^2
+            v[3 * l + 2] += q.z;                // sum mu^2
+          } else {
+            const float4 q = ws[1 + (size_t)s * T[l] + t];
+            v[3 * l + 0] += q.x;                // sum eps^2
+            v[3 * l + 1] += q.y;                // sum w^2 | sum log p_mix
+            v[3 * l + 2] += ws[1 + t].z;        // sum log sigma (stored with sample 0)
+          }
         }
-        ls = block_sum(ls, scratch);
-        s2 = block_sum(s2, scratch);
-        m2 = block_sum(m2, scratch);
-        const double cnt = (double)p.lout[l] * p.lin[l] + p.lout[l], sp = p.prior.sigma_p;
-        // per-layer fp32 rounding, then fp32 adds, as the reference sums l1+l2+l3 (networks.py:181)
-        const float layer_kl = (float)(0.5 * (2.0 * cnt * log(sp) - 2.0 * ls - cnt + (s2 + m2) / (sp * sp)));
-        kl = (double)((float)kl + layer_kl);
       }
-      if (threadIdx.x == 0) p.kl[s] = (float)kl;
     }
-  } else if (p.log_prior || p.log_q) {
-    float lp_tot = 0.f, lq_tot = 0.f;
-    for (int l = 0; l < p.n_layers; ++l) {
-      const int T = (p.lout[l] + 15) >> 4;
-      double e2 = 0, a = 0, ls = 0;
-      for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(p.ws[l])[(size_t)s * T + t];
-        const float4 v0 = reinterpret_cast<const float4*>(p.ws[l])[t];
-        e2 += v.x;
-        a += v.y;
-        ls += v0.z;
-      }
-      e2 = block_sum(e2, scratch);
-      a = block_sum(a, scratch);
-      ls = block_sum(ls, scratch);
-      const double cnt = (double)p.lout[l] * p.lin[l] + p.lout[l];
-      const double lq = cnt * c0 - ls - 0.5 * e2;
-      double lp;
-      if (p.prior.kind == BNN_PRIOR_GAUSS) {
-        const double sp = p.prior.sigma_p;
-        lp = cnt * (c0 - log(sp)) - a / (2.0 * sp * sp);
+    if (p.nll && p.logits) {
+      const float* lg = p.logits + (size_t)s * p.B * p.C;
+      float acc = 0.f;
+      if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
+        const long long* tgt = reinterpret_cast<const long long*>(p.target);
+        for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
+          const float* row = lg + (size_t)b * p.C;
+          float mx = row[0];
+          for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
+          float se = 0.f;
+          for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
+          const long long tc = tgt[b];
+          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
+          acc += (mx + logf(se)) - picked;
+        }
       } else {
-        lp = a;
+        const float* tgt = reinterpret_cast<const float*>(p.target);
+        const long tot = (long)p.B * p.C;
+        for (long i = threadIdx.x; i < tot; i += blockDim.x) {
+          const float d = tgt[i] - lg[i];
+          acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
+        }
       }
-      lp_tot += (float)lp;   // networks.py:174-178: fp32 sum of the layers' fp32 scalars
-      lq_tot += (float)lq;
+      v[NV - 1] = acc;
     }
+    const int nv = 3 * p.n_layers;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < nv || i == NV - 1) {               // block-uniform
+        const float t = wave_sum(v[i]);
+        if (lane == 0) part[wave * NV + i] = t;
+      }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      if (p.log_prior) p.log_prior[s] = lp_tot;
-      if (p.log_q) p.log_q[s] = lq_tot;
+      const int nwv = blockDim.x >> 6;
+      auto red = [&](int i) {
+        double t = 0;
+        for (int w = 0; w < nwv; ++w) t += (double)part[w * NV + i];
+        return t;
+      };
+      // per-layer fp32 rounding, then fp32 adds, as the reference sums l1 + l2 + l3
+      // (networks.py:174-181)
+      float a_tot = 0.f, b_tot = 0.f;
+      for (int l = 0; l < p.n_layers; ++l) {
+        const double r0 = red(3 * l), r1 = red(3 * l + 1), r2 = red(3 * l + 2);
+        if (p.local_reparam) {
+          a_tot += (float)(cst.kl_const[l] - r0 + (r1 + r2) * cst.inv2var);
+        } else {
+          const double lq = cst.cnt_c0[l] - r2 - 0.5 * r0;
+          const double lp = (p.prior.kind == BNN_PRIOR_GAUSS) ? cst.lp_const[l] - r1 * cst.inv2var : r1;
+          a_tot += (float)lp;
+          b_tot += (float)lq;
+        }
+      }
+      const float nll = (float)red(NV - 1);
+      if (p.local_reparam) {
+        if (p.kl) p.kl[s] = a_tot;
+      } else {
+        if (p.log_prior) p.log_prior[s] = a_tot;
+        if (p.log_q) p.log_q[s] = b_tot;
+      }
+      if (p.nll && p.logits) p.nll[s] = nll;
+      tot_a += a_tot;
+      tot_b += b_tot;
+      tot_n += nll;
     }
+    if (s + 1 < s_end) __syncthreads();
   }
-  // ---- negative log-likelihood of sample s
-  if (p.nll && p.logits) {
-    const float* lg = p.logits + (size_t)s * p.B * p.C;
-    double acc = 0;
-    if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
-      const long long* tgt = reinterpret_cast<const long long*>(p.target);
-      for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
-        const float* row = lg + (size_t)b * p.C;
-        float mx = row[0];
-        for (int c = 1; c < p.C; ++c) mx = fmaxf(mx, row[c]);
-        float se = 0.f;
-        for (int c = 0; c < p.C; ++c) se += expf(row[c] - mx);
-        const long long tc = tgt[b];
-        const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
-        acc += (double)((mx + logf(se)) - picked);
-      }
-    } else {
-      const float* tgt = reinterpret_cast<const float*>(p.target);
-      const double sg = p.nll_sigma;
-      const double cst = log(sg) - c0;
-      const long tot = (long)p.B * p.C;
-      for (long i = threadIdx.x; i < tot; i += blockDim.x) {
-        const float d = tgt[i] - lg[i];
-        acc += (double)(d * d) / (2.0 * sg * sg) + cst;
-      }
-    }
-    acc = block_sum(acc, scratch);
-    if (threadIdx.x == 0) p.nll[s] = (float)acc;
+  if (single && sums && threadIdx.x == 0) {
+    sums[0] = (float)tot_a;
+    sums[1] = (float)tot_b;
+    sums[2] = (float)tot_n;
+    sums[3] = (float)p.S;
   }
   if (p.sample_counter && blockIdx.x == 0 && threadIdx.x == 0) *p.sample_counter += p.sample_counter_inc;
 }
@@ -298,14 +333,28 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
   k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(a->n_samples), dim3(256), 0, stream, k);
+  FinC cst{};
+  const double c0 = -0.91893853320467274178;
+  const double sp = (a->prior.kind == BNN_PRIOR_MIXTURE) ? 1.0 : (double)a->prior.sigma_p;
+  for (int l = 0; l < a->n_layers; ++l) {
+    const double cnt = (double)a->layer_out[l] * a->layer_in[l] + a->layer_out[l];
+    cst.cnt_c0[l] = cnt * c0;
+    cst.lp_const[l] = cnt * (c0 - log(sp));
+    cst.kl_const[l] = 0.5 * (2.0 * cnt * log(sp) - cnt);
+  }
+  cst.inv2var = 1.0 / (2.0 * sp * sp);
+  const double ns = a->nll_sigma > 0.f ? (double)a->nll_sigma : 1.0;
+  cst.reg_const = log(ns) - c0;
+  cst.reg_inv2var = 1.0 / (2.0 * ns * ns);
+  const int single = a->n_samples <= 16;
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single,
+                     a->sums);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  if (a->sums) {
+  if (a->sums && !single) {
     const float* first = a->local_reparam ? a->kl : a->log_prior;
     const float* second = a->local_reparam ? nullptr : a->log_q;
-    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(a->n_samples >= 256 ? 256 : 64), 0, stream, first, second,
-                       a->nll, a->n_samples, a->sums);
+    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples, a->sums);
     err = hipGetLastError();
   }
   return err == hipSuccess ? BNN_OK : (int)err;

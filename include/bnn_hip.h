@@ -95,10 +95,12 @@ typedef struct bnn_prior {
  * w_mu,w_rho [out,in]; b_mu,b_rho [out]; eps_w [n_samples,out,in]; eps_b [n_samples,out];
  * y [n_samples, batch, out].
  *
- * Stats workspace (want_stats != 0): float[n_samples][T][4], T = ceil(out/16); entry
- * (s,t) holds for the 16 output features of tile t (weights + their biases):
- *   [0] sum eps^2   [1] sum w^2 (Gaussian prior) or sum log p_mix(w) (mixture prior)
- *   [2] sum log sigma (only in s = 0; it does not depend on eps)   [3] 0
+ * Stats workspace (want_stats != 0): opaque to the caller, produced here and consumed only
+ * by this library (the optional per-layer reduction below and bnn_elbo_finalize).  It holds,
+ * per (sample, feature tile), the fp32 partial sums {sum eps^2, sum w^2 (Gaussian prior) or
+ * sum log p_mix(w) (mixture prior), sum log sigma} over the tile's weights and biases, plus a
+ * one-entry header with the tile count, so the launch geometry may change between library
+ * versions without touching callers.  One partial per block, no atomics.
  * If log_prior/log_q are non-NULL a second tiny kernel reduces the partials to the
  * layer's per-sample scalars float[n_samples] (the values BayesianLinear stores in
  * self.log_prior / self.log_variational_posterior).
@@ -147,8 +149,8 @@ int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
  * with the closed-form KL(q||p) partial sums (networks.py:109-114, :134-136) taken from
  * the same pass over (M, rho).  Weights are [in, out] (networks.py:95-96).
  * eps_act [n_samples,batch,out], eps_b [n_samples,out].
- * KL workspace (want_kl != 0): float[T][4], T = ceil(out/16):
- *   [0] sum log sigma  [1] sum sigma^2  [2] sum mu^2  [3] 0   (weights + biases of tile t)
+ * KL workspace (want_kl != 0): opaque, as for K1; per feature tile the fp32 partial sums
+ * {sum log sigma, sum sigma^2, sum mu^2} over the tile's weights and biases.
  * kl_out (optional, float[3]) = {weight_kl + bias_kl, weight_kl, bias_kl}.
  * ---------------------------------------------------------------------------------- */
 typedef struct bnn_lr_fwd_args {
