@@ -21,7 +21,7 @@ EXPORTS = (
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_philox_normal",
+    "bnn_elbo_finalize", "bnn_philox_normal", "bnn_cast_bf16",
 )
 
 
@@ -124,6 +124,8 @@ def load():
     lib.bnn_philox_normal.restype = C.c_int
     lib.bnn_philox_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]
+    lib.bnn_cast_bf16.restype = C.c_int
+    lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     v = lib.bnn_version()
     if v != ABI_VERSION:
         raise BnnHipError(f"libbnn_hip.so ABI version {v} != binding version {ABI_VERSION}")

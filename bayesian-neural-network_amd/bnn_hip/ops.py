@@ -255,3 +255,14 @@ def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int,
     L.check(lib.bnn_philox_normal(eps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, tensor_id, sample_offset & 0xFFFFFFFF,
                                   n_samples, rows, cols, _stream()), "bnn_philox_normal")
     return eps
+
+
+def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 -> bf16 copy of a contiguous device tensor (one tiny kernel)."""
+    lib = L.load()
+    require_device(x)
+    x = _f32c(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(lib.bnn_cast_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "bnn_cast_bf16")
+    return out

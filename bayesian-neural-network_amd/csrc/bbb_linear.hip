@@ -62,17 +62,29 @@ struct BbbK {
 #define BNN_STAMP(i)                                                                              \
   do {                                                                                            \
     if (p.dbg && threadIdx.x == 0)                                                                \
-      p.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+      p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define BNN_STAMP_RT(i)                                                                           \
   do {                                                                                            \
     if (p.dbg && threadIdx.x == 0)                                                                \
-      p.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+      p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define BNN_STAMP(i)
 #define BNN_STAMP_RT(i)
 #endif
+
+// XCD-aware block -> work mapping (speed only, never correctness).  Blocks are dealt round-robin
+// over the 8 XCDs (block b and b+8 share an L2), so XCD x = b % 8 is given the contiguous
+// range [x*chunk, (x+1)*chunk) of the (tile-major, sample-minor) work list: the few feature
+// tiles an XCD touches keep their (mu, rho) resident in that XCD's 4 MiB L2 while the samples
+// stream through.  Returns false for the padding blocks of the last range.
+__device__ __forceinline__ bool xcd_work_item(int total, int& item) {
+  const int b = blockIdx.x;
+  const int chunk = (total + 7) >> 3;
+  item = (b & 7) * chunk + (b >> 3);
+  return (b >> 3) < chunk && item < total;
+}
 
 template <bool ALIGNED>
 __device__ __forceinline__ void load8(const float* __restrict__ p, int valid, float v[8]) {
@@ -233,8 +245,11 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int c = r / F, f = r % F;
-  const int nt = blockIdx.x, s = blockIdx.y, mb = blockIdx.z;
   const int K = p.K, N = p.N, B = p.B;
+  const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
+  int item;
+  if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
+  const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int n = nt * F + f;
   const bool n_ok = n < N;
   const int nc = min(n, N - 1);                     // clamped feature for unconditional loads
@@ -259,8 +274,7 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-  if (do_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    p.ws[0] = make_float4(__int_as_float((int)gridDim.x), 0.f, 0.f, 0.f);
+  if (do_stats && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
 
   // (mu, rho) of this lane for super-step t: prefetched one step ahead.
   float mu_n[8], rho_n[8];
@@ -463,11 +477,207 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
       b += lds_red[wv * 3 + 1];
       cc += lds_red[wv * 3 + 2];
     }
-    p.ws[1 + (size_t)s * gridDim.x + nt] = make_float4(a, b, cc, 0.f);
+    p.ws[1 + (size_t)s * ntiles + nt] = make_float4(a, b, cc, 0.f);
   }
   epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0);
   BNN_STAMP(6);
   BNN_STAMP_RT(9);
+}
+
+// ------------------------------------------------------------------------------------------
+// Throughput kernel (many MC samples in flight, bf16 math, bf16 x): the block GEMM form.
+//   1-D grid over (feature-tile group, sample, batch block) work items (XCD-aware order),
+//   block = NW waves.  Wave j owns the 16 output features of tile tb*NW + j for ALL of K (no
+//   cross-wave reduction, no LDS slabs); the 128 x 32 x-tile of each k-step is brought ONCE
+//   per block into double-buffered LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs are held
+//   across the generator work).  One DMA wave-instruction fills exactly one batch tile's
+//   lane-linear 1 KiB fragment block: lane l fetches x[16m + (l&15)][k0 + 8(l>>4) .. +7], so
+//   every wave's B-fragment read is one conflict-free ds_read_b128.  The DMA for tile t+1 is
+//   issued at the top of step t and drained (vmcnt(0)) just before the step's single barrier:
+//   a whole k-step of Philox/softplus work covers its latency.  ~115 VGPRs -> 4 waves/SIMD.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) {
+  __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];      // 2 x 8 KiB
+  __shared__ float bias_s[NW][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
+  int item;
+  if (!xcd_work_item(tbs * p.S * mbs, item)) return;          // block-uniform
+  const int tb = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
+  const int tile = tb * NW + wave;
+  const int n = tile * 16 + r;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 1);
+  const int m0 = mb * 128;
+  const int ksteps = (K + 31) >> 5;
+  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const bool do_stats = p.want_stats && mb == 0;
+  const bool do_ls = do_stats && s == 0;
+  const bool do_dump = mb == 0;
+  const int gpr = (K + 3) >> 2;
+  const uint32_t wid = p.layer_id * 4u;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
+  const int T = (N + 15) >> 4;
+
+  if (do_stats && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+
+  // LDS-DMA staging: wave w brings batch tiles m = w, w + NW, ... of the k-step's x tile.
+  size_t xrow[8 / NW];
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) xrow[i] = (size_t)min(m0 + (wave + i * NW) * 16 + r, B - 1) * K;
+  auto stage_dma = [&](int t, int buf) {
+    const int kk = min(t * 32 + q * 8, K - 8);
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
+                                       (__attribute__((address_space(3))) void*)&xt[buf][(wave + i * NW) * 64], 16, 0, 0);
+    }
+  };
+
+  float mu_n[8], rho_n[8];
+  auto load_params = [&](int t) {
+    const size_t woff = (size_t)nc * K + min(t * 32 + q * 8, K - 8);
+    load8<true>(p.w_mu + woff, 8, mu_n);
+    load8<true>(p.w_rho + woff, 8, rho_n);
+  };
+
+  // bias of this wave's tile: eps now, applied in the epilogue
+  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
+  if (q == 0 && n_ok) {
+    bmu_pre = p.b_mu[n];
+    brho_pre = p.b_rho[n];
+    beps_pre = bias_eps(p, n, s, gs, do_dump);
+  }
+
+  load_params(0);
+  stage_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
+
+#pragma nounroll
+  for (int t = 0; t < ksteps; ++t) {
+    const int k = t * 32 + q * 8;
+    const bool lane_ok = n_ok && k < K;
+    float mu[8], sg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mu_n[j];
+      sg[j] = rho_n[j];
+    }
+    const bool more = t + 1 < ksteps;
+    if (more) {
+      stage_dma(t + 1, (t + 1) & 1);     // buffer (t+1)&1 was last read in step t-1 (barrier since)
+      load_params(t + 1);
+    }
+    float e[8], w[8];
+    if (p.eps_mode == BNN_EPS_PHILOX) {
+      const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
+      philox_normal4(g, gs, wid, p.k0, p.k1, e);
+      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+    } else if (p.eps_mode == BNN_EPS_MEMORY) {
+      load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    }
+    if (p.eps_w_dump && do_dump) store8<true>(p.eps_w_dump + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
+    float e2 = 0.f, a = 0.f, ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sg[j] = softplus(sg[j]);
+      w[j] = __builtin_fmaf(sg[j], e[j], mu[j]);
+      e2 = __builtin_fmaf(e[j], e[j], e2);
+    }
+    if (do_stats) {
+      if (p.prior_kind == BNN_PRIOR_GAUSS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += mix_logp(p, w[j]);
+      }
+      if (do_ls) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ls += fast_log(sg[j]);
+      }
+      s_e2 += lane_ok ? e2 : 0.f;
+      s_a += lane_ok ? a : 0.f;
+      s_ls += lane_ok ? ls : 0.f;
+    }
+    bf16x8 wa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wa[j] = lane_ok ? (__bf16)w[j] : (__bf16)0.f;
+    const float4* xb = xt[t & 1];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, stats, store (no cross-wave reduction)
+  if (q == 0) {
+    float b = 0.f;
+    if (n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    bias_s[wave][r] = b;
+  }
+  if (do_stats) {
+    const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
+    if (lane == 0 && tile < T) p.ws[1 + (size_t)s * T + tile] = make_float4(a, b, cc, 0.f);
+  }
+  __syncthreads();
+  const int nb = tile * 16 + q * 4;
+  const bool vec_ok = (N & 3) == 0;
+  if (nb < N) {
+    float bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int brow = m0 + m * 16 + r;
+      if (brow < B) {
+        f32x4 v = acc[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o = v[i] + bq[i];
+          if (p.relu) o = fmaxf(o, 0.f);
+          v[i] = o;
+        }
+        const size_t yoff = ((size_t)s * B + brow) * N + nb;
+        if (p.y_bf16) {
+          __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
+          if (vec_ok) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            *reinterpret_cast<bf16x4*>(yp) = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = (__bf16)v[i];
+          }
+        } else {
+          float* yp = reinterpret_cast<float*>(p.y) + yoff;
+          if (vec_ok) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = v[i];
+          }
+        }
+      }
+    }
+  }
 }
 
 // Per-layer reduction of the stats partials into the scalars BayesianLinear stores
@@ -561,7 +771,7 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
-  if (a->n_samples > 65535 || (a->batch + 127) / 128 > 65535) return BNN_ERR_SHAPE;
+  if ((double)a->n_samples * ((a->batch + 127) / 128) * ((a->out_features + 3) / 4) > 2.0e9) return BNN_ERR_SHAPE;
   if (!a->x || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->y) return BNN_ERR_NULL;
   if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u ||
       (unsigned)a->prior.kind > 1u)
@@ -614,12 +824,36 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
 
+  const int xdt = a->x_dtype, math = a->math;
+  hipError_t err = hipSuccess;
+  // Throughput form (block GEMM, x tile shared through LDS) once the launch has enough
+  // (feature-tile-group x sample) blocks to fill the chip several waves deep.
+  {
+    const int mbs = (a->batch + 127) / 128;
+    const long gemm_blocks = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
+    const int force = env_int("BNN_HIP_BBB_GEMM", -1);
+    const bool use_gemm = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8 &&
+                          (force == 1 || (force != 0 && gemm_blocks >= 768));
+    if (use_gemm) {
+      const long total = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
+      const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(256);
+      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+      err = hipGetLastError();
+      if (err != hipSuccess) return (int)err;
+      if (a->log_prior || a->log_q) {
+        hipLaunchKernelGGL(bbb_layer_scalars_kernel, dim3(a->n_samples), dim3(256), 0, stream, k.ws, K, a->out_features,
+                           a->prior, a->log_prior, a->log_q);
+        err = hipGetLastError();
+        if (err != hipSuccess) return (int)err;
+      }
+      return BNN_OK;
+    }
+  }
   const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al);
   k.spb = 1;
-  const dim3 grid(pl.tiles, a->n_samples, (a->batch + 127) / 128), block(pl.nw * 64);
+  const long total = (long)pl.tiles * a->n_samples * ((a->batch + 127) / 128);
+  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
   const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
-  hipError_t err = hipSuccess;
-  const int xdt = a->x_dtype, math = a->math;
 
 #define BNN_GO(MATH, XDT, RR, AL)                                                              \
   do {                                                                                         \

@@ -249,6 +249,13 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
 int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sample_offset,
                       int32_t n_samples, int32_t rows, int32_t cols, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * bnn_cast_bf16 — fp32 -> bf16 (round to nearest even) of n contiguous elements: the input
+ * batch is cast once per ELBO evaluation when bf16 math runs many MC samples, so every
+ * layer streams 2-byte activations.  (The reference keeps x in fp32, main.py / class_task.py:71.)
+ * ---------------------------------------------------------------------------------- */
+int bnn_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
 const char* bnn_status_string(int status); /* static string for a negative status */
 
