@@ -59,7 +59,7 @@ class LayerSpec:
 
 def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first_sample: int, *,
                want_stats: bool, sample: bool, injected: Optional[List[torch.Tensor]] = None,
-               differentiable: bool):
+               differentiable: bool, fin_kw: Optional[dict] = None):
     """Push `n_local` MC samples through the stack.  Returns (logits[S,B,C] fp32,
     per-layer stats).  Stats are (log_prior[S], log_q[S]) or kl3[3] tensors on the
     differentiable path and raw workspaces on the forward-only path."""
@@ -96,10 +96,14 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
                                         want_kl=want_stats)
             else:
-                out = ops.bbb_linear_fwd(h, *pd, n_samples=n_local, prior=call.prior, math_mode=math_mode,
-                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_w=e_w, eps_b=e_b,
-                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
-                                         want_stats=want_stats)
+                kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
+                          eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
+                          sample_offset=first_sample, want_stats=want_stats)
+                if last and fin_kw is not None and want_stats:
+                    # last layer + finalize in one launch (when the layer is a single feature tile)
+                    out, fin = ops.bbb_final_fwd((h,) + pd, kw, dict(workspaces=stats, **fin_kw))
+                    return out["y"], fin
+                out = ops.bbb_linear_fwd(h, *pd, **kw)
             h = out["y"]
             stats.append(out["workspace"])
     return h, stats
@@ -154,8 +158,15 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
         injected = collect_injected(layers, B, samples, dev)
         if injected is not None and world > 1:
             injected = [t[lo:lo + n_local].contiguous() for t in injected]
+        fin_kw = None
+        if not differentiable:
+            fin_kw = dict(layer_in=[sp.in_out[0] for sp in layers], layer_out=[sp.in_out[1] for sp in layers],
+                          local_reparam=local_reparam, prior=layers[0].m._prior_spec, n_samples=n_local, target=target,
+                          mode=mode, nll_sigma=float(sigma),
+                          ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None)
         logits, stats = run_layers(layers, x, n_local, first_global + lo, want_stats=True, sample=True,
-                                   injected=injected, differentiable=differentiable)
+                                   injected=injected, differentiable=differentiable,
+                                   fin_kw=fin_kw if not local_reparam else None)
         if differentiable:
             nll = NLLFn.apply(logits, target, mode, float(sigma))
             if local_reparam:
@@ -171,10 +182,7 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
                 a, b = lp.sum(), lq.sum()
             sums = torch.stack([a, b, nll.sum()])
         else:
-            fin = ops.elbo_finalize(workspaces=stats, layer_in=[sp.in_out[0] for sp in layers],
-                                    layer_out=[sp.in_out[1] for sp in layers], local_reparam=local_reparam,
-                                    prior=layers[0].m._prior_spec, n_samples=n_local, logits=logits, target=target,
-                                    mode=mode, nll_sigma=float(sigma))
+            fin = stats if isinstance(stats, dict) else ops.elbo_finalize(workspaces=stats, logits=logits, **fin_kw)
             if local_reparam:
                 sums = torch.stack([fin["kl"].sum(), zero, fin["nll"].sum()])
             else:
@@ -194,8 +202,13 @@ class GraphedElbo:
     sum nll, n_local}: the vector a sharded job all-reduces."""
 
     def __init__(self, net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0,
-                 capture: bool = True):
+                 capture: bool = True, counter_stride: int = 1, stream: Optional[torch.cuda.Stream] = None):
+        """`counter_stride` > 1: this evaluator is one of several that run concurrently on their
+        own streams and interleave the global MC sample index space (evaluator j of n starts j
+        evaluations in and advances by n evaluations per replay)."""
         self.net, self.samples, self.sigma = net, int(samples), float(sigma)
+        self.stride = int(counter_stride)
+        self.stream = stream
         self.rank, self.world = dist_info()
         self.lo, self.n_local = shard_range(self.samples, self.rank, self.world)
         if self.n_local <= 0:
@@ -220,14 +233,18 @@ class GraphedElbo:
         keys = ("kl",) if self.lr else ("log_prior", "log_q")
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
         self.sums = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and S >= CAST_INPUT_MIN_SAMPLES) else None)
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
         torch.cuda.synchronize()
+        if self.stride > 1:                  # undo the warm-up's stride-sized advance: next index = first + S
+            self.counter.fill_(first + self.samples)
+            torch.cuda.synchronize()
         if capture:
-            side = torch.cuda.Stream()
+            side = self.stream if self.stream is not None else torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
@@ -239,6 +256,12 @@ class GraphedElbo:
     def _enqueue(self):
         math_mode = state.math
         h = self.x if self.x16 is None else ops.cast_bf16(self.x, out=self.x16)
+        last = len(self.specs) - 1
+        fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                      local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
+                      target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                      sample_counter_inc=self.samples * self.stride, out=self.out, sums=self.sums,
+                      ticket=self.ticket)
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
@@ -246,17 +269,20 @@ class GraphedElbo:
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i])
             if self.lr:
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, **common)
+            elif i == last:
+                ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
+                                  dict(workspaces=self.ws[:last], **fin_kw))
             else:
                 ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, **common)
             h = self.bufs[i]
-        ops.elbo_finalize(workspaces=self.ws, layer_in=[sp.in_out[0] for sp in self.specs],
-                          layer_out=[sp.in_out[1] for sp in self.specs], local_reparam=self.lr,
-                          prior=self.specs[0].m._prior_spec, n_samples=self.n_local, logits=h, target=self.target,
-                          mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                          sample_counter_inc=self.samples, out=self.out, sums=self.sums)
+        if self.lr:
+            ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
 
     def replay(self) -> torch.Tensor:
-        if self.graph is not None:
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.graph.replay() if self.graph is not None else self._enqueue()
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self._enqueue()

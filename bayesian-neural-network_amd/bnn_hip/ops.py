@@ -88,13 +88,12 @@ def lr_workspace(out_features: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int,
-                   relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
-                   layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
-                   want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
-                   out=None):
-    """K1.  Returns dict(y, workspace, log_prior, log_q, eps_w, eps_b)."""
-    lib = L.load()
+def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int,
+               relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
+               layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
+               want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
+               out=None):
+    """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
@@ -130,8 +129,17 @@ def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorS
     a.workspace_bytes = workspace.numel() * 4 if (want_stats and workspace is not None) else 0
     a.log_prior, a.log_q = _ptr(lp), _ptr(lq)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    res = dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter)
+    return a, res, keep
+
+
+def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
+    """K1.  Returns dict(y, workspace, log_prior, log_q, eps_w, eps_b)."""
+    lib = L.load()
+    a, res, keep = _bbb_build(x, w_mu, w_rho, b_mu, b_rho, **kw)
     L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
-    return dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
+    return res
 
 
 def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
@@ -193,11 +201,10 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
     return out
 
 
-def elbo_finalize(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
-                  logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
-                  nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None):
-    """K4.  Returns dict(log_prior, log_q, kl, nll): float32[n_samples] tensors (or None)."""
-    lib = L.load()
+def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
+               logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
+               nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
+               ticket=None):
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -240,9 +247,32 @@ def elbo_finalize(*, workspaces, layer_in, layer_out, local_reparam: bool, prior
             out["nll"] = torch.empty(n_samples, dtype=torch.float32, device=dev)
     a.sample_counter, a.sample_counter_inc = _ptr(sample_counter), int(sample_counter_inc)
     a.sums = _ptr(sums)
+    a.ticket = _ptr(ticket)
     a.log_prior, a.log_q, a.kl, a.nll = _ptr(out["log_prior"]), _ptr(out["log_q"]), _ptr(out["kl"]), _ptr(out["nll"])
+    keep += [sample_counter, sums, ticket] + list(workspaces)
+    return a, out, keep
+
+
+def elbo_finalize(**kw):
+    """K4.  Returns dict(log_prior, log_q, kl, nll): float32[n_samples] tensors (or None)."""
+    lib = L.load()
+    a, out, keep = _fin_build(**kw)
     L.check(lib.bnn_elbo_finalize(C.byref(a), _stream()), "bnn_elbo_finalize")
     return out
+
+
+def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
+    """Last BBB layer + ELBO finalize through bnn_bbb_final_fwd (one launch when the layer is a
+    single feature tile).  `fin_kw` must not carry `logits`/`workspaces` for the last layer:
+    they are taken from the layer call.  Returns (layer result dict, finalize result dict)."""
+    lib = L.load()
+    a, res, keep1 = _bbb_build(*layer_args, **layer_kw)
+    fin_kw = dict(fin_kw)
+    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
+    fin_kw["logits"] = res["y"]
+    f, out, keep2 = _fin_build(**fin_kw)
+    L.check(lib.bnn_bbb_final_fwd(C.byref(a), C.byref(f), _stream()), "bnn_bbb_final_fwd")
+    return res, out
 
 
 def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int, rows: int, cols: int,

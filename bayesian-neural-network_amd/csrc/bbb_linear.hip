@@ -31,6 +31,7 @@
 // written by block 0, then entry (s, t) = {sum eps^2, sum w^2 | sum log p_mix(w),
 // sum log sigma (s = 0 only), 0} for the features of tile t.
 #include "bnn_device.h"
+#include "bnn_fin.h"
 #include "../../include/bnn_hip.h"
 
 namespace bnn {
@@ -186,7 +187,7 @@ __device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brh
 template <int R>
 __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __restrict__ slab,
                                                const float* __restrict__ lds_bias, int nw, int mtiles, int nt, int s,
-                                               int m0) {
+                                               int m0, float* __restrict__ lds_out = nullptr) {
   constexpr int F = 16 / R, FG = F / 4;
   const int N = p.N, B = p.B;
   const bool vec_ok = (N & 3) == 0;
@@ -195,7 +196,8 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
     const int rem = item - m * (16 * FG);
     const int fg = rem >> 4, b = rem & 15;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int wv = 0; wv < nw; ++wv) {
+#pragma unroll 4
+    for (int wv = 0; wv < nw; ++wv) {          // fixed order: wave-major, class-minor
 #pragma unroll
       for (int c = 0; c < R; ++c) v += slab[(wv * 8 + m) * 64 + (c * FG + fg) * 16 + b];
     }
@@ -208,6 +210,7 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
       if (p.relu) o = fmaxf(o, 0.f);
       v[i] = o;
     }
+    if (lds_out) *reinterpret_cast<f32x4*>(lds_out + (m * 16 + b) * 16 + fg * 4) = v;
     const size_t yoff = ((size_t)s * B + brow) * N + nb;
     if (p.y_bf16) {
       __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
@@ -238,8 +241,18 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
 // ALIGNED = true : K % 8 == 0 and 16-byte aligned bases; every load is an unconditional
 //                  16-byte access at a clamped address, issued in batches.
 // ALIGNED = false: any K / alignment (guarded scalar loads); R must be 1.
-template <int MATH, int XDT, int R, bool ALIGNED>
-__global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
+struct FinPack {
+  FinK k;
+  FinC c;
+  float* sums;          // float[4] or nullptr
+  uint32_t* ticket;     // zero-initialised word: arrival counter of the sample blocks
+};
+
+// FINAL: this launch is the last layer of an ELBO evaluation (one 16-feature tile, batch <= 128):
+// the block of sample s finishes with that sample's NLL and log p / log q, i.e. the work of
+// bnn_elbo_finalize, without another launch.
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL>
+__device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
   const bool do_stats = p.want_stats && mb == 0;
-  const bool do_ls = do_stats && s == 0;
+  const bool do_ls = do_stats && (s == 0 || FINAL);
   const bool do_dump = mb == 0;
   const int gpr = (K + 3) >> 2;
   const uint32_t wid = p.layer_id * 4u;
@@ -470,18 +483,72 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
   BNN_STAMP(4);
   __syncthreads();
   BNN_STAMP(5);
+  float own0 = 0.f, own1 = 0.f, own2 = 0.f;
   if (do_stats && threadIdx.x == 0) {
-    float a = 0.f, b = 0.f, cc = 0.f;
     for (int wv = 0; wv < nw; ++wv) {
-      a += lds_red[wv * 3 + 0];
-      b += lds_red[wv * 3 + 1];
-      cc += lds_red[wv * 3 + 2];
+      own0 += lds_red[wv * 3 + 0];
+      own1 += lds_red[wv * 3 + 1];
+      own2 += lds_red[wv * 3 + 2];
     }
-    p.ws[1 + (size_t)s * ntiles + nt] = make_float4(a, b, cc, 0.f);
+    p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
   }
-  epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0);
+  float* fin_lg = lds_red + 3 * nw;               // FINAL only: [128][16] final logits + reduce scratch
+  epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
   BNN_STAMP(6);
   BNN_STAMP_RT(9);
+  if (FINAL) {
+    const FinK& fk = fp->k;
+    float* part = fin_lg + 128 * 16;
+    int T[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      T[l] = (l < fk.n_layers - 1) ? __float_as_int(reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
+    __syncthreads();                               // logits tile complete in LDS
+    float a = 0.f, b = 0.f, nll = 0.f;
+    // thread 0 supplies this layer's own partial sums directly (every FINAL block computes its
+    // own sum log sigma, so nothing is read from another block of this launch)
+    const int own_layer = fk.n_layers - 1;
+    fin_sample(fk, fp->c, s, T, fin_lg, 16, own_layer, own0, own1, own2, part, a, b, nll);
+    if (threadIdx.x == 0) {
+      fin_store(fk, s, a, b, nll);
+      if (fk.S == 1) {
+        if (fp->sums) {
+          fp->sums[0] = a; fp->sums[1] = b; fp->sums[2] = nll; fp->sums[3] = 1.f;
+        }
+        if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+      } else {
+        // last-arriving sample block folds the per-sample scalars (sample order) and advances
+        // the Philox sample counter: every block has read it by the time it takes a ticket.
+        __threadfence();
+        const uint32_t tk = atomicAdd(fp->ticket, 1u);
+        if (tk == (uint32_t)fk.S - 1u) {
+          __threadfence();
+          if (fp->sums) {
+            double ta = 0, tb = 0, tn = 0;
+            const float* pa = fk.local_reparam ? fk.kl : fk.log_prior;
+            for (int i = 0; i < fk.S; ++i) {
+              if (pa) ta += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (!fk.local_reparam && fk.log_q) tb += __hip_atomic_load(fk.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (fk.nll) tn += __hip_atomic_load(fk.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            fp->sums[0] = (float)ta; fp->sums[1] = (float)tb; fp->sums[2] = (float)tn; fp->sums[3] = (float)fk.S;
+          }
+          *fp->ticket = 0u;
+          if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+        }
+      }
+    }
+  }
+}
+
+template <int MATH, int XDT, int R, bool ALIGNED>
+__global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
+  bbb_fwd_body<MATH, XDT, R, ALIGNED, false>(p, nullptr);
+}
+
+template <int MATH, int XDT>
+__global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const FinPack fp) {
+  bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,7 +834,9 @@ hipError_t allow_big_lds(KernelT kernel, size_t lds) {
 }
 }  // namespace
 
-extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
+// Validate the arguments and fill the kernel parameter block.  `al` = the 16-byte vector path
+// applies (K % 8 == 0, aligned bases).
+static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
@@ -783,9 +852,6 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (!aligned16(a->workspace)) return BNN_ERR_ALIGN;
   }
   if ((a->log_prior || a->log_q) && !a->want_stats) return BNN_ERR_WORKSPACE;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-
-  BbbK k;
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
@@ -794,7 +860,7 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = a->want_stats ? 1 : 0;
-  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16;
+  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
 #ifdef BNN_STAMPS
@@ -815,46 +881,39 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (a->want_stats && !(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
     k.inv2var1 = k.inv2var2 = k.c1 = k.c2 = 0.f;
   }
-
-  // 16-byte vector path: rows of 8 elements stay inside a row and every base is aligned.
   const int K = a->in_features;
-  bool al = (K % 8 == 0) && aligned16(a->x) && aligned16(a->w_mu) && aligned16(a->w_rho);
+  al = (K % 8 == 0) && aligned16(a->x) && aligned16(a->w_mu) && aligned16(a->w_rho);
   if (a->eps_mode == BNN_EPS_MEMORY) al = al && aligned16(a->eps_w);
   if (a->eps_w_dump) al = al && aligned16(a->eps_w_dump);
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
+  return BNN_OK;
+}
 
+extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
+  BbbK k;
+  bool al = false;
+  const int rc = prepare(a, k, al);
+  if (rc != BNN_OK) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int K = a->in_features;
   const int xdt = a->x_dtype, math = a->math;
   hipError_t err = hipSuccess;
+  const int mbs = (a->batch + 127) / 128;
   // Throughput form (block GEMM, x tile shared through LDS) once the launch has enough
   // (feature-tile-group x sample) blocks to fill the chip several waves deep.
-  {
-    const int mbs = (a->batch + 127) / 128;
-    const long gemm_blocks = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
-    const int force = env_int("BNN_HIP_BBB_GEMM", -1);
-    const bool use_gemm = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8 &&
-                          (force == 1 || (force != 0 && gemm_blocks >= 768));
-    if (use_gemm) {
-      const long total = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
-      const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(256);
-      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
-      err = hipGetLastError();
-      if (err != hipSuccess) return (int)err;
-      if (a->log_prior || a->log_q) {
-        hipLaunchKernelGGL(bbb_layer_scalars_kernel, dim3(a->n_samples), dim3(256), 0, stream, k.ws, K, a->out_features,
-                           a->prior, a->log_prior, a->log_q);
-        err = hipGetLastError();
-        if (err != hipSuccess) return (int)err;
-      }
-      return BNN_OK;
-    }
-  }
-  const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al);
-  k.spb = 1;
-  const long total = (long)pl.tiles * a->n_samples * ((a->batch + 127) / 128);
-  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
-
+  const long gemm_blocks = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
+  const int force = env_int("BNN_HIP_BBB_GEMM", -1);
+  const bool use_gemm = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8 &&
+                        (force == 1 || (force != 0 && gemm_blocks >= 450));
+  if (use_gemm) {
+    const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
+    hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+  } else {
+    const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al);
+    const long total = (long)pl.tiles * a->n_samples * mbs;
+    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
+    const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
 #define BNN_GO(MATH, XDT, RR, AL)                                                              \
   do {                                                                                         \
     err = allow_big_lds(bbb_fwd_kernel<MATH, XDT, RR, AL>, lds);                               \
@@ -868,17 +927,17 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     else if (pl.R == 2) BNN_GO(MATH, XDT, 2, true);           \
     else BNN_GO(MATH, XDT, 4, true);                          \
   } while (0)
-  if (math == BNN_MATH_BF16) {
-    if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_BF16, BNN_F32); else BNN_GO_R(BNN_MATH_BF16, BNN_BF16);
-  } else {
-    if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_F32, BNN_F32); else BNN_GO_R(BNN_MATH_F32, BNN_BF16);
-  }
+    if (math == BNN_MATH_BF16) {
+      if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_BF16, BNN_F32); else BNN_GO_R(BNN_MATH_BF16, BNN_BF16);
+    } else {
+      if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_F32, BNN_F32); else BNN_GO_R(BNN_MATH_F32, BNN_BF16);
+    }
 #undef BNN_GO
 #undef BNN_GO_R
-  if (err != hipSuccess) return (int)err;
+    if (err != hipSuccess) return (int)err;
+  }
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-
   if (a->log_prior || a->log_q) {
     hipLaunchKernelGGL(bbb_layer_scalars_kernel, dim3(a->n_samples), dim3(256), 0, stream, k.ws, K, a->out_features,
                        a->prior, a->log_prior, a->log_q);
@@ -886,4 +945,56 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (err != hipSuccess) return (int)err;
   }
   return BNN_OK;
+}
+
+// Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
+// tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
+// the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
+extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
+  BbbK k;
+  bool al = false;
+  int rc = prepare(a, k, al);
+  if (rc != BNN_OK) return rc;
+  FinPack fp;
+  rc = make_fin(f, fp.k, fp.c);
+  if (rc != BNN_OK) return rc;
+  const int nl = f->n_layers;
+  const bool fuse = al && a->out_features <= 16 && a->batch <= 128 && a->want_stats && !f->local_reparam && nl >= 1 &&
+                    f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
+                    f->classes == a->out_features && f->batch == a->batch && a->y_dtype == BNN_F32 &&
+                    (a->n_samples == 1 || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
+                    env_int("BNN_HIP_FUSE_FINAL", 1) != 0;
+  if (!fuse) {
+    rc = bnn_bbb_linear_fwd(a, stream_);
+    if (rc != BNN_OK) return rc;
+    return bnn_elbo_finalize(f, stream_);
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  fp.sums = f->sums;
+  fp.ticket = f->ticket;
+  const int K = a->in_features;
+  const int ssteps = (K + 31) / 32;
+  int spw = 1;
+  while ((ssteps + spw - 1) / spw > 12) ++spw;
+  int nw = (ssteps + spw - 1) / spw;
+  nw = nw < 1 ? 1 : nw;
+  const long total = a->n_samples;                      // one tile, one batch block
+  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
+  const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
+  hipError_t err = hipSuccess;
+#define BNN_FIN(MATH, XDT)                                                                     \
+  do {                                                                                         \
+    err = allow_big_lds(bbb_fwd_final_kernel<MATH, XDT>, lds);                                 \
+    if (err == hipSuccess)                                                                     \
+      hipLaunchKernelGGL((bbb_fwd_final_kernel<MATH, XDT>), grid, block, lds, stream, k, fp);  \
+  } while (0)
+  if (a->math == BNN_MATH_BF16) {
+    if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_BF16, BNN_F32); else BNN_FIN(BNN_MATH_BF16, BNN_BF16);
+  } else {
+    if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_F32, BNN_F32); else BNN_FIN(BNN_MATH_F32, BNN_BF16);
+  }
+#undef BNN_FIN
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
 }

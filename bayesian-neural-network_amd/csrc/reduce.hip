@@ -2,6 +2,7 @@
 // (per-sample log p / log q / KL / NLL scalars of one ELBO evaluation), the Philox
 // epsilon materialiser, and the library's version/status entry points.
 #include "bnn_device.h"
+#include "bnn_fin.h"
 #include "../../include/bnn_hip.h"
 
 namespace bnn {
@@ -96,39 +97,10 @@ static inline int kl_blocks(long n) {
 }
 
 // ----------------------------------------------------------------------------- K4
-struct FinK {
-  const float* ws[8];
-  int lin[8], lout[8];
-  int n_layers, local_reparam, S, B, C;
-  bnn_prior prior;
-  const float* logits;
-  const void* target;
-  int nll_mode;
-  float nll_sigma;
-  float *log_prior, *log_q, *kl, *nll;
-  uint32_t* sample_counter;
-  uint32_t sample_counter_inc;
-};
-
 // grid = n_samples blocks (one sample each), or ONE block looping over all samples when
 // `single` (small n_samples): then the block also writes the 4-vector of sums, in sample order.
-// Latency-lean: every global load is issued before anything waits (headers, then partials and
-// logits together), partial sums go through fp32 wave shuffles (each thread holds at most a
-// few partials) and fp64 only across the 4 waves; all transcendental constants of the priors
-// arrive precomputed from the host.
-struct FinC {
-  double cnt_c0[8];      // count * c0                                  (log q constant)
-  double lp_const[8];    // count * (c0 - log sigma_p)                  (Gaussian log p constant)
-  double kl_const[8];    // 0.5 * (2 count log sigma_p - count)         (LR)
-  double inv2var;        // 1 / (2 sigma_p^2)
-  double reg_const;      // log(nll_sigma) - c0                          (regression NLL per element)
-  double reg_inv2var;    // 1 / (2 nll_sigma^2)
-};
-
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums) {
-  constexpr int NV = 25;                       // 3 sums x 8 layers + nll
-  __shared__ float part[4 * NV];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float part[4 * kFinNV];
   int T[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l)
@@ -136,93 +108,13 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
   const int s_begin = single ? 0 : blockIdx.x, s_end = single ? p.S : blockIdx.x + 1;
   double tot_a = 0, tot_b = 0, tot_n = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    float v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = 0.f;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      if (l < p.n_layers) {
-        const float4* ws = reinterpret_cast<const float4*>(p.ws[l]);
-        for (int t = threadIdx.x; t < T[l]; t += blockDim.x) {
-          if (p.local_reparam) {
-            const float4 q = ws[1 + t];
-            v[3 * l + 0] += q.x;                // sum log sigma
-            v[3 * l + 1] += q.y;                // sum sigma^2
-            v[3 * l + 2] += q.z;                // sum mu^2
-          } else {
-            const float4 q = ws[1 + (size_t)s * T[l] + t];
-            v[3 * l + 0] += q.x;                // sum eps^2
-            v[3 * l + 1] += q.y;                // sum w^2 | sum log p_mix
-            v[3 * l + 2] += ws[1 + t].z;        // sum log sigma (stored with sample 0)
-          }
-        }
-      }
-    }
-    if (p.nll && p.logits) {
-      const float* lg = p.logits + (size_t)s * p.B * p.C;
-      float acc = 0.f;
-      if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
-        const long long* tgt = reinterpret_cast<const long long*>(p.target);
-        for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
-          const float* row = lg + (size_t)b * p.C;
-          float mx = row[0];
-          for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
-          float se = 0.f;
-          for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
-          const long long tc = tgt[b];
-          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
-          acc += (mx + logf(se)) - picked;
-        }
-      } else {
-        const float* tgt = reinterpret_cast<const float*>(p.target);
-        const long tot = (long)p.B * p.C;
-        for (long i = threadIdx.x; i < tot; i += blockDim.x) {
-          const float d = tgt[i] - lg[i];
-          acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
-        }
-      }
-      v[NV - 1] = acc;
-    }
-    const int nv = 3 * p.n_layers;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (i < nv || i == NV - 1) {               // block-uniform
-        const float t = wave_sum(v[i]);
-        if (lane == 0) part[wave * NV + i] = t;
-      }
-    }
-    __syncthreads();
+    float a = 0.f, b = 0.f, nll = 0.f;
+    const float* lg = p.logits ? p.logits + (size_t)s * p.B * p.C : nullptr;
+    fin_sample(p, cst, s, T, lg, p.C, -1, 0.f, 0.f, 0.f, part, a, b, nll);
     if (threadIdx.x == 0) {
-      const int nwv = blockDim.x >> 6;
-      auto red = [&](int i) {
-        double t = 0;
-        for (int w = 0; w < nwv; ++w) t += (double)part[w * NV + i];
-        return t;
-      };
-      // per-layer fp32 rounding, then fp32 adds, as the reference sums l1 + l2 + l3
-      // (networks.py:174-181)
-      float a_tot = 0.f, b_tot = 0.f;
-      for (int l = 0; l < p.n_layers; ++l) {
-        const double r0 = red(3 * l), r1 = red(3 * l + 1), r2 = red(3 * l + 2);
-        if (p.local_reparam) {
-          a_tot += (float)(cst.kl_const[l] - r0 + (r1 + r2) * cst.inv2var);
-        } else {
-          const double lq = cst.cnt_c0[l] - r2 - 0.5 * r0;
-          const double lp = (p.prior.kind == BNN_PRIOR_GAUSS) ? cst.lp_const[l] - r1 * cst.inv2var : r1;
-          a_tot += (float)lp;
-          b_tot += (float)lq;
-        }
-      }
-      const float nll = (float)red(NV - 1);
-      if (p.local_reparam) {
-        if (p.kl) p.kl[s] = a_tot;
-      } else {
-        if (p.log_prior) p.log_prior[s] = a_tot;
-        if (p.log_q) p.log_q[s] = b_tot;
-      }
-      if (p.nll && p.logits) p.nll[s] = nll;
-      tot_a += a_tot;
-      tot_b += b_tot;
+      fin_store(p, s, a, b, nll);
+      tot_a += a;
+      tot_b += b;
       tot_n += nll;
     }
     if (s + 1 < s_end) __syncthreads();
@@ -326,45 +218,11 @@ extern "C" int bnn_gauss_kl(const float* mu, const float* rho, int64_t n, float 
 }
 
 extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
-  if (!a) return BNN_ERR_NULL;
-  if (a->struct_bytes != sizeof(bnn_finalize_args)) return BNN_ERR_ABI;
-  if (a->n_layers < 0 || a->n_layers > 8 || a->n_samples <= 0 || a->n_samples > 65535) return BNN_ERR_SHAPE;
-  if ((unsigned)a->prior.kind > 1u || (unsigned)a->nll_mode > 1u) return BNN_ERR_ENUM;
   FinK k;
-  for (int l = 0; l < 8; ++l) {
-    k.ws[l] = l < a->n_layers ? reinterpret_cast<const float*>(a->layer_workspace[l]) : nullptr;
-    k.lin[l] = l < a->n_layers ? a->layer_in[l] : 0;
-    k.lout[l] = l < a->n_layers ? a->layer_out[l] : 0;
-    if (l < a->n_layers) {
-      if (!k.ws[l]) return BNN_ERR_NULL;
-      if (reinterpret_cast<uintptr_t>(k.ws[l]) & 15) return BNN_ERR_ALIGN;
-      if (k.lin[l] <= 0 || k.lout[l] <= 0) return BNN_ERR_SHAPE;
-    }
-  }
-  if (a->n_layers > 0 && !(a->prior.kind == BNN_PRIOR_MIXTURE) && !(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
-  if (a->nll) {
-    if (!a->logits || !a->target) return BNN_ERR_NULL;
-    if (a->batch <= 0 || a->classes <= 0) return BNN_ERR_SHAPE;
-    if (a->nll_mode == BNN_NLL_REGRESSION && !(a->nll_sigma > 0.f)) return BNN_ERR_SHAPE;
-  }
-  k.n_layers = a->n_layers; k.local_reparam = a->local_reparam; k.S = a->n_samples; k.B = a->batch; k.C = a->classes;
-  k.prior = a->prior; k.logits = a->logits; k.target = a->target; k.nll_mode = a->nll_mode;
-  k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
-  k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
+  FinC cst;
+  const int rc = make_fin(a, k, cst);
+  if (rc != BNN_OK) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  FinC cst{};
-  const double c0 = -0.91893853320467274178;
-  const double sp = (a->prior.kind == BNN_PRIOR_MIXTURE) ? 1.0 : (double)a->prior.sigma_p;
-  for (int l = 0; l < a->n_layers; ++l) {
-    const double cnt = (double)a->layer_out[l] * a->layer_in[l] + a->layer_out[l];
-    cst.cnt_c0[l] = cnt * c0;
-    cst.lp_const[l] = cnt * (c0 - log(sp));
-    cst.kl_const[l] = 0.5 * (2.0 * cnt * log(sp) - cnt);
-  }
-  cst.inv2var = 1.0 / (2.0 * sp * sp);
-  const double ns = a->nll_sigma > 0.f ? (double)a->nll_sigma : 1.0;
-  cst.reg_const = log(ns) - c0;
-  cst.reg_inv2var = 1.0 / (2.0 * ns * ns);
   const int single = a->n_samples <= 16;
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single,
                      a->sums);

@@ -5,15 +5,22 @@ Workload (BASELINE.json configs[1], SURVEY §8(d) "C2"): the 784-1200-1200-10 BB
 batch 128, bf16 MFMA operands / fp32 statistics, synthetic inputs (mu~U(-0.2,0.2),
 rho~U(-5,-4), x~U(0,1), labels~U{0..9}; numpy RandomState seeds 1234/5678), Gaussian prior
 sigma_p=1, on-chip Philox epsilon.  One STEP = one forward-only ELBO evaluation of
-`--samples` MC samples per GPU: for every sample the full 3-layer forward, the sampled
-log p(w) / log q(w) reductions over all 2 395 210 stochastic parameters and the NLL
-(reference networks.py:199-203), i.e. one launch per layer + one finalize launch, replayed
-as a hipGraph.  With N>1 ranks every rank owns `--samples` samples of each evaluation (weak
-scaling) and the only collective is one RCCL sum all-reduce of the 4 ELBO scalars per step.
+`--samples` MC samples per GPU (default 1, as configs[1] names): for every sample the full
+3-layer forward, the sampled log p(w) / log q(w) reductions over all 2 395 210 stochastic
+parameters and the NLL (reference networks.py:199-203) — three kernel launches replayed as a
+hipGraph.  `--streams` independent evaluations are kept in flight per GPU (one hipGraph +
+HIP stream each; every evaluation still has `--samples` MC samples and its own Philox
+sample indices).  With N>1 ranks every rank owns `--samples` samples of each evaluation
+(weak scaling) and the only collective is one RCCL sum all-reduce of the 4 ELBO scalars per
+step.
 
-Prints ONE JSON line (rank 0).  value = total MC samples / s over all ranks.
+Prints ONE JSON line (rank 0).  value = total MC samples / s over all ranks; `roofline` is
+the dominant kernel (layer 2, 1200x1200 weights) against the HBM roof with SURVEY §8(d)'s
+algorithmic bytes; `cpu_baseline` is the parity-pinned CPU oracle timed on this host;
+`extras` are the same network at larger MC batches per evaluation (throughput regime).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -31,7 +38,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s me
 
 
 def algorithmic_bytes_layer(fin, fout, batch, x_bytes, y_bytes):
-    """(mu, rho) fp32 read once (8 B/param incl. bias) + x read + y written."""
+    """(mu, rho) fp32 read once per sample (8 B/param incl. bias, eps on chip,
+    w never stored) + x read + y written."""
     return 8 * (fin * fout + fout) + batch * fin * x_bytes + batch * fout * y_bytes
 
 
@@ -45,26 +53,105 @@ def build_net(dims, lr, batch, device):
     sd = synth.synth_state_dict(dims[0], dims[1], dims[2], lr)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     x, y = synth.synth_batch(mode, batch, dims[0], dims[2])
-    return net.to(device).train(), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device), sd
+    return net.to(device).train(), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)
 
 
-def time_kernel_alone(fn, reps, stream):
-    """Average duration of back-to-back launches of one kernel between two HIP events
-    recorded on the launch stream."""
+def n_stochastic(dims):
+    return sum(i * o + o for i, o in ((dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])))
+
+
+def run_steps(evs, steps, warmup, world, dist, results):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+    nstr = len(evs)
+
+    def step(i):
+        e = evs[i % nstr]
+        sums = e.replay()
+        if world > 1:
+            with torch.cuda.stream(e.stream) if e.stream is not None else contextlib.nullcontext():
+                results[i].copy_(sums)
+                dist.all_reduce(results[i], op=dist.ReduceOp.SUM, async_op=True)   # ELBO scalars only
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=results.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
+
+
+def make_evaluators(engine, net, x, y, S_global, nstr, graph=True):
+    streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
+    return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st) for st in streams]
+
+
+def kernel_alone_us(launch, stream, per_graph=20, reps=50):
+    """Average duration of one launch of a kernel: `per_graph` back-to-back launches captured in
+    a hipGraph, replayed `reps` times between two HIP events recorded on the launch stream."""
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(stream)
+    with torch.cuda.stream(side):
+        launch()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                launch()
+    stream.wait_stream(side)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        fn()
+        g.replay()
     e0.record(stream)
     for _ in range(reps):
-        fn()
+        g.replay()
     e1.record(stream)
     e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps   # us
+    return e0.elapsed_time(e1) * 1e3 / (reps * per_graph)
+
+
+def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
+    import bnn_hip
+    from bnn_hip import ops, _lib as L
+    hid_b = 4 if math_name == "f32" else 2
+    l2 = net.l2
+    pd = tuple(t.detach() for t in (l2.weight_mu, l2.weight_rho, l2.bias_mu, l2.bias_rho))
+    xin, ws, out = ev.bufs[0], ev.ws[1], ev.bufs[1]
+    mm = bnn_hip.runtime.state.math
+
+    def launch():
+        if lr:
+            ops.lr_linear_fwd(xin, *pd, n_samples=S_local, sigma_p=1.0, math_mode=mm, relu=True, y_dtype=out.dtype,
+                              eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_kl=True, workspace=ws, out=out)
+        else:
+            ops.bbb_linear_fwd(xin, *pd, n_samples=S_local, prior=l2._prior_spec, math_mode=mm, relu=True,
+                               y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True,
+                               workspace=ws, out=out)
+    us = kernel_alone_us(launch, torch.cuda.current_stream())
+    abytes = S_local * algorithmic_bytes_layer(dims[1], dims[1], batch, hid_b, hid_b)
+    achieved = abytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": ("lr_linear_fwd_kernel" if lr else "K1 bbb_linear_fwd") + f" layer 2 ({dims[1]}x{dims[1]})",
+            "algorithmic_bytes_per_launch": abytes, "mc_samples_per_launch": S_local, "avg_launch_us": us,
+            "note": "HIP events around back-to-back graph launches of this kernel on its stream (incl. the "
+                    "dependent-launch boundary); un-amortised 8 B/param/sample formula of SURVEY 8(d)"}
 
 
 def cpu_baseline(dims, lr, batch, budget_s=20.0):
-    """The oracle (op-for-op CPU restatement of the reference path, parity-pinned by
-    tests/golden) timed on this box's host cores: S=1 sample_elbo calls incl. the eps draw."""
+    """The oracle (op-for-op CPU restatement of the reference path, parity-pinned by tests/golden)
+    timed on this box's host cores: S=1 sample_elbo calls incl. the CPU eps draw, like the
+    reference's own loop body."""
     from oracle import bnn_oracle as O
     from bnn_hip import synth
     ncpu = os.cpu_count() or 1
@@ -84,18 +171,25 @@ def cpu_baseline(dims, lr, batch, budget_s=20.0):
             fn(p, xt, yt, 0.5, 1)
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
     return {"value": 1.0 / med, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} sample_elbo(S=1) calls of the CPU oracle incl. eps draw, median {med*1e3:.2f} ms, "
-                      f"os.cpu_count()={ncpu}",
+            "sample": f"{len(times)} sample_elbo(S=1) calls of the CPU oracle (fp32, no_grad, incl. eps draw) in "
+                      f"{sum(times):.1f} s, median {med*1e3:.2f} ms; os.cpu_count()={ncpu}; {model}",
             "kl_elements_per_s": p.n_stochastic() / med}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--net", default="mnist", choices=list(DIMS))
     ap.add_argument("--variant", default="bbb", choices=["bbb", "lr"])
@@ -108,13 +202,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import bnn_hip
-    from bnn_hip import engine, ops, _lib as L
+    from bnn_hip import engine
     bnn_hip.set_math(args.math)
     dist = None
     if world > 1:
@@ -124,102 +216,61 @@ def main():
         bnn_hip.shard_samples(True)
 
     dims, lr = DIMS[args.net], args.variant == "lr"
-    net, x, y, sd = build_net(dims, lr, args.batch, dev)
+    net, x, y = build_net(dims, lr, args.batch, dev)
     S_local, S_global = args.samples, args.samples * world
-    ev = engine.GraphedElbo(net, x, y, S_global, capture=not args.no_graph)
-    assert ev.n_local == S_local
+    nstr = max(1, args.streams)
+    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph)
+    assert evs[0].n_local == S_local
     results = torch.zeros((args.steps + args.warmup, 4), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream()
-
-    def step(i):
-        sums = ev.replay()
-        if world > 1:
-            results[i].copy_(sums)
-            dist.all_reduce(results[i], op=dist.ReduceOp.SUM, async_op=True)   # ELBO scalars only
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    e1.record(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms_per_step = dt * 1e3 / args.steps
+    dt = run_steps(evs, args.steps, args.warmup, world, dist, results)
     value = S_global * args.steps / dt
-    n_stoch = sum(dims_in * dims_out + dims_out for dims_in, dims_out in
-                  [(dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])])
+    nst = n_stochastic(dims)
+    layers = "-".join(map(str, (dims[0], dims[1], dims[1], dims[2])))
 
     out = {
-        "metric": "MC-forward-samples/sec (784-1200-1200-10 BNN: 3-layer forward + log p/log q reductions + NLL per sample)"
-        if args.net == "mnist" else f"MC-forward-samples/sec ({args.net})",
+        "metric": "MC-forward-samples/sec + KL-elements/sec, 784-1200-1200-10 BNN" if args.net == "mnist"
+        else f"MC-forward-samples/sec + KL-elements/sec, {layers} BNN",
         "value": value, "unit": "MC-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.math if args.math == "f32" else "bf16", "data": "synthetic",
-        "config": {"workload": f"{'x'.join(map(str, dims))if False else '-'.join(map(str,(dims[0],dims[1],dims[1],dims[2])))} "
-                               f"{'LR' if lr else 'BBB'} forward-only ELBO evaluation, batch {args.batch}, "
-                               f"{S_local} MC sample(s) per GPU per step, Gaussian prior, on-chip Philox eps",
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"{layers} {'LR' if lr else 'BBB'} forward-only ELBO evaluation (3-layer forward + "
+                               f"log p/log q reductions over {nst} stochastic params + NLL per MC sample), batch "
+                               f"{args.batch}, {S_local} MC sample(s) per GPU per evaluation, {nstr} evaluation(s) in "
+                               f"flight per GPU, Gaussian prior, on-chip Philox eps",
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
-                   "stochastic_params": n_stoch, "hipgraph": not args.no_graph,
+                   "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
                    "parallelism": f"mc-sample-shard x{world} + allreduce(4 floats)/step" if world > 1 else "single GPU"},
-        "kl_elements_per_s": value * n_stoch,
-        "device_ms_per_step_events": e0.elapsed_time(e1) / args.steps,
+        "kl_elements_per_s": value * nst,
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (layer 2: 1200x1200 weights): algorithmic bytes per
-        # launch / average launch duration measured with HIP events on the launch stream.
-        hid_b = 4 if args.math == "f32" else 2
-        l2 = net.l2
-        fin2, fout2 = dims[1], dims[1]
-        xin = ev.bufs[0]
-        ws = ev.ws[1]
-        pd = tuple(t.detach() for t in (l2.weight_mu, l2.weight_rho, l2.bias_mu, l2.bias_rho))
-
-        def launch_l2():
-            if lr:
-                ops.lr_linear_fwd(xin, *pd, n_samples=S_local, sigma_p=1.0, math_mode=bnn_hip.runtime.state.math,
-                                  relu=True, y_dtype=ev.bufs[1].dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1,
-                                  want_kl=True, workspace=ws, out=ev.bufs[1])
-            else:
-                ops.bbb_linear_fwd(xin, *pd, n_samples=S_local, prior=l2._prior_spec,
-                                   math_mode=bnn_hip.runtime.state.math, relu=True, y_dtype=ev.bufs[1].dtype,
-                                   eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True, workspace=ws,
-                                   out=ev.bufs[1])
-        g = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(stream)
-        with torch.cuda.stream(side):
-            launch_l2()
-            with torch.cuda.graph(g, stream=side):
-                for _ in range(20):
-                    launch_l2()
-        stream.wait_stream(side)
-        torch.cuda.synchronize()
-        us = time_kernel_alone(g.replay, 50, stream) / 20.0
-        abytes = S_local * algorithmic_bytes_layer(fin2, fout2, args.batch, hid_b, hid_b)
-        achieved = abytes / (us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "lr_linear_fwd_kernel" if lr else "bbb_linear_fwd_kernel (layer 2, 1200x1200)",
-                           "algorithmic_bytes_per_launch": abytes, "avg_launch_us": us,
-                           "note": "back-to-back launches incl. the dependent-kernel boundary; un-amortised "
-                                   "8 B/param formula (params are cache-resident across launches at this size)"}
-        if not args.no_cpu_baseline and world == 1:
+        roof = layer2_roofline(evs[0], net, dims, args.batch, S_local, lr, args.math)
+        tj = os.path.join(REPO, "profiles", "traffic.json")      # measured by tools/collect_traffic.py (rocprofv3 --pmc)
+        if os.path.exists(tj):
+            try:
+                t = json.load(open(tj))
+                key = f"{args.variant}_S{S_local}_{args.math}"
+                if key in t:
+                    roof["traffic"] = t[key]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = t[key].get("source", "profiles/traffic.json")
+            except Exception:
+                pass
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, lr, args.batch)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_extras and args.net == "mnist":
+            extras = []
+            for (S, ns, steps) in ((8, 2, 300), (64, 1, 100), (256, 1, 40)):
+                e2 = make_evaluators(engine, net, x, y, S, ns)
+                d2 = run_steps(e2, steps, max(5, steps // 10), 1, None, None)
+                r2 = layer2_roofline(e2[0], net, dims, args.batch, S, lr, args.math)
+                extras.append({"mc_samples_per_evaluation": S, "evaluations_in_flight": ns, "steps": steps,
+                               "samples_per_s": S * steps / d2, "kl_elements_per_s": S * steps / d2 * nst,
+                               "us_per_evaluation": d2 * 1e6 / steps, "layer2_us_per_launch": r2["avg_launch_us"],
+                               "layer2_hbm_frac": r2["frac"]})
+                del e2
+            out["extras"] = extras
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -236,10 +236,20 @@ typedef struct bnn_finalize_args {
   uint32_t reserved;
   float* sums;                      /* optional float[4]: sums over the n_samples local samples of
                                        {log p | KL, log q | 0, nll, n_samples}: the vector a sharded
-                                       job all-reduces (one extra one-block kernel, fixed order) */
+                                       job all-reduces (fixed summation order) */
+  uint32_t* ticket;                 /* optional zero-initialised device word used by the fused
+                                       last-layer form (bnn_bbb_final_fwd) when n_samples > 1 */
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
+
+/* bnn_bbb_final_fwd — the LAST BBB layer of an evaluation together with its finalize: the
+ * same results as bnn_bbb_linear_fwd(layer) followed by bnn_elbo_finalize(fin) with
+ * fin->logits == layer->y and fin->layer_workspace[n_layers-1] == layer->workspace, but in ONE
+ * launch when the layer is a single feature tile (out_features <= 16, batch <= 128): the block
+ * that produced a sample's logits also forms its NLL (networks.py:183-190) and log p / log q
+ * (networks.py:174-178).  Falls back to the two launches otherwise. */
+int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into

@@ -391,3 +391,36 @@ def test_cpu_tensors_raise_no_fallback():
     layer = networks.BayesianLinear(4, 3, [-0.2, 0.2], [-5, -4], [1.0], False)
     with pytest.raises(bnn_hip.BnnHipError):
         layer(torch.rand(2, 4))
+
+
+def test_fused_final_layer_equals_two_launches(dev, monkeypatch):
+    """bnn_bbb_final_fwd (last layer + finalize in one launch, incl. the multi-sample ticket
+    path and the device sample counter) gives the same scalars as the two-launch form."""
+    from bnn_hip import engine
+    for math_mode in ("f32", "bf16"):
+        bnn_hip.set_math(math_mode)
+        for S in (1, 5):
+            net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+            x, y = synth.synth_batch("classification", 128, 784, 10)
+            xd, yd = t(x).to(dev), t(y).to(dev)
+            outs = []
+            for fuse in ("1", "0"):
+                monkeypatch.setenv("BNN_HIP_FUSE_FINAL", fuse)
+                bnn_hip.manual_seed(77, counter=1000)
+                ev = engine.GraphedElbo(net, xd, yd, S, capture=False)
+                sums1 = ev.replay().clone()
+                per1 = {k: v.clone() for k, v in ev.out.items()}
+                sums2 = ev.replay().clone()                 # counter advanced on device: fresh eps
+                outs.append((sums1, per1, sums2, ev.logits.clone(), int(ev.counter.item())))
+            (a1, p1, a2, lg_a, c_a), (b1, p2, b2, lg_b, c_b) = outs
+            assert c_a == c_b == 1000 + 3 * S                # warm-up + 2 replays
+            scale = float(lg_a.abs().max())                  # different tile geometry: fp32 sum order only
+            assert float((lg_a - lg_b).abs().max()) <= (5e-6 if math_mode == "f32" else 2e-3) * scale
+            tol = 1e-6 if math_mode == "f32" else 1e-3       # nll follows the logits
+            for k in p1:
+                close(p1[k], p2[k].cpu().numpy(), rtol=tol if k == "nll" else 1e-6)
+            close(a1, b1.cpu().numpy(), rtol=tol)
+            close(a2, b2.cpu().numpy(), rtol=tol)
+            assert not torch.equal(a1, a2)                   # second replay drew different eps
+            close(a1[:3], torch.stack([p1["log_prior"].sum(), p1["log_q"].sum(), p1["nll"].sum()]).cpu().numpy(),
+                  rtol=1e-6)
