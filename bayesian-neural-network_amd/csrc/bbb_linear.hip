@@ -75,18 +75,6 @@ struct BbbK {
 #define BNN_STAMP_RT(i)
 #endif
 
-// XCD-aware block -> work mapping (speed only, never correctness).  Blocks are dealt round-robin
-// over the 8 XCDs (block b and b+8 share an L2), so XCD x = b % 8 is given the contiguous
-// range [x*chunk, (x+1)*chunk) of the (tile-major, sample-minor) work list: the few feature
-// tiles an XCD touches keep their (mu, rho) resident in that XCD's 4 MiB L2 while the samples
-// stream through.  Returns false for the padding blocks of the last range.
-__device__ __forceinline__ bool xcd_work_item(int total, int& item) {
-  const int b = blockIdx.x;
-  const int chunk = (total + 7) >> 3;
-  item = (b & 7) * chunk + (b >> 3);
-  return (b >> 3) < chunk && item < total;
-}
-
 template <bool ALIGNED>
 __device__ __forceinline__ void load8(const float* __restrict__ p, int valid, float v[8]) {
   if (ALIGNED) {

@@ -115,15 +115,34 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     float acc = 0.f;
     if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
       const long long* tgt = reinterpret_cast<const long long*>(p.target);
-      for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
-        const float* row = lg + (size_t)b * ldc;
-        float mx = row[0];
-        for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
-        float se = 0.f;
-        for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
-        const long long tc = tgt[b];
-        const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
-        acc += (mx + logf(se)) - picked;
+      if (p.C <= 32) {                           // a thread per row
+        for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
+          const float* row = lg + (size_t)b * ldc;
+          float mx = row[0];
+          for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
+          float se = 0.f;
+          for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
+          const long long tc = tgt[b];
+          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
+          acc += (mx + logf(se)) - picked;
+        }
+      } else {                                   // a wave per row, lanes stride over the classes
+        const int nwv = blockDim.x >> 6;
+        for (int b = wave; b < p.B; b += nwv) {
+          const float* row = lg + (size_t)b * ldc;
+          float mx = -3.0e38f;
+          for (int cc = lane; cc < p.C; cc += 64) mx = fmaxf(mx, row[cc]);
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+          float se = 0.f;
+          for (int cc = lane; cc < p.C; cc += 64) se += expf(row[cc] - mx);
+          se = wave_sum(se);
+          if (lane == 0) {
+            const long long tc = tgt[b];
+            const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
+            acc += (mx + logf(se)) - picked;
+          }
+        }
       }
     } else {
       const float* tgt = reinterpret_cast<const float*>(p.target);

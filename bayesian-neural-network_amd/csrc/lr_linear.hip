@@ -1,17 +1,25 @@
 // K3  lr_linear_fwd — BayesianLinearLR.forward (reference networks.py:116-138) for all
-// locally owned MC samples of one layer in one launch.
+// locally owned MC samples of one layer in one launch:
 //
 //   m = x . M,  v = x^2 . softplus(rho)^2,  y = m + sqrt(v)*eps_act + (b_mu + sigma_b*eps_b)
 //
-// Same decomposition as K1 (bbb_linear.hip): grid (ceil(out/16), n_samples, ceil(batch/128)),
-// NW waves split the k-steps of one 16-feature tile, two accumulator sets (mean, variance)
-// share every x fragment.  Weights are stored [in, out] (networks.py:95-96), so lane (r,q)
-// gathers M[32t + 8q + j][n0 + r], j = 0..7: for each j the 16 lanes of a quad row read 64
-// contiguous bytes.  sigma^2 is formed on the fly from rho; the closed-form KL sums
-// (sum log sigma, sum sigma^2, sum mu^2; networks.py:113) are taken from the same registers
-// by the blocks of sample 0, so (M, rho) are read once for GEMMs and KL together.
-// eps_act is generated in the epilogue, in the D-fragment layout (4 consecutive features
-// of one batch row = one Philox call).
+// Same decomposition as K1a (bbb_linear.hip): 1-D XCD-aware grid over (feature tile, sample,
+// batch block); the 16 MFMA A rows carry F = 16/R features x R k-range classes so a single
+// sample already covers the chip without cross-block reduction; the block's NW waves split
+// the k-steps evenly; x fragments arrive as one batch of unconditional 16-byte loads at
+// clamped addresses; (M, rho) of the next step are prefetched.  Differences from K1a:
+//   * weights are stored [in, out] (networks.py:95-96): lane (r,q) GATHERS M[k0+8q+j][n],
+//     j = 0..7 (for each j the 16 lanes of a quad row read 64 contiguous bytes; the other
+//     half of each 128-byte line belongs to the neighbouring tile, which the XCD-aware order
+//     places on the same L2);
+//   * two accumulator sets (mean, variance) share every x fragment; x^2 is formed in fp32
+//     from the fragment and re-rounded;
+//   * nothing is sampled per weight: the closed-form KL sums (sum log sigma, sum sigma^2,
+//     sum mu^2; networks.py:113) come from the same registers in the blocks of sample 0, so
+//     (M, rho) are read once for both GEMMs and the KL;
+//   * eps_act is generated in the epilogue in the D-fragment layout (4 consecutive features
+//     of one batch row = one Philox call).
+// The mean and variance slabs go through the same LDS region one after the other.
 #include "bnn_device.h"
 #include "../../include/bnn_hip.h"
 
@@ -29,30 +37,56 @@ struct LrK {
   float* eps_act_dump;
   float* eps_b_dump;
   void* y;
-  float* partial;   // [T][4]
+  float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
   int eps_mode, want_kl, relu, y_bf16;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
 };
 
-template <int MATH, int XDT>
-__global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
+template <int MATH, int XDT, int R>
+__global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
+  constexpr int F = 16 / R, FG = F / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int nt = blockIdx.x, s = blockIdx.y, mb = blockIdx.z;
+  const int c = r / F, f = r % F;
   const int K = p.K, N = p.N, B = p.B;
-  const int n = nt * 16 + r;
+  const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
+  int item;
+  if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
+  const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
+  const int n = nt * F + f;
   const bool n_ok = n < N;
+  const int nc = min(n, N - 1);
   const int m0 = mb * 128;
   const int mtiles = min(8, (B - m0 + 15) >> 4);
+  const int ssteps = (K + 32 * R - 1) / (32 * R);
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
   const bool do_kl = p.want_kl && mb == 0 && s == 0;
-  const bool do_dump = nt >= 0;   // every (s, mb, nt) block owns distinct eps_act elements
-  const int ksteps = (K + 31) >> 5;
-  const char* xs = reinterpret_cast<const char*>(p.x) +
-                   (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+  const bool x_al = (K & 7) == 0;                             // 16-byte x fragments possible
+  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+
+  f32x4* slab = reinterpret_cast<f32x4*>(lds);
+  float* lds_bias = lds + (size_t)nw * 8 * 64 * 4;
+  float* lds_red = lds_bias + 16;
+
+  if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
+
+  // bias of the tile: parameters and eps fetched now, applied in the epilogue
+  float bmu_pre = 0.f, bsig_pre = 0.f, beps_pre = 0.f;
+  if (wave == nw - 1 && lane < F && n_ok) {
+    bmu_pre = p.b_mu[n];
+    bsig_pre = softplus(p.b_rho[n]);
+    if (p.eps_mode == BNN_EPS_PHILOX) {
+      float e4[4];
+      philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+      beps_pre = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+    } else if (p.eps_mode == BNN_EPS_MEMORY) {
+      beps_pre = p.eps_b[(size_t)s * N + n];
+    }
+    if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
+  }
 
   f32x4 am[8], av[8];
 #pragma unroll
@@ -62,134 +96,210 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
   }
   float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
 
-  for (int t = wave; t < ksteps; t += nw) {
-    const int k = t * 32 + q * 8;
+  // gathered (M, rho) fragment of super-step t: rows k0+8q+j of column n, clamped; prefetched.
+  float mu_n[8], rho_n[8];
+  auto load_params = [&](int t) {
+    const int k = (t * R + c) * 32 + q * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
+      mu_n[j] = p.w_mu[off];
+      rho_n[j] = p.w_rho[off];
+    }
+  };
+  if (wave < ssteps) load_params(wave);
+
+#pragma nounroll
+  for (int t = wave; t < ssteps; t += nw) {
+    const int k = (t * R + c) * 32 + q * 8;
+    constexpr int FR = (XDT == BNN_F32) ? 2 : 1;
+    constexpr int MC = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));
+    float4 xraw[MC * R * FR];
+    auto stage = [&](int ch) {
+#pragma unroll
+      for (int mm = 0; mm < MC; ++mm) {
+        const int row = m0 + (ch * MC + mm) * 16 + r;
+#pragma unroll
+        for (int cc = 0; cc < R; ++cc) {
+          const int xk = (t * R + cc) * 32 + q * 8;
+          if (x_al) {
+            const size_t off = (size_t)min(row, B - 1) * K + min(xk, K - 8);
+            if (XDT == BNN_F32) {
+              const float4* px = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xs) + off);
+              xraw[(mm * R + cc) * 2 + 0] = px[0];
+              xraw[(mm * R + cc) * 2 + 1] = px[1];
+            } else {
+              xraw[mm * R + cc] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xs) + off);
+            }
+          } else {                                   // any K: guarded element loads
+            const size_t ro = (size_t)min(row, B - 1) * K;
+            if (XDT == BNN_F32) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = (xk + j < K) ? reinterpret_cast<const float*>(xs)[ro + xk + j] : 0.f;
+              xraw[(mm * R + cc) * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+              xraw[(mm * R + cc) * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              bf16x8 vb;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                vb[j] = (xk + j < K) ? reinterpret_cast<const __bf16*>(xs)[ro + xk + j] : (__bf16)0.0f;
+              xraw[mm * R + cc] = __builtin_bit_cast(float4, vb);
+            }
+          }
+        }
+      }
+    };
+    stage(0);
+
     float mu[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool ok = n_ok && (k + j) < K;
-      const size_t off = (size_t)(k + j) * N + n;
-      const float m_ = ok ? p.w_mu[off] : 0.f;
-      const float rho = ok ? p.w_rho[off] : 0.f;
-      const float sig = softplus(rho);
-      mu[j] = m_;
-      s2[j] = ok ? sig * sig : 0.f;
-      if (do_kl) {
-        s_ls += ok ? fast_log(sig) : 0.f;
-        s_s2 += s2[j];
-        s_m2 = __builtin_fmaf(m_, m_, s_m2);
-      }
+      mu[j] = mu_n[j];
+      s2[j] = rho_n[j];
     }
-    bf16x8 ma, sa;
+    if (t + nw < ssteps) load_params(t + nw);
+
+    float ls = 0.f, a2 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = n_ok && (k + j) < K;
+      const float sig = softplus(s2[j]);
+      if (do_kl) {
+        ls += ok ? fast_log(sig) : 0.f;
+        a2 += ok ? sig * sig : 0.f;
+        m2 += ok ? mu[j] * mu[j] : 0.f;
+      }
+      mu[j] = ok ? mu[j] : 0.f;
+      s2[j] = ok ? sig * sig : 0.f;
+    }
+    s_ls += ls;
+    s_s2 += a2;
+    s_m2 += m2;
+
+    bf16x8 ma, sa, wz;
     if (MATH == BNN_MATH_BF16) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ma[j] = (__bf16)mu[j];
         sa[j] = (__bf16)s2[j];
+        wz[j] = (__bf16)0.f;
       }
     }
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < mtiles) {
-        const int row = m0 + m * 16 + r;
-        float xv[8];
+    for (int ch = 0; ch < 8 / MC; ++ch) {
+      if (ch * MC < mtiles) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = row < B && (k + j) < K;
-          const long off = (long)row * K + k + j;
-          if (XDT == BNN_F32)
-            xv[j] = ok ? reinterpret_cast<const float*>(xs)[off] : 0.f;
-          else
-            xv[j] = ok ? (float)reinterpret_cast<const __bf16*>(xs)[off] : 0.f;
-        }
-        if (MATH == BNN_MATH_BF16) {
-          bf16x8 xb, x2b;
+        for (int mm = 0; mm < MC; ++mm) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            xb[j] = (__bf16)xv[j];
-            x2b[j] = (__bf16)(xv[j] * xv[j]);
+          for (int cc = 0; cc < R; ++cc) {
+            const int m = ch * MC + mm;
+            float xv[8];
+            if (XDT == BNN_F32) {
+              const float4 lo = xraw[(mm * R + cc) * 2], hi = xraw[(mm * R + cc) * 2 + 1];
+              xv[0] = lo.x; xv[1] = lo.y; xv[2] = lo.z; xv[3] = lo.w;
+              xv[4] = hi.x; xv[5] = hi.y; xv[6] = hi.z; xv[7] = hi.w;
+            } else {
+              const bf16x8 xb = __builtin_bit_cast(bf16x8, xraw[mm * R + cc]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) xv[j] = (float)xb[j];
+            }
+            if (MATH == BNN_MATH_BF16) {
+              bf16x8 xb, x2b;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                xb[j] = (__bf16)xv[j];
+                x2b[j] = (__bf16)(xv[j] * xv[j]);
+              }
+              am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? ma : wz, xb, am[m], 0, 0, 0);
+              av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? sa : wz, x2b, av[m], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                am[m] = __builtin_amdgcn_mfma_f32_16x16x4f32((R == 1 || c == cc) ? mu[j] : 0.f, xv[j], am[m], 0, 0, 0);
+                av[m] = __builtin_amdgcn_mfma_f32_16x16x4f32((R == 1 || c == cc) ? s2[j] : 0.f, xv[j] * xv[j], av[m], 0, 0, 0);
+              }
+            }
           }
-          am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xb, am[m], 0, 0, 0);
-          av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, x2b, av[m], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            am[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(mu[j], xv[j], am[m], 0, 0, 0);
-            av[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s2[j], xv[j] * xv[j], av[m], 0, 0, 0);
-          }
         }
+        if ((ch + 1) * MC < 8 && (ch + 1) * MC < mtiles) stage(ch + 1);
       }
     }
   }
 
-  // ---- bias (wave 0, lanes 0..15)
-  const size_t slab_floats = (size_t)nw * 8 * 64 * 4;
-  float* lds_bias = lds + 2 * slab_floats;
-  float* lds_red = lds_bias + 16;
-  if (wave == 0 && q == 0) {
+  // ---- bias + its KL terms
+  if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
-    if (n_ok) {
-      const float bmu = p.b_mu[n], sig = softplus(p.b_rho[n]);
-      float e = 0.f;
-      if (p.eps_mode == BNN_EPS_PHILOX) {
-        float e4[4];
-        philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
-        e = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
-      } else if (p.eps_mode == BNN_EPS_MEMORY) {
-        e = p.eps_b[(size_t)s * N + n];
-      }
-      if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = e;
-      b = __builtin_fmaf(sig, e, bmu);
+    if (lane < F && n_ok) {
+      b = __builtin_fmaf(bsig_pre, beps_pre, bmu_pre);
       if (do_kl) {
-        s_ls += fast_log(sig);
-        s_s2 = __builtin_fmaf(sig, sig, s_s2);
-        s_m2 = __builtin_fmaf(bmu, bmu, s_m2);
+        s_ls += fast_log(bsig_pre);
+        s_s2 = __builtin_fmaf(bsig_pre, bsig_pre, s_s2);
+        s_m2 = __builtin_fmaf(bmu_pre, bmu_pre, s_m2);
       }
     }
-    lds_bias[r] = b;
+    lds_bias[lane] = b;
   }
-
-  f32x4* slab_m = reinterpret_cast<f32x4*>(lds);
-  f32x4* slab_v = reinterpret_cast<f32x4*>(lds + slab_floats);
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < mtiles) {
-      slab_m[(wave * 8 + m) * 64 + lane] = am[m];
-      slab_v[(wave * 8 + m) * 64 + lane] = av[m];
-    }
   if (do_kl) {
-    const float a = wave_sum(s_ls), b = wave_sum(s_s2), c = wave_sum(s_m2);
+    const float a = wave_sum(s_ls), b = wave_sum(s_s2), cc = wave_sum(s_m2);
     if (lane == 0) {
       lds_red[wave * 3 + 0] = a;
       lds_red[wave * 3 + 1] = b;
-      lds_red[wave * 3 + 2] = c;
+      lds_red[wave * 3 + 2] = cc;
     }
   }
-  __syncthreads();
 
+  // ---- cross-wave reduction: mean slabs, then variance slabs, through the same LDS region.
+  // Each thread owns at most NI output items (batch row x 4 consecutive features).
+  constexpr int NI = 2;
+  f32x4 vm[NI], vv[NI];
+  auto reduce_items = [&](f32x4 (&out)[NI]) {
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) {
+      const int it = threadIdx.x + ii * blockDim.x;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (it < mtiles * 16 * FG) {
+        const int m = it / (16 * FG), rem = it - m * (16 * FG), fg = rem >> 4, b = rem & 15;
+#pragma unroll 4
+        for (int wv = 0; wv < nw; ++wv) {
+#pragma unroll
+          for (int cc = 0; cc < R; ++cc) v += slab[(wv * 8 + m) * 64 + (cc * FG + fg) * 16 + b];
+        }
+      }
+      out[ii] = v;
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = am[m];
+  __syncthreads();
+  reduce_items(vm);
   if (do_kl && threadIdx.x == 0) {
-    float a = 0.f, b = 0.f, c = 0.f;
+    float a = 0.f, b = 0.f, cc = 0.f;
     for (int wv = 0; wv < nw; ++wv) {
       a += lds_red[wv * 3 + 0];
       b += lds_red[wv * 3 + 1];
-      c += lds_red[wv * 3 + 2];
+      cc += lds_red[wv * 3 + 2];
     }
-    reinterpret_cast<float4*>(p.partial)[1 + nt] = make_float4(a, b, c, 0.f);
-    if (nt == 0) reinterpret_cast<float4*>(p.partial)[0] = make_float4(__int_as_float((int)gridDim.x), 0.f, 0.f, 0.f);
+    p.ws[1 + nt] = make_float4(a, b, cc, 0.f);
   }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = av[m];
+  __syncthreads();
+  reduce_items(vv);
 
+  // ---- epilogue: y = m + sqrt(v) * eps + b  [-> ReLU]
   const bool vec_ok = (N & 3) == 0;
   const int gprN = (N + 3) >> 2;
-  for (int item = threadIdx.x; item < mtiles * 64; item += blockDim.x) {
-    const int m = item >> 6, l = item & 63;
-    f32x4 vm = slab_m[m * 64 + l], vv = slab_v[m * 64 + l];
-    for (int wv = 1; wv < nw; ++wv) {
-      vm += slab_m[(wv * 8 + m) * 64 + l];
-      vv += slab_v[(wv * 8 + m) * 64 + l];
-    }
-    const int brow = m0 + m * 16 + (l & 15);
-    const int f0 = (l >> 4) * 4;
-    const int nb = nt * 16 + f0;
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii) {
+    const int it = threadIdx.x + ii * blockDim.x;
+    if (it >= mtiles * 16 * FG) continue;
+    const int m = it / (16 * FG), rem = it - m * (16 * FG), fg = rem >> 4, b = rem & 15;
+    const int brow = m0 + m * 16 + b;
+    const int nb = nt * F + fg * 4;
     if (brow >= B || nb >= N) continue;
     const size_t yoff = ((size_t)s * B + brow) * N + nb;
     float e4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -200,7 +310,7 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
       for (int i = 0; i < 4; ++i)
         if (nb + i < N) e4[i] = p.eps_act[yoff + i];
     }
-    if (p.eps_act_dump && do_dump) {
+    if (p.eps_act_dump) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (nb + i < N) p.eps_act_dump[yoff + i] = e4[i];
@@ -208,7 +318,7 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv[i]), e4[i], vm[i]) + lds_bias[f0 + i];
+      float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv[ii][i]), e4[i], vm[ii][i]) + lds_bias[fg * 4 + i];
       if (p.relu) o = fmaxf(o, 0.f);
       v[i] = o;
     }
@@ -241,14 +351,14 @@ __global__ __launch_bounds__(256) void lr_linear_fwd_kernel(const LrK p) {
 // weights and biases together (the network only needs the total); the bias term is small
 // (N elements) and is recomputed here so that weight_kl_cost / bias_kl_cost can be
 // reported separately.  out3 = {kl, weight_kl, bias_kl}.
-__global__ void lr_layer_kl_kernel(const float* __restrict__ partial, int K, int N, float sigma_p,
+__global__ void lr_layer_kl_kernel(const float4* __restrict__ ws, int K, int N, float sigma_p,
                                    const float* __restrict__ b_mu, const float* __restrict__ b_rho,
                                    float* __restrict__ out3) {
   __shared__ double scratch[16];
   double ls = 0, s2 = 0, m2 = 0, bls = 0, bs2 = 0, bm2 = 0;
-  const int T = __float_as_int(reinterpret_cast<const float4*>(partial)[0].x);
+  const int T = __float_as_int(ws[0].x);
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(partial)[1 + t];
+    const float4 v = ws[1 + t];
     ls += v.x;
     s2 += v.y;
     m2 += v.z;
@@ -284,16 +394,20 @@ extern "C" size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features) {
   return (1 + (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
 }
 
+static int lr_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_lr_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
-  if (a->n_samples > 65535 || (a->batch + 127) / 128 > 65535) return BNN_ERR_SHAPE;
+  if ((double)a->n_samples * ((a->batch + 127) / 128) * ((a->out_features + 3) / 4) > 2.0e9) return BNN_ERR_SHAPE;
   if (!a->x || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->y) return BNN_ERR_NULL;
   if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u)
     return BNN_ERR_ENUM;
   if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_act || !a->eps_b)) return BNN_ERR_NULL;
-  const int T = (a->out_features + 15) / 16;
   if (a->want_kl) {
     if (!a->workspace || a->workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(a->out_features))
       return BNN_ERR_WORKSPACE;
@@ -303,6 +417,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   if (a->kl_out && !a->want_kl) return BNN_ERR_WORKSPACE;
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
+  if ((a->in_features % 8 == 0) && (reinterpret_cast<uintptr_t>(a->x) & 15)) return BNN_ERR_ALIGN;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 
   LrK k;
@@ -311,29 +426,54 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
-  k.partial = reinterpret_cast<float*>(a->workspace);
+  k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.want_kl = a->want_kl ? 1 : 0; k.relu = a->relu ? 1 : 0; k.y_bf16 = ybf;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
 
-  const int ksteps = (a->in_features + 31) / 32;
-  int nw = ksteps / 3;
-  nw = nw < 1 ? 1 : (nw > 4 ? 4 : nw);
-  const dim3 grid(T, a->n_samples, (a->batch + 127) / 128), block(nw * 64);
-  const size_t lds = (2 * (size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);
-#define BNN_LAUNCH(MATH, XDT) hipLaunchKernelGGL((lr_linear_fwd_kernel<MATH, XDT>), grid, block, lds, stream, k)
+  // launch geometry: a function of the shape only
+  const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
+  int R = 1;
+  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
+  const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
+  if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
+  const int F = 16 / R;
+  const int ssteps = (K + 32 * R - 1) / (32 * R);
+  int spw = 1;
+  while ((ssteps + spw - 1) / spw > 8) ++spw;
+  int nw = (ssteps + spw - 1) / spw;
+  nw = nw < 1 ? 1 : nw;
+  const long total = (long)((N + F - 1) / F) * a->n_samples * mbs;
+  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
+  const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+  hipError_t err = hipSuccess;
+#define BNN_LR(MATH, XDT, RR)                                                                       \
+  do {                                                                                              \
+    if (lds > 64 * 1024)                                                                            \
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fwd_kernel<MATH, XDT, RR>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+    if (err == hipSuccess) hipLaunchKernelGGL((lr_fwd_kernel<MATH, XDT, RR>), grid, block, lds, stream, k); \
+  } while (0)
+#define BNN_LR_R(MATH, XDT)                      \
+  do {                                           \
+    if (R == 1) BNN_LR(MATH, XDT, 1);            \
+    else if (R == 2) BNN_LR(MATH, XDT, 2);       \
+    else BNN_LR(MATH, XDT, 4);                   \
+  } while (0)
   if (a->math == BNN_MATH_BF16) {
-    if (a->x_dtype == BNN_F32) BNN_LAUNCH(BNN_MATH_BF16, BNN_F32); else BNN_LAUNCH(BNN_MATH_BF16, BNN_BF16);
+    if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_BF16, BNN_F32); else BNN_LR_R(BNN_MATH_BF16, BNN_BF16);
   } else {
-    if (a->x_dtype == BNN_F32) BNN_LAUNCH(BNN_MATH_F32, BNN_F32); else BNN_LAUNCH(BNN_MATH_F32, BNN_BF16);
+    if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_F32, BNN_F32); else BNN_LR_R(BNN_MATH_F32, BNN_BF16);
   }
-#undef BNN_LAUNCH
-  hipError_t err = hipGetLastError();
+#undef BNN_LR
+#undef BNN_LR_R
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->kl_out) {
-    hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.partial, a->in_features,
-                       a->out_features, a->sigma_p, a->b_mu, a->b_rho, a->kl_out);
+    hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.ws, K, N, a->sigma_p, a->b_mu, a->b_rho,
+                       a->kl_out);
     err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }
