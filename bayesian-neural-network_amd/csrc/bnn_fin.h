@@ -131,11 +131,13 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
         for (int b = wave; b < p.B; b += nwv) {
           const float* row = lg + (size_t)b * ldc;
           float mx = -3.0e38f;
-          for (int cc = lane; cc < p.C; cc += 64) mx = fmaxf(mx, row[cc]);
+#pragma unroll 8
+          for (int cc = lane; cc < p.C; cc += 64) mx = fmaxf(mx, row[cc]);     // 8 loads in flight
 #pragma unroll
           for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
           float se = 0.f;
-          for (int cc = lane; cc < p.C; cc += 64) se += expf(row[cc] - mx);
+#pragma unroll 8
+          for (int cc = lane; cc < p.C; cc += 64) se += __expf(row[cc] - mx);
           se = wave_sum(se);
           if (lane == 0) {
             const long long tc = tgt[b];
