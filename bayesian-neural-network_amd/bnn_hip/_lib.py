@@ -21,7 +21,7 @@ EXPORTS = (
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_philox_normal", "bnn_cast_bf16",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16",
 )
 
 
@@ -78,7 +78,7 @@ class FinalizeArgs(C.Structure):
         ("nll_mode", C.c_int32), ("nll_sigma", C.c_float),
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p), ("kl", C.c_void_p), ("nll", C.c_void_p),
         ("sample_counter", C.c_void_p), ("sample_counter_inc", C.c_uint32), ("reserved", C.c_uint32),
-        ("sums", C.c_void_p), ("ticket", C.c_void_p),
+        ("sums", C.c_void_p), ("ticket", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
     ]
 
 
@@ -121,6 +121,8 @@ def load():
                                  C.c_void_p, C.c_void_p]
     lib.bnn_elbo_finalize.restype = C.c_int
     lib.bnn_elbo_finalize.argtypes = [C.POINTER(FinalizeArgs), C.c_void_p]
+    lib.bnn_bbb_final_scratch_bytes.restype = C.c_size_t
+    lib.bnn_bbb_final_scratch_bytes.argtypes = [C.c_int32]
     lib.bnn_bbb_final_fwd.restype = C.c_int
     lib.bnn_bbb_final_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.c_void_p]
     lib.bnn_philox_normal.restype = C.c_int

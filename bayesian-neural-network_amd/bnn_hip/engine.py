@@ -163,7 +163,8 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
             fin_kw = dict(layer_in=[sp.in_out[0] for sp in layers], layer_out=[sp.in_out[1] for sp in layers],
                           local_reparam=local_reparam, prior=layers[0].m._prior_spec, n_samples=n_local, target=target,
                           mode=mode, nll_sigma=float(sigma),
-                          ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None)
+                          ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None,
+                          scratch=None if local_reparam else ops.final_scratch(n_local, dev))
         logits, stats = run_layers(layers, x, n_local, first_global + lo, want_stats=True, sample=True,
                                    injected=injected, differentiable=differentiable,
                                    fin_kw=fin_kw if not local_reparam else None)
@@ -234,6 +235,7 @@ class GraphedElbo:
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
         self.sums = torch.zeros(4, dtype=torch.float32, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = None if self.lr else ops.final_scratch(S, dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and S >= CAST_INPUT_MIN_SAMPLES) else None)
         self.graph = None
@@ -261,7 +263,7 @@ class GraphedElbo:
                       local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
                       sample_counter_inc=self.samples * self.stride, out=self.out, sums=self.sums,
-                      ticket=self.ticket)
+                      ticket=self.ticket, scratch=self.scratch)
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,

@@ -83,6 +83,12 @@ def bbb_workspace(n_samples: int, out_features: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
+def final_scratch(n_samples: int, device) -> torch.Tensor:
+    """Zeroed scratch for the fused last layer (K-range slices per sample)."""
+    nbytes = L.load().bnn_bbb_final_scratch_bytes(n_samples)
+    return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+
 def lr_workspace(out_features: int, device) -> torch.Tensor:
     nbytes = L.load().bnn_lr_linear_fwd_workspace_bytes(out_features)
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
@@ -204,7 +210,7 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
 def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
                logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
                nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
-               ticket=None):
+               ticket=None, scratch=None):
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -248,8 +254,10 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
     a.sample_counter, a.sample_counter_inc = _ptr(sample_counter), int(sample_counter_inc)
     a.sums = _ptr(sums)
     a.ticket = _ptr(ticket)
+    a.scratch = _ptr(scratch)
+    a.scratch_bytes = scratch.numel() * scratch.element_size() if scratch is not None else 0
     a.log_prior, a.log_q, a.kl, a.nll = _ptr(out["log_prior"]), _ptr(out["log_q"]), _ptr(out["kl"]), _ptr(out["nll"])
-    keep += [sample_counter, sums, ticket] + list(workspaces)
+    keep += [sample_counter, sums, ticket, scratch] + list(workspaces)
     return a, out, keep
 
 

@@ -175,7 +175,8 @@ __device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brh
 template <int R>
 __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __restrict__ slab,
                                                const float* __restrict__ lds_bias, int nw, int mtiles, int nt, int s,
-                                               int m0, float* __restrict__ lds_out = nullptr) {
+                                               int m0, float* __restrict__ lds_out = nullptr,
+                                               float* __restrict__ raw_out = nullptr) {
   constexpr int F = 16 / R, FG = F / 4;
   const int N = p.N, B = p.B;
   const bool vec_ok = (N & 3) == 0;
@@ -191,6 +192,12 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
     }
     const int brow = m0 + m * 16 + b;
     const int nb = nt * F + fg * 4;
+    if (raw_out) {                                 // K-slice partial of the fused last layer: no ReLU yet
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += lds_bias[fg * 4 + i];
+      *reinterpret_cast<f32x4*>(raw_out + (m * 16 + b) * 16 + fg * 4) = v;
+      continue;
+    }
     if (brow >= B || nb >= N) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -234,6 +241,10 @@ struct FinPack {
   FinC c;
   float* sums;          // float[4] or nullptr
   uint32_t* ticket;     // zero-initialised word: arrival counter of the sample blocks
+  int ks;               // K-range slices per sample (blocks per sample); 1: no cross-block stage
+  uint32_t* ks_ticket;  // [S] zero-initialised arrival counters of a sample's slice blocks
+  float4* ks_stats;     // [S*ks] per-slice {sum eps^2, sum w^2|log p_mix, sum log sigma, 0}
+  float* ks_tiles;      // [S*ks][128*16] per-slice partial logits (fp32, bias in slice 0)
 };
 
 // FINAL: this launch is the last layer of an ELBO evaluation (one 16-feature tile, batch <= 128):
@@ -249,7 +260,10 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   const int K = p.K, N = p.N, B = p.B;
   const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
   int item;
-  if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
+  const int KS = FINAL ? fp->ks : 1;                          // K-range slices per sample (FINAL only)
+  if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return;   // block-uniform
+  const int ks = item % KS;
+  item /= KS;
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int n = nt * F + f;
   const bool n_ok = n < N;
@@ -257,6 +271,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   const int m0 = mb * 128;
   const int mtiles = min(8, (B - m0 + 15) >> 4);
   const int ssteps = (K + 32 * R - 1) / (32 * R);
+  const int spb = (ssteps + KS - 1) / KS;                      // super-steps per K-range slice
+  const int t_lo = ks * spb, t_hi = min(ssteps, t_lo + spb);
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
   const bool do_stats = p.want_stats && mb == 0;
   const bool do_ls = do_stats && (s == 0 || FINAL);
@@ -275,7 +291,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-  if (do_stats && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
+  if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0)
+    p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
 
   // (mu, rho) of this lane for super-step t: prefetched one step ahead.
   float mu_n[8], rho_n[8];
@@ -292,17 +309,17 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       load8<false>(p.w_rho + woff, valid, rho_n);
     }
   };
-  if (wave < ssteps) load_params(wave);
+  if (t_lo + wave < t_hi) load_params(t_lo + wave);
   // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (wave == nw - 1 && lane < F && n_ok) {          // the last wave owns the fewest k-steps
+  if (wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
     beps_pre = bias_eps(p, n, s, gs, do_dump);
   }
 
 #pragma nounroll
-  for (int t = wave; t < ssteps; t += nw) {
+  for (int t = t_lo + wave; t < t_hi; t += nw) {
     const int k = (t * R + c) * 32 + q * 8;
     const int valid = n_ok ? min(8, K - k) : 0;     // ALIGNED: 8 or <= 0
     // ---- x fragments of the first batch-tile chunk, issued ahead of the generator work.
@@ -353,8 +370,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       mu[j] = mu_n[j];
       sg[j] = rho_n[j];
     }
-    if (t + nw < ssteps) load_params(t + nw);
-    if (t == wave) { asm volatile("" :: "v"(mu[0]), "v"(sg[0])); BNN_STAMP(1); }
+    if (t + nw < t_hi) load_params(t + nw);
+    if (t == t_lo + wave) { asm volatile("" :: "v"(mu[0]), "v"(sg[0])); BNN_STAMP(1); }
 
     float e[8], w[8];
     if (p.eps_mode == BNN_EPS_PHILOX) {
@@ -400,7 +417,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) w[j] = 0.f;
     }
-    if (t == wave) { asm volatile("" :: "v"(w[0]), "v"(w[7])); BNN_STAMP(2); }
+    if (t == t_lo + wave) { asm volatile("" :: "v"(w[0]), "v"(w[7])); BNN_STAMP(2); }
     bf16x8 wa, wz;
     if (MATH == BNN_MATH_BF16) {
 #pragma unroll
@@ -454,7 +471,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   // ---- bias of the tile's F features: wave 0, lanes 0..F-1
   if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
-    if (lane < F && n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    if (lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
     lds_bias[lane] = b;
   }
 #pragma unroll
@@ -478,10 +495,12 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       own1 += lds_red[wv * 3 + 1];
       own2 += lds_red[wv * 3 + 2];
     }
-    p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
+    if (KS == 1) p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
   }
   float* fin_lg = lds_red + 3 * nw;               // FINAL only: [128][16] final logits + reduce scratch
-  epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
+  if (!FINAL || KS == 1) {
+    epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
+  }
   BNN_STAMP(6);
   BNN_STAMP_RT(9);
   if (FINAL) {
@@ -491,6 +510,59 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
     for (int l = 0; l < 8; ++l)
       T[l] = (l < fk.n_layers - 1) ? __float_as_int(reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
+    if (KS > 1) {
+      // ---- K-range slices of one sample meet here (placement-independent hand-off: every storing
+      // wave drains its stores, one lane releases at agent scope, takes a ticket; the last
+      // arriver acquires, then sums the slices' partial tiles in slice order).
+      float* mine = fp->ks_tiles + ((size_t)s * KS + ks) * (128 * 16);
+      epilogue_store<R>(p, slab, lds_bias, nw, 8, nt, s, m0, nullptr, mine);
+      if (threadIdx.x == 0) fp->ks_stats[(size_t)s * KS + ks] = make_float4(own0, own1, own2, 0.f);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      uint32_t* flag = reinterpret_cast<uint32_t*>(part);          // LDS broadcast of "I am last"
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(fp->ks_ticket + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = (tk == (uint32_t)KS - 1u) ? 1u : 0u;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      if (*flag == 0u) return;                                    // block-uniform
+      __syncthreads();
+      const float* tiles = fp->ks_tiles + (size_t)s * KS * (128 * 16);
+      for (int it = threadIdx.x; it < 128 * 4; it += blockDim.x) {   // (batch row, 4 consecutive features)
+        const int brow = it >> 2, fg = it & 3;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KS; ++j) v += *reinterpret_cast<const f32x4*>(tiles + (size_t)j * (128 * 16) + brow * 16 + fg * 4);
+        if (p.relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(fin_lg + brow * 16 + fg * 4) = v;
+        if (brow < B) {
+          float* yp = reinterpret_cast<float*>(p.y) + ((size_t)s * B + brow) * N + fg * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (fg * 4 + i < N) yp[i] = v[i];
+        }
+      }
+      if (threadIdx.x == 0) {
+        own0 = own1 = own2 = 0.f;
+        for (int j = 0; j < KS; ++j) {
+          const float4 q4 = fp->ks_stats[(size_t)s * KS + j];
+          own0 += q4.x;
+          own1 += q4.y;
+          own2 += q4.z;
+        }
+        p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
+        fp->ks_ticket[s] = 0u;                                    // ready for the next launch
+      }
+    }
     __syncthreads();                               // logits tile complete in LDS
     float a = 0.f, b = 0.f, nll = 0.f;
     // thread 0 supplies this layer's own partial sums directly (every FINAL block computes its
@@ -507,10 +579,12 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       } else {
         // last-arriving sample block folds the per-sample scalars (sample order) and advances
         // the Philox sample counter: every block has read it by the time it takes a ticket.
-        __threadfence();
-        const uint32_t tk = atomicAdd(fp->ticket, 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(fp->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tk == (uint32_t)fk.S - 1u) {
-          __threadfence();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (fp->sums) {
             double ta = 0, tb = 0, tn = 0;
             const float* pa = fk.local_reparam ? fk.kl : fk.log_prior;
@@ -935,6 +1009,16 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   return BNN_OK;
 }
 
+static constexpr int kFinalMaxSlices = 8;
+
+// Scratch of the fused last layer: per-sample tickets, per-slice stats and partial logits tiles.
+// Zero-initialised ONCE by the caller (the kernel leaves the tickets at zero again).
+extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
+  if (n_samples <= 0) return 0;
+  const size_t S = (size_t)n_samples;
+  return ((S * 4 + 255) / 256) * 256 + S * kFinalMaxSlices * 16 + S * kFinalMaxSlices * (128 * 16 * 4);
+}
+
 // Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
 // tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
 // the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
@@ -962,11 +1046,29 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   fp.ticket = f->ticket;
   const int K = a->in_features;
   const int ssteps = (K + 31) / 32;
+  // K-range slices per sample: one k-step per wave where the scratch allows it (<= 12 waves per
+  // block), so the last layer's latency chain is one step long instead of ceil(ssteps/12).
+  int KS = (ssteps + 11) / 12;
+  KS = KS > kFinalMaxSlices ? kFinalMaxSlices : KS;
+  const int forceKs = env_int("BNN_HIP_FINAL_KS", 0);
+  if (forceKs >= 1 && forceKs <= kFinalMaxSlices) KS = forceKs;
+  if (KS > 1 && (!f->scratch || f->scratch_bytes < bnn_bbb_final_scratch_bytes(a->n_samples) ||
+                 (reinterpret_cast<uintptr_t>(f->scratch) & 15)))
+    KS = 1;
+  const int spb = (ssteps + KS - 1) / KS;
   int spw = 1;
-  while ((ssteps + spw - 1) / spw > 12) ++spw;
-  int nw = (ssteps + spw - 1) / spw;
+  while ((spb + spw - 1) / spw > 12) ++spw;
+  int nw = (spb + spw - 1) / spw;
   nw = nw < 1 ? 1 : nw;
-  const long total = a->n_samples;                      // one tile, one batch block
+  fp.ks = KS;
+  {
+    char* base = reinterpret_cast<char*>(f->scratch);
+    const size_t S = (size_t)a->n_samples;
+    fp.ks_ticket = reinterpret_cast<uint32_t*>(base);
+    fp.ks_stats = reinterpret_cast<float4*>(base + ((S * 4 + 255) / 256) * 256);
+    fp.ks_tiles = reinterpret_cast<float*>(base + ((S * 4 + 255) / 256) * 256 + S * kFinalMaxSlices * 16);
+  }
+  const long total = (long)a->n_samples * KS;           // one tile, one batch block, KS slices
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
   const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
   hipError_t err = hipSuccess;

@@ -239,6 +239,10 @@ typedef struct bnn_finalize_args {
                                        job all-reduces (fixed summation order) */
   uint32_t* ticket;                 /* optional zero-initialised device word used by the fused
                                        last-layer form (bnn_bbb_final_fwd) when n_samples > 1 */
+  void* scratch;                    /* optional, bnn_bbb_final_scratch_bytes(n_samples) bytes, 16-byte
+                                       aligned, ZEROED ONCE by the caller: lets the fused last layer
+                                       split its K range over several blocks per sample */
+  size_t scratch_bytes;
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
@@ -249,6 +253,7 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
  * launch when the layer is a single feature tile (out_features <= 16, batch <= 128): the block
  * that produced a sample's logits also forms its NLL (networks.py:183-190) and log p / log q
  * (networks.py:174-178).  Falls back to the two launches otherwise. */
+size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 
 /* ------------------------------------------------------------------------------------
