@@ -64,6 +64,7 @@ class LrFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
+        ("x_sq", C.c_void_p), ("y_sq", C.c_void_p),
     ]
 
 
@@ -129,7 +130,7 @@ def load():
     lib.bnn_philox_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int
-    lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     v = lib.bnn_version()
     if v != ABI_VERSION:
         raise BnnHipError(f"libbnn_hip.so ABI version {v} != binding version {ABI_VERSION}")

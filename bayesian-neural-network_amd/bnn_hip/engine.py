@@ -65,9 +65,15 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     differentiable path and raw workspaces on the forward-only path."""
     math_mode = state.math
     hidden_dtype = torch.float32 if (differentiable or math_mode == L.MATH_F32) else torch.bfloat16
-    h = x
+    h, h_sq = x, None
+    lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= CAST_INPUT_MIN_SAMPLES and \
+        any(sp.lr for sp in layers)
     if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES:
-        h = ops.cast_bf16(x)             # once per evaluation: every layer then streams 2-byte x
+        # once per evaluation: every layer then streams 2-byte x (LR: and its elementwise square)
+        if lr_sq:
+            h, h_sq = ops.cast_bf16(x, want_sq=True)
+        else:
+            h = ops.cast_bf16(x)
     stats = []
     for i, sp in enumerate(layers):
         last = i == len(layers) - 1
@@ -91,10 +97,14 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
         else:
             pd = tuple(t.detach() for t in p)
             if sp.lr:
+                want_sq = lr_sq and not last
                 out = ops.lr_linear_fwd(h, *pd, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_act=e_w, eps_b=e_b,
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
-                                        want_kl=want_stats)
+                                        want_kl=want_stats, x_sq=h_sq if lr_sq else None,
+                                        out_sq=torch.empty((n_local, h.shape[-2], sp.in_out[1]), dtype=torch.bfloat16,
+                                                           device=h.device) if want_sq else None)
+                h_sq = out["y_sq"]
             else:
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
@@ -238,6 +248,10 @@ class GraphedElbo:
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and S >= CAST_INPUT_MIN_SAMPLES) else None)
+        self.lr_sq = self.lr and self.x16 is not None
+        self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
+        self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
+                        else None for i, b in enumerate(self.bufs)]
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -257,7 +271,13 @@ class GraphedElbo:
 
     def _enqueue(self):
         math_mode = state.math
-        h = self.x if self.x16 is None else ops.cast_bf16(self.x, out=self.x16)
+        h_sq = None
+        if self.x16 is None:
+            h = self.x
+        elif self.lr_sq:
+            h, h_sq = ops.cast_bf16(self.x, out=self.x16, out_sq=self.x16_sq)
+        else:
+            h = ops.cast_bf16(self.x, out=self.x16)
         last = len(self.specs) - 1
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
                       local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
@@ -270,7 +290,9 @@ class GraphedElbo:
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i])
             if self.lr:
-                ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, **common)
+                ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
+                                  out_sq=self.bufs_sq[i], **common)
+                h_sq = self.bufs_sq[i]
             elif i == last:
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))

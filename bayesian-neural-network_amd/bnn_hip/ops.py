@@ -151,7 +151,8 @@ def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
 def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
-                  dump_eps: bool = False, workspace=None, sample_counter=None, out=None):
+                  dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
+                  out_sq=None):
     """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
     lib = L.load()
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -188,8 +189,16 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
     a.workspace_bytes = workspace.numel() * 4 if (want_kl and workspace is not None) else 0
     a.kl_out = _ptr(kl3)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    if x_sq is not None:
+        if x_sq.dtype != torch.bfloat16 or tuple(x_sq.shape) != tuple(xs.shape) or not x_sq.is_contiguous():
+            raise BnnHipError("x_sq must be a contiguous bfloat16 tensor shaped like x")
+        a.x_sq = x_sq.data_ptr()
+    if out_sq is not None:
+        if out_sq.dtype != torch.bfloat16 or out_sq.numel() != y.numel():
+            raise BnnHipError("out_sq must be bfloat16 shaped like y")
+        a.y_sq = out_sq.data_ptr()
     L.check(lib.bnn_lr_linear_fwd(C.byref(a), _stream()), "bnn_lr_linear_fwd")
-    return dict(y=y, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db)
+    return dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db)
 
 
 def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tensor:
@@ -295,12 +304,16 @@ def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int,
     return eps
 
 
-def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fp32 -> bf16 copy of a contiguous device tensor (one tiny kernel)."""
+def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_sq: Optional[torch.Tensor] = None,
+              want_sq: bool = False):
+    """fp32 -> bf16 copy of a contiguous device tensor (one tiny kernel); with `want_sq` also
+    x*x in bf16.  Returns out, or (out, out_sq)."""
     lib = L.load()
     require_device(x)
     x = _f32c(x, "x")
     if out is None:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    L.check(lib.bnn_cast_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "bnn_cast_bf16")
-    return out
+    if want_sq and out_sq is None:
+        out_sq = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(lib.bnn_cast_bf16(x.data_ptr(), out.data_ptr(), _ptr(out_sq), x.numel(), _stream()), "bnn_cast_bf16")
+    return (out, out_sq) if (want_sq or out_sq is not None) else out

@@ -37,6 +37,8 @@ struct LrK {
   float* eps_act_dump;
   float* eps_b_dump;
   void* y;
+  const void* x_sq; // optional bf16 x*x (same shape as x)
+  void* y_sq;       // optional bf16 y*y
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
   int eps_mode, want_kl, relu, y_bf16;
@@ -322,6 +324,12 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
       if (p.relu) o = fmaxf(o, 0.f);
       v[i] = o;
     }
+    if (p.y_sq) {
+      __bf16* qp = reinterpret_cast<__bf16*>(p.y_sq) + yoff;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+    }
     if (p.y_bf16) {
       __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
       if (vec_ok) {
@@ -342,6 +350,223 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (nb + i < N) yp[i] = v[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3b  throughput form (many MC samples, bf16 math, bf16 x AND x^2 provided): block GEMM.
+//   1-D XCD-aware grid over (feature-tile group, sample, batch block), block = NW waves; wave j
+//   owns 16 features for ALL of K.  Per k-step the 128 x 32 tiles of x and x^2 are brought once
+//   per block into double-buffered LDS by LDS-DMA (global_load_lds_dwordx4: one wave-instruction
+//   = one batch tile's lane-linear 1 KiB fragment block), each wave gathers its (M, rho)
+//   fragment (prefetched a step ahead), forms sigma^2 and issues 16 MFMAs (mean and variance
+//   against the two tiles).  No per-weight sampling: ~150 VALU ops per k-step, one barrier.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void lr_fwd_gemm_kernel(const LrK p) {
+  __shared__ __attribute__((aligned(16))) float4 xt[2][2][8 * 64];   // [buffer][x | x^2][tile] = 32 KiB
+  __shared__ float bias_s[NW][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
+  int item;
+  if (!xcd_work_item(tbs * p.S * mbs, item)) return;          // block-uniform
+  const int tb = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
+  const int tile = tb * NW + wave;
+  const int n = tile * 16 + r;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 1);
+  const int m0 = mb * 128;
+  const int ksteps = (K + 31) >> 5;
+  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const bool do_kl = p.want_kl && mb == 0 && s == 0;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
+  const __bf16* xq = reinterpret_cast<const __bf16*>(p.x_sq) + (size_t)s * (size_t)p.x_sstride;
+  const int T = (N + 15) >> 4;
+  if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+
+  size_t xrow[8 / NW];
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) xrow[i] = (size_t)min(m0 + (wave + i * NW) * 16 + r, B - 1) * K;
+  auto stage_dma = [&](int t, int buf) {
+    const int kk = min(t * 32 + q * 8, K - 8);
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
+                                       (__attribute__((address_space(3))) void*)&xt[buf][0][(wave + i * NW) * 64], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + xrow[i] + kk),
+                                       (__attribute__((address_space(3))) void*)&xt[buf][1][(wave + i * NW) * 64], 16, 0, 0);
+    }
+  };
+  float mu_n[8], rho_n[8];
+  auto load_params = [&](int t) {
+    const int k = t * 32 + q * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
+      mu_n[j] = p.w_mu[off];
+      rho_n[j] = p.w_rho[off];
+    }
+  };
+  float bmu_pre = 0.f, bsig_pre = 0.f, beps_pre = 0.f;
+  if (q == 0 && n_ok) {
+    bmu_pre = p.b_mu[n];
+    bsig_pre = softplus(p.b_rho[n]);
+    if (p.eps_mode == BNN_EPS_PHILOX) {
+      float e4[4];
+      philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+      beps_pre = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+    } else if (p.eps_mode == BNN_EPS_MEMORY) {
+      beps_pre = p.eps_b[(size_t)s * N + n];
+    }
+    if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
+  }
+  load_params(0);
+  stage_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 am[8], av[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    am[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    av[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
+#pragma nounroll
+  for (int t = 0; t < ksteps; ++t) {
+    const int k = t * 32 + q * 8;
+    float mu[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = mu_n[j];
+      s2[j] = rho_n[j];
+    }
+    if (t + 1 < ksteps) {
+      stage_dma(t + 1, (t + 1) & 1);
+      load_params(t + 1);
+    }
+    float ls = 0.f, a2 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = n_ok && (k + j) < K;
+      const float sig = softplus(s2[j]);
+      if (do_kl) {
+        ls += ok ? fast_log(sig) : 0.f;
+        a2 += ok ? sig * sig : 0.f;
+        m2 += ok ? mu[j] * mu[j] : 0.f;
+      }
+      mu[j] = ok ? mu[j] : 0.f;
+      s2[j] = ok ? sig * sig : 0.f;
+    }
+    s_ls += ls;
+    s_s2 += a2;
+    s_m2 += m2;
+    bf16x8 ma, sa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ma[j] = (__bf16)mu[j];
+      sa[j] = (__bf16)s2[j];
+    }
+    const float4* xb = xt[t & 1][0];
+    const float4* qb = xt[t & 1][1];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
+      const bf16x8 qf = __builtin_bit_cast(bf16x8, qb[(m * 4 + q) * 16 + r]);
+      am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xf, am[m], 0, 0, 0);
+      av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, qf, av[m], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (q == 0) {
+    float b = 0.f;
+    if (n_ok) {
+      b = __builtin_fmaf(bsig_pre, beps_pre, bmu_pre);
+      if (do_kl) {
+        s_ls += fast_log(bsig_pre);
+        s_s2 = __builtin_fmaf(bsig_pre, bsig_pre, s_s2);
+        s_m2 = __builtin_fmaf(bmu_pre, bmu_pre, s_m2);
+      }
+    }
+    bias_s[wave][r] = b;
+  }
+  if (do_kl) {
+    const float a = wave_sum(s_ls), b = wave_sum(s_s2), cc = wave_sum(s_m2);
+    if (lane == 0 && tile < T) p.ws[1 + tile] = make_float4(a, b, cc, 0.f);
+  }
+  __syncthreads();
+  const int nb = tile * 16 + q * 4;
+  const bool vec_ok = (N & 3) == 0;
+  const int gprN = (N + 3) >> 2;
+  if (nb < N) {
+    float bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int brow = m0 + m * 16 + r;
+      if (brow < B) {
+        const size_t yoff = ((size_t)s * B + brow) * N + nb;
+        float e4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.eps_mode == BNN_EPS_PHILOX) {
+          philox_normal4((uint32_t)brow * (uint32_t)gprN + (uint32_t)(nb >> 2), gs, p.layer_id * 4u + 2u, p.k0, p.k1, e4);
+        } else if (p.eps_mode == BNN_EPS_MEMORY) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < N) e4[i] = p.eps_act[yoff + i];
+        }
+        if (p.eps_act_dump) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < N) p.eps_act_dump[yoff + i] = e4[i];
+        }
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(av[m][i]), e4[i], am[m][i]) + bq[i];
+          if (p.relu) o = fmaxf(o, 0.f);
+          v[i] = o;
+        }
+        if (p.y_sq) {
+          __bf16* qp = reinterpret_cast<__bf16*>(p.y_sq) + yoff;
+          if (vec_ok) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] * v[i]);
+            *reinterpret_cast<bf16x4*>(qp) = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+          }
+        }
+        if (p.y_bf16) {
+          __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
+          if (vec_ok) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            *reinterpret_cast<bf16x4*>(yp) = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = (__bf16)v[i];
+          }
+        } else {
+          float* yp = reinterpret_cast<float*>(p.y) + yoff;
+          if (vec_ok) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = v[i];
+          }
+        }
       }
     }
   }
@@ -426,6 +651,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
+  k.x_sq = a->x_sq; k.y_sq = a->y_sq;
   k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.want_kl = a->want_kl ? 1 : 0; k.relu = a->relu ? 1 : 0; k.y_bf16 = ybf;
@@ -434,6 +660,26 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
 
   // launch geometry: a function of the shape only
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
+  hipError_t err = hipSuccess;
+  {
+    const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
+    const int force = lr_env_int("BNN_HIP_LR_GEMM", -1);
+    const bool can = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+                     !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
+    if (can && (force == 1 || (force != 0 && gemm_blocks >= 300))) {
+      const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
+      hipLaunchKernelGGL((lr_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+      err = hipGetLastError();
+      if (err != hipSuccess) return (int)err;
+      if (a->kl_out) {
+        hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.ws, K, N, a->sigma_p, a->b_mu, a->b_rho,
+                           a->kl_out);
+        err = hipGetLastError();
+        if (err != hipSuccess) return (int)err;
+      }
+      return BNN_OK;
+    }
+  }
   int R = 1;
   while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
   const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
@@ -447,7 +693,6 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   const long total = (long)((N + F - 1) / F) * a->n_samples * mbs;
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
   const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);
-  hipError_t err = hipSuccess;
 #define BNN_LR(MATH, XDT, RR)                                                                       \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \

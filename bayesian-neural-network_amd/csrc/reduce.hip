@@ -152,20 +152,32 @@ __global__ void sample_sums_kernel(const float* __restrict__ a, const float* __r
 
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
 // the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).
-__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n, int vec_ok) {
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, __bf16* __restrict__ dsq,
+                                 long n, int vec_ok) {
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
   if (vec_ok) {
     const long n8 = n >> 3;
     for (long i = tid; i < n8; i += nt) {
       const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-      bf16x8 v;
-      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      bf16x8 v, q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (__bf16)f[j];
+        q[j] = (__bf16)(f[j] * f[j]);
+      }
       reinterpret_cast<bf16x8*>(dst)[i] = v;
+      if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
     }
-    for (long i = (n8 << 3) + tid; i < n; i += nt) dst[i] = (__bf16)src[i];
+    for (long i = (n8 << 3) + tid; i < n; i += nt) {
+      dst[i] = (__bf16)src[i];
+      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+    }
   } else {
-    for (long i = tid; i < n; i += nt) dst[i] = (__bf16)src[i];
+    for (long i = tid; i < n; i += nt) {
+      dst[i] = (__bf16)src[i];
+      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+    }
   }
 }
 
@@ -250,15 +262,16 @@ extern "C" int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, 
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 
-extern "C" int bnn_cast_bf16(const float* src, void* dst, int64_t n, void* stream_) {
+extern "C" int bnn_cast_bf16(const float* src, void* dst, void* dst_sq, int64_t n, void* stream_) {
   if (!src || !dst) return BNN_ERR_NULL;
   if (n <= 0) return BNN_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(src) & 3) || (reinterpret_cast<uintptr_t>(dst) & 1)) return BNN_ERR_ALIGN;
-  const int vec_ok = !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15);
+  const int vec_ok = !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                        reinterpret_cast<uintptr_t>(dst_sq)) & 15);
   long nb = (n / 8 + 255) / 256;
   nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), src,
-                     reinterpret_cast<__bf16*>(dst), (long)n, vec_ok);
+                     reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dst_sq), (long)n, vec_ok);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -183,6 +183,10 @@ typedef struct bnn_lr_fwd_args {
   void* y;
   int32_t y_dtype;
   int32_t reserved2;
+  const void* x_sq;         /* optional bf16 [x_samples,batch,in]: x*x elementwise (what a previous
+                               layer's y_sq or bnn_cast_bf16 produced); lets the throughput kernel
+                               stream both GEMM operands of networks.py:120-121 by LDS-DMA */
+  void* y_sq;               /* optional bf16 [n_samples,batch,out]: also write y*y (after ReLU) */
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
@@ -269,7 +273,7 @@ int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sa
  * batch is cast once per ELBO evaluation when bf16 math runs many MC samples, so every
  * layer streams 2-byte activations.  (The reference keeps x in fp32, main.py / class_task.py:71.)
  * ---------------------------------------------------------------------------------- */
-int bnn_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+int bnn_cast_bf16(const float* src, void* dst_bf16, void* dst_sq_bf16 /* optional: x*x */, int64_t n, void* stream);
 
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
 const char* bnn_status_string(int status); /* static string for a negative status */

@@ -424,3 +424,25 @@ def test_fused_final_layer_equals_two_launches(dev, monkeypatch):
             assert not torch.equal(a1, a2)                   # second replay drew different eps
             close(a1[:3], torch.stack([p1["log_prior"].sum(), p1["log_q"].sum(), p1["nll"].sum()]).cpu().numpy(),
                   rtol=1e-6)
+
+
+@pytest.mark.parametrize("force_gemm", ["0", "1"])
+def test_lr_throughput_path_against_oracle(dev, monkeypatch, force_gemm):
+    """LR network, 8 MC samples in one evaluation, bf16 math with the bf16 x / x^2 activation pair:
+    the K-split kernel (0) and the LDS-DMA block-GEMM kernel (1) against the oracle on injected eps."""
+    monkeypatch.setenv("BNN_HIP_LR_GEMM", force_gemm)
+    bnn_hip.set_math("bf16")
+    S, B = 8, 128
+    net, sd = build_net(dev, True, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", B, 784, 10)
+    p = O.NetParams.from_state_dict(sd, "classification", 784, True, O.Prior.from_init([1.0], False))
+    eps = [[t(a) for a in synth.synth_eps(p.eps_shapes(B), s)] for s in range(S)]
+    torch.set_num_threads(8)
+    ref = O.sample_elbo_lr(p, t(x), t(y), 0.5, S, eps=eps)
+    torch.set_num_threads(1)
+    install_eps(net, B, S, True)
+    with torch.no_grad():
+        got = net.sample_elbo_lr(t(x).to(dev), t(y).to(dev), 0.5, S)
+    close(got[1], ref[1].numpy())                       # KL: fp32 statistics
+    close(got[2], ref[2].numpy(), rtol=3e-3)            # NLL follows bf16 logits
+    close(got[0], ref[0].numpy(), rtol=1e-4)            # ELBO
