@@ -19,7 +19,7 @@ NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
 EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16",
 )
@@ -64,7 +64,7 @@ class LrFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
-        ("x_sq", C.c_void_p), ("y_sq", C.c_void_p),
+        ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p),
     ]
 
 
@@ -115,6 +115,11 @@ def load():
     lib.bnn_lr_linear_fwd_workspace_bytes.argtypes = [C.c_int32]
     lib.bnn_lr_linear_fwd.restype = C.c_int
     lib.bnn_lr_linear_fwd.argtypes = [C.POINTER(LrFwdArgs), C.c_void_p]
+    lib.bnn_lr_prepare_bytes.restype = C.c_size_t
+    lib.bnn_lr_prepare_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.bnn_lr_prepare.restype = C.c_int
+    lib.bnn_lr_prepare.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                     C.c_void_p]
     lib.bnn_gauss_kl_workspace_bytes.restype = C.c_size_t
     lib.bnn_gauss_kl_workspace_bytes.argtypes = [C.c_int64]
     lib.bnn_gauss_kl.restype = C.c_int

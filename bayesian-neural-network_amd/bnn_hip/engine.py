@@ -17,6 +17,13 @@ from .runtime import state, take_samples
 
 
 CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it saves
+LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
+
+
+def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
+    """True when the LR throughput kernel (block GEMM) will run for this layer and enough samples share the
+    prepared weights to pay for the extra pass (mirrors the launcher's geometry rule)."""
+    return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 300
 
 
 def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
@@ -98,7 +105,10 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
             pd = tuple(t.detach() for t in p)
             if sp.lr:
                 want_sq = lr_sq and not last
-                out = ops.lr_linear_fwd(h, *pd, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
+                wfrag, ws_pre = (None, None)
+                if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]):
+                    wfrag, ws_pre = ops.lr_prepare(*pd)
+                out = ops.lr_linear_fwd(h, *pd, w_frag=wfrag, workspace=ws_pre, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_act=e_w, eps_b=e_b,
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
                                         want_kl=want_stats, x_sq=h_sq if lr_sq else None,
@@ -252,6 +262,10 @@ class GraphedElbo:
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]
+        self.wfrag = [None] * len(self.specs)
+        if self.lr_sq:
+            self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
+                          if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -290,8 +304,10 @@ class GraphedElbo:
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i])
             if self.lr:
+                if self.wfrag[i] is not None:
+                    ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
-                                  out_sq=self.bufs_sq[i], **common)
+                                  out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]
             elif i == last:
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),

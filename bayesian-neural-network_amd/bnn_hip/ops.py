@@ -152,7 +152,7 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None):
+                  out_sq=None, w_frag=None):
     """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
     lib = L.load()
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -193,6 +193,8 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
         if x_sq.dtype != torch.bfloat16 or tuple(x_sq.shape) != tuple(xs.shape) or not x_sq.is_contiguous():
             raise BnnHipError("x_sq must be a contiguous bfloat16 tensor shaped like x")
         a.x_sq = x_sq.data_ptr()
+    if w_frag is not None:
+        a.w_frag = w_frag.data_ptr()
     if out_sq is not None:
         if out_sq.dtype != torch.bfloat16 or out_sq.numel() != y.numel():
             raise BnnHipError("out_sq must be bfloat16 shaped like y")
@@ -317,3 +319,22 @@ def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_sq: Optio
         out_sq = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     L.check(lib.bnn_cast_bf16(x.data_ptr(), out.data_ptr(), _ptr(out_sq), x.numel(), _stream()), "bnn_cast_bf16")
     return (out, out_sq) if (want_sq or out_sq is not None) else out
+
+
+def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None):
+    """bnn_lr_prepare: bf16 (M, sigma^2) in MFMA fragment order + the KL sums into `workspace`.
+    Returns (w_frag, workspace)."""
+    lib = L.load()
+    require_device(w_mu, w_rho, b_mu, b_rho)
+    w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
+    b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
+    K, N = w_mu.shape
+    nbytes = lib.bnn_lr_prepare_bytes(K, N)
+    if out is None:
+        out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_mu.device)
+    if workspace is None:
+        workspace = lr_workspace(N, w_mu.device)
+    L.check(lib.bnn_lr_prepare(w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr(), K, N,
+                               out.data_ptr(), out.numel() * 4, workspace.data_ptr(), workspace.numel() * 4, _stream()),
+            "bnn_lr_prepare")
+    return out, workspace

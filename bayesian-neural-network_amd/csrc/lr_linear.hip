@@ -38,6 +38,7 @@ struct LrK {
   float* eps_b_dump;
   void* y;
   const void* x_sq; // optional bf16 x*x (same shape as x)
+  const float4* w_frag;  // optional prepared weights (lr_prepare_kernel): [T][ksteps][2][64] x 16 B
   void* y_sq;       // optional bf16 y*y
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
@@ -363,8 +364,74 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
 //   = one batch tile's lane-linear 1 KiB fragment block), each wave gathers its (M, rho)
 //   fragment (prefetched a step ahead), forms sigma^2 and issues 16 MFMAs (mean and variance
 //   against the two tiles).  No per-weight sampling: ~150 VALU ops per k-step, one barrier.
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 3) void lr_fwd_gemm_kernel(const LrK p) {
+// Prepared weights for K3b: the eps-independent half of the LR layer, done ONCE per evaluation
+// instead of once per MC sample.  Block = one 16-feature tile, its waves split the k-steps;
+// lane (r,q) gathers its A fragment of (M, rho), forms sigma^2, and writes both as bf16 in
+// FRAGMENT ORDER ([tile][k-step][mean | variance][lane] x 16 B), so the GEMM kernel's operand
+// fetch is one coalesced 16-byte load per fragment.  The closed-form KL sums of the tile
+// (networks.py:113) are reduced here, deterministically, into the layer's KL workspace.
+__global__ __launch_bounds__(512) void lr_prepare_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+                                                         const float* __restrict__ b_mu, const float* __restrict__ b_rho,
+                                                         int K, int N, float4* __restrict__ frag, float4* __restrict__ ws) {
+  __shared__ float red[8 * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, T = gridDim.x;
+  const int n = tile * 16 + r;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 1);
+  const int ksteps = (K + 31) >> 5;
+  float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
+  for (int t = wave; t < ksteps; t += nw) {
+    const int k = t * 32 + q * 8;
+    bf16x8 ma, sa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = n_ok && (k + j) < K;
+      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
+      const float mu = w_mu[off];
+      const float sig = softplus(w_rho[off]);
+      if (ws) {
+        s_ls += ok ? fast_log(sig) : 0.f;
+        s_s2 += ok ? sig * sig : 0.f;
+        s_m2 += ok ? mu * mu : 0.f;
+      }
+      ma[j] = ok ? (__bf16)mu : (__bf16)0.f;
+      sa[j] = ok ? (__bf16)(sig * sig) : (__bf16)0.f;
+    }
+    float4* dst = frag + ((size_t)tile * ksteps + t) * 128;
+    dst[lane] = __builtin_bit_cast(float4, ma);
+    dst[64 + lane] = __builtin_bit_cast(float4, sa);
+  }
+  if (ws) {
+    if (wave == 0 && q == 0 && n_ok) {                 // the tile's biases
+      const float sig = softplus(b_rho[n]), mu = b_mu[n];
+      s_ls += fast_log(sig);
+      s_s2 = __builtin_fmaf(sig, sig, s_s2);
+      s_m2 = __builtin_fmaf(mu, mu, s_m2);
+    }
+    const float a = wave_sum(s_ls), b = wave_sum(s_s2), c = wave_sum(s_m2);
+    if (lane == 0) {
+      red[wave * 3 + 0] = a;
+      red[wave * 3 + 1] = b;
+      red[wave * 3 + 2] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float x = 0.f, y = 0.f, z = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        x += red[w * 3 + 0];
+        y += red[w * 3 + 1];
+        z += red[w * 3 + 2];
+      }
+      ws[1 + tile] = make_float4(x, y, z, 0.f);
+      if (tile == 0) ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+template <int NW, bool PREP>
+__global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(const LrK p) {
   __shared__ __attribute__((aligned(16))) float4 xt[2][2][8 * 64];   // [buffer][x | x^2][tile] = 32 KiB
   __shared__ float bias_s[NW][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,7 +448,7 @@ __global__ __launch_bounds__(NW * 64, 3) void lr_fwd_gemm_kernel(const LrK p) {
   const int m0 = mb * 128;
   const int ksteps = (K + 31) >> 5;
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
-  const bool do_kl = p.want_kl && mb == 0 && s == 0;
+  const bool do_kl = !PREP && p.want_kl && mb == 0 && s == 0;   // PREP: the prepare pass owns the KL sums
   const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
   const __bf16* xq = reinterpret_cast<const __bf16*>(p.x_sq) + (size_t)s * (size_t)p.x_sstride;
   const int T = (N + 15) >> 4;
@@ -401,13 +468,21 @@ __global__ __launch_bounds__(NW * 64, 3) void lr_fwd_gemm_kernel(const LrK p) {
     }
   };
   float mu_n[8], rho_n[8];
+  float4 ma_n, sa_n;                                   // PREP: prepared bf16 fragments
+  const int tclamp = min(tile, T - 1);
   auto load_params = [&](int t) {
-    const int k = t * 32 + q * 8;
+    if (PREP) {
+      const float4* src = p.w_frag + ((size_t)tclamp * ksteps + t) * 128;
+      ma_n = src[lane];
+      sa_n = src[64 + lane];
+    } else {
+      const int k = t * 32 + q * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
-      mu_n[j] = p.w_mu[off];
-      rho_n[j] = p.w_rho[off];
+      for (int j = 0; j < 8; ++j) {
+        const size_t off = (size_t)min(k + j, K - 1) * N + nc;
+        mu_n[j] = p.w_mu[off];
+        rho_n[j] = p.w_rho[off];
+      }
     }
   };
   float bmu_pre = 0.f, bsig_pre = 0.f, beps_pre = 0.f;
@@ -438,37 +513,48 @@ __global__ __launch_bounds__(NW * 64, 3) void lr_fwd_gemm_kernel(const LrK p) {
 #pragma nounroll
   for (int t = 0; t < ksteps; ++t) {
     const int k = t * 32 + q * 8;
+    bf16x8 ma, sa;
     float mu[8], s2[8];
+    if (PREP) {
+      ma = __builtin_bit_cast(bf16x8, ma_n);
+      sa = __builtin_bit_cast(bf16x8, sa_n);
+      if (tile >= T) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      mu[j] = mu_n[j];
-      s2[j] = rho_n[j];
+        for (int j = 0; j < 8; ++j) ma[j] = sa[j] = (__bf16)0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mu[j] = mu_n[j];
+        s2[j] = rho_n[j];
+      }
     }
     if (t + 1 < ksteps) {
       stage_dma(t + 1, (t + 1) & 1);
       load_params(t + 1);
     }
-    float ls = 0.f, a2 = 0.f, m2 = 0.f;
+    if (!PREP) {
+      float ls = 0.f, a2 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = n_ok && (k + j) < K;
-      const float sig = softplus(s2[j]);
-      if (do_kl) {
-        ls += ok ? fast_log(sig) : 0.f;
-        a2 += ok ? sig * sig : 0.f;
-        m2 += ok ? mu[j] * mu[j] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = n_ok && (k + j) < K;
+        const float sig = softplus(s2[j]);
+        if (do_kl) {
+          ls += ok ? fast_log(sig) : 0.f;
+          a2 += ok ? sig * sig : 0.f;
+          m2 += ok ? mu[j] * mu[j] : 0.f;
+        }
+        mu[j] = ok ? mu[j] : 0.f;
+        s2[j] = ok ? sig * sig : 0.f;
       }
-      mu[j] = ok ? mu[j] : 0.f;
-      s2[j] = ok ? sig * sig : 0.f;
-    }
-    s_ls += ls;
-    s_s2 += a2;
-    s_m2 += m2;
-    bf16x8 ma, sa;
+      s_ls += ls;
+      s_s2 += a2;
+      s_m2 += m2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ma[j] = (__bf16)mu[j];
-      sa[j] = (__bf16)s2[j];
+      for (int j = 0; j < 8; ++j) {
+        ma[j] = (__bf16)mu[j];
+        sa[j] = (__bf16)s2[j];
+      }
     }
     const float4* xb = xt[t & 1][0];
     const float4* qb = xt[t & 1][1];
@@ -624,6 +710,30 @@ static int lr_env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+extern "C" size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features) {
+  if (in_features <= 0 || out_features <= 0) return 0;
+  return (size_t)((out_features + 15) / 16) * (size_t)((in_features + 31) / 32) * 128 * 16;
+}
+
+extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                              int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                              void* kl_workspace, size_t kl_workspace_bytes, void* stream_) {
+  if (!w_mu || !w_rho || !b_mu || !b_rho || !w_frag) return BNN_ERR_NULL;
+  if (in_features <= 0 || out_features <= 0) return BNN_ERR_SHAPE;
+  if (w_frag_bytes < bnn_lr_prepare_bytes(in_features, out_features)) return BNN_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(w_frag) & 15) return BNN_ERR_ALIGN;
+  if (kl_workspace) {
+    if (kl_workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(out_features)) return BNN_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(kl_workspace) & 15) return BNN_ERR_ALIGN;
+  }
+  const int T = (out_features + 15) / 16;
+  hipLaunchKernelGGL(lr_prepare_kernel, dim3(T), dim3(512), 0, reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu,
+                     b_rho, in_features, out_features, reinterpret_cast<float4*>(w_frag),
+                     reinterpret_cast<float4*>(kl_workspace));
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
 extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_lr_fwd_args)) return BNN_ERR_ABI;
@@ -652,6 +762,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
   k.x_sq = a->x_sq; k.y_sq = a->y_sq;
+  k.w_frag = reinterpret_cast<const float4*>(a->w_frag);
   k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.want_kl = a->want_kl ? 1 : 0; k.relu = a->relu ? 1 : 0; k.y_bf16 = ybf;
@@ -668,7 +779,12 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
                      !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
     if (can && (force == 1 || (force != 0 && gemm_blocks >= 300))) {
       const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
-      hipLaunchKernelGGL((lr_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+      if (a->w_frag) {
+        if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
+        hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+      } else {
+        hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
+      }
       err = hipGetLastError();
       if (err != hipSuccess) return (int)err;
       if (a->kl_out) {

@@ -187,10 +187,22 @@ typedef struct bnn_lr_fwd_args {
                                layer's y_sq or bnn_cast_bf16 produced); lets the throughput kernel
                                stream both GEMM operands of networks.py:120-121 by LDS-DMA */
   void* y_sq;               /* optional bf16 [n_samples,batch,out]: also write y*y (after ReLU) */
+  const void* w_frag;       /* optional output of bnn_lr_prepare for these weights: the throughput
+                               kernel then streams ready bf16 (M, sigma^2) fragments and the KL
+                               workspace is the one bnn_lr_prepare filled (want_kl still set) */
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
 int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
+
+/* bnn_lr_prepare — the eps-independent half of BayesianLinearLR.forward, once per ELBO
+ * evaluation instead of once per MC sample (the reference recomputes it inside its sample loop,
+ * networks.py:118-119, :134-136): sigma^2 = softplus(rho)^2, both GEMM operands rounded to bf16
+ * and stored in MFMA fragment order, plus the closed-form KL sums into kl_workspace (optional). */
+size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features);
+int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                   int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                   void* kl_workspace, size_t kl_workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K2  bnn_gauss_kl — one streaming pass over (mu, rho)[n]: the eps-independent sums of

@@ -426,13 +426,14 @@ def test_fused_final_layer_equals_two_launches(dev, monkeypatch):
                   rtol=1e-6)
 
 
-@pytest.mark.parametrize("force_gemm", ["0", "1"])
-def test_lr_throughput_path_against_oracle(dev, monkeypatch, force_gemm):
-    """LR network, 8 MC samples in one evaluation, bf16 math with the bf16 x / x^2 activation pair:
-    the K-split kernel (0) and the LDS-DMA block-GEMM kernel (1) against the oracle on injected eps."""
+@pytest.mark.parametrize("force_gemm,S", [("0", 8), ("1", 8), ("1", 24)])
+def test_lr_throughput_path_against_oracle(dev, monkeypatch, force_gemm, S):
+    """LR network, S MC samples in one evaluation, bf16 math with the bf16 x / x^2 activation pair:
+    the K-split kernel ("0"), the LDS-DMA block-GEMM kernel ("1") and, at S=24, the prepared-
+    fragment form of it (bnn_lr_prepare), against the oracle on injected eps."""
     monkeypatch.setenv("BNN_HIP_LR_GEMM", force_gemm)
     bnn_hip.set_math("bf16")
-    S, B = 8, 128
+    B = 128
     net, sd = build_net(dev, True, (784, 1200, 10), "classification")
     x, y = synth.synth_batch("classification", B, 784, 10)
     p = O.NetParams.from_state_dict(sd, "classification", 784, True, O.Prior.from_init([1.0], False))
