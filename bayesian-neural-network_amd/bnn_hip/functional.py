@@ -8,6 +8,7 @@ the formulas here are the ones they will implement and are pinned by golden G5 g
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -31,6 +32,11 @@ class LayerCall:
     sample_offset: int
     want_stats: bool
     y_dtype: torch.dtype = torch.float32
+
+
+# F1 switch: True = HIP backward kernels (bnn_bbb_linear_bwd); False = the closed-form gradients
+# evaluated with device tensor ops (kept as the cross-check the GPU tests compare against).
+HIP_BACKWARD = os.environ.get("BNN_HIP_BACKWARD", "1") != "0"
 
 
 def _naive_softplus(rho):
@@ -64,6 +70,17 @@ class BBBLinearFn(torch.autograd.Function):
         S = call.n_samples
         N, K = w_mu.shape
         dev = w_mu.device
+        if HIP_BACKWARD and x.dtype == torch.float32 and (y is None or y.dtype == torch.float32):
+            # F1: hand-written backward kernels, eps regenerated on chip
+            g_wmu, g_wrho, g_bmu, g_brho, gx = ops.bbb_linear_bwd(
+                x, gy.float(), y, w_mu, w_rho, b_mu, b_rho, n_samples=S, prior=call.prior, math_mode=call.math_mode,
+                relu=call.relu, eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
+                layer_id=call.layer_id, sample_offset=call.sample_offset,
+                g_log_prior=glp if call.want_stats else None, g_log_q=glq if call.want_stats else None,
+                want_gx=ctx.needs_input_grad[0])
+            if gx is not None and x.dim() == 2:
+                gx = gx.sum(0)
+            return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
         if call.eps_mode == L.EPS_PHILOX:
             eps_w = ops.philox_normal(call.seed, call.layer_id * 4 + 0, call.sample_offset, S, N, K, dev)
             eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)

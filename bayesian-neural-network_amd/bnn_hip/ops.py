@@ -338,3 +338,47 @@ def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None):
                                out.data_ptr(), out.numel() * 4, workspace.data_ptr(), workspace.numel() * 4, _stream()),
             "bnn_lr_prepare")
     return out, workspace
+
+
+def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
+                   eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
+                   g_log_prior=None, g_log_q=None, want_gx: bool = True):
+    """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
+    (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
+    lib = L.load()
+    require_device(x, gy, y, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, g_log_prior, g_log_q)
+    w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
+    b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
+    N, K = w_mu.shape
+    xs, B, Kx, per_sample = _x3(_f32c(x, "x"), n_samples)
+    gy = _f32c(gy, "gy")
+    if Kx != K or gy.numel() != n_samples * B * N:
+        raise BnnHipError("bbb_linear_bwd: shape mismatch")
+    dev = xs.device
+    a = L.BbbBwdArgs()
+    a.struct_bytes = C.sizeof(L.BbbBwdArgs)
+    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+    a.x, a.x_per_sample, a.relu = xs.data_ptr(), per_sample, int(relu)
+    a.gy = gy.data_ptr()
+    if relu:
+        y = _f32c(y, "y")
+        a.y = y.data_ptr()
+    a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+    a.eps_mode, a.math = eps_mode, math_mode
+    if eps_mode == L.EPS_MEMORY:
+        eps_w, eps_b = _f32c(eps_w, "eps_w"), _f32c(eps_b, "eps_b")
+        a.eps_w, a.eps_b = eps_w.data_ptr(), eps_b.data_ptr()
+    a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
+    a.prior = prior.c()
+    glp = _f32c(g_log_prior, "g_log_prior") if g_log_prior is not None else None
+    glq = _f32c(g_log_q, "g_log_q") if g_log_q is not None else None
+    a.g_log_prior, a.g_log_q = _ptr(glp), _ptr(glq)
+    g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
+    g_bmu, g_brho = torch.empty_like(b_mu), torch.empty_like(b_rho)
+    gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
+    a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
+    a.g_x = _ptr(gx)
+    ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(lib.bnn_bbb_linear_bwd(C.byref(a), _stream()), "bnn_bbb_linear_bwd")
+    return g_wmu, g_wrho, g_bmu, g_brho, gx

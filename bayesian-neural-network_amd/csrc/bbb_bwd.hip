@@ -1,0 +1,254 @@
+// F1  backward of BayesianLinear (what autograd does for reference networks.py:73-88 when
+// classification/class_task.py:78 calls loss.backward()), SURVEY Appendix A.5.
+//
+// For MC samples s = 0..S-1 with upstream gradients gy_s (w.r.t. the layer output), glp_s
+// (w.r.t. the layer's log p) and glq_s (w.r.t. its log q):
+//     gz_s   = gy_s * (y_s > 0)                       (the ReLU fused into the forward)
+//     gW_s   = gz_s^T . x_s                           [out, in]
+//     t_s    = gW_s + glp_s * dlogp/dw (w_s),   w_s = mu + sigma * eps_s  (eps REGENERATED)
+//     g_mu   = sum_s t_s
+//     g_rho  = ( sum_s t_s * eps_s  -  (sum_s glq_s) / sigma ) * sigmoid(rho)
+// and likewise for the bias with gb_s = column sums of gz_s.  The input gradient
+// gx_s = gz_s . w_s is produced by the forward K-split kernel with a transposed
+// weight-fragment generator (bbb_linear.hip, TRANS).
+//
+// `bbb_bwd_weights_kernel`: grid (ceil(K/64), ceil(N/64)), 4 waves.  Wave j owns feature tile
+// n0 = 64*by + 16*j and the 4 k-tiles of the block's 64-wide k strip and walks the samples.
+// gW^T tiles come from the exact-fp32 matrix core (v_mfma_f32_16x16x4_f32): with the reduction
+// over the batch, A[i = k][kk = b] = x[b][k0 + i] and B[kk = b][j = n] = gz[b][n0 + j] are both
+// read along their contiguous dimension.  D[row = k][col = n] leaves a lane with 4 consecutive k
+// of one feature — exactly one Philox group — so eps is regenerated in the epilogue and neither
+// eps nor w ever exists in memory.  (G, H) = (sum t, sum t*eps) stay in registers across the
+// sample loop; one pass writes g_mu and g_rho.  No atomics.
+#include "bnn_device.h"
+#include "../../include/bnn_hip.h"
+
+namespace bnn {
+
+struct BwdK {
+  const float* x;       // [Sx, B, K] fp32
+  long x_sstride;
+  const float* gz;      // [S, B, N] fp32, ReLU mask applied
+  const float* w_mu;
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  const float* eps_w;   // BNN_EPS_MEMORY
+  const float* eps_b;
+  const float* glp;     // [S] or nullptr (zeros)
+  const float* glq;     // [S] or nullptr
+  float* g_wmu;
+  float* g_wrho;
+  float* g_bmu;
+  float* g_brho;
+  int S, B, K, N;
+  int eps_mode, prior_kind;
+  uint32_t k0, k1, layer_id, sample_offset;
+  float inv_var_p;                                   // Gaussian prior: 1 / sigma_p^2
+  float a1, a2, inv2var1, inv2var2, invvar1, invvar2; // mixture: a_i = pi_i / sigma_i
+};
+
+// d log p(w) / dw
+__device__ __forceinline__ float dlogp(const BwdK& p, float w) {
+  if (p.prior_kind == BNN_PRIOR_GAUSS) return -w * p.inv_var_p;
+  const float w2 = w * w;
+  const float n1 = p.a1 * fast_exp(-w2 * p.inv2var1);
+  const float n2 = p.a2 * fast_exp(-w2 * p.inv2var2);
+  return -w * (n1 * p.invvar1 + n2 * p.invvar2) * __builtin_amdgcn_rcpf(n1 + n2);
+}
+
+__device__ __forceinline__ float sigmoidf(float r) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-r)); }
+
+__global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int k0 = blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64 + wave * 16;
+  if (n0 >= N) return;                                   // wave-uniform; no barriers below
+  const int n = n0 + r;                                   // this lane's feature (D column / B-operand column)
+  const bool n_ok = n < N;
+  const int gpr = (K + 3) >> 2;
+
+  // resident parameters of the lane's 4 x 4 weights: rows k = k0 + 16 kt + 4 q + i of column n
+  float mu[4][4], sg[4][4], rh[4][4];
+  f32x4 G[4], H[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    G[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    H[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kt * 16 + q * 4 + i;
+      const bool ok = n_ok && k < K;
+      const size_t off = (size_t)min(n, N - 1) * K + min(k, K - 1);
+      mu[kt][i] = ok ? p.w_mu[off] : 0.f;
+      rh[kt][i] = ok ? p.w_rho[off] : 0.f;
+      sg[kt][i] = softplus(rh[kt][i]);
+    }
+  }
+  const bool do_bias = blockIdx.x == 0 && q == 0 && n_ok;   // one lane per feature
+  float bmu = 0.f, brh = 0.f, bsg = 1.f, Gb = 0.f, Hb = 0.f;
+  if (do_bias) {
+    bmu = p.b_mu[n];
+    brh = p.b_rho[n];
+    bsg = softplus(brh);
+  }
+  float cq = 0.f;
+
+  for (int s = 0; s < p.S; ++s) {
+    const float glp = p.glp ? p.glp[s] : 0.f;
+    cq += p.glq ? p.glq[s] : 0.f;
+    const uint32_t gs = p.sample_offset + (uint32_t)s;
+    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+    const float* gzs = p.gz + (size_t)s * B * N;
+    f32x4 acc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;
+#pragma unroll 4
+    for (int b0 = 0; b0 < B; b0 += 4) {
+      const int brow = b0 + q;
+      const bool b_ok = brow < B;
+      const float bv = (b_ok && n_ok) ? gzs[(size_t)brow * N + n] : 0.f;
+      colsum += bv;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int k = k0 + kt * 16 + r;
+        const float av = (b_ok && k < K) ? xs[(size_t)brow * K + k] : 0.f;
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kt], 0, 0, 0);
+      }
+    }
+    // ---- epilogue of sample s: regenerate eps of the lane's weights, fold into (G, H)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int kb = k0 + kt * 16 + q * 4;
+      if (n_ok && kb < K) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.eps_mode == BNN_EPS_PHILOX) {
+          philox_normal4((uint32_t)n * (uint32_t)gpr + (uint32_t)(kb >> 2), gs, p.layer_id * 4u, p.k0, p.k1, e);
+        } else if (p.eps_mode == BNN_EPS_MEMORY) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (kb + i < K) e[i] = p.eps_w[((size_t)s * N + n) * K + kb + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float w = __builtin_fmaf(sg[kt][i], e[i], mu[kt][i]);
+          const float t = acc[kt][i] + glp * dlogp(p, w);
+          G[kt][i] += t;
+          H[kt][i] = __builtin_fmaf(t, e[i], H[kt][i]);
+        }
+      }
+    }
+    // ---- bias: gb_s[n] = sum_b gz_s[b][n]; the 4 lane quads hold b = q (mod 4)
+    colsum += __shfl_xor(colsum, 16, kWave);
+    colsum += __shfl_xor(colsum, 32, kWave);
+    if (do_bias) {
+      float e = 0.f;
+      if (p.eps_mode == BNN_EPS_PHILOX) {
+        float e4[4];
+        philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+        e = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+      } else if (p.eps_mode == BNN_EPS_MEMORY) {
+        e = p.eps_b[(size_t)s * N + n];
+      }
+      const float bw = __builtin_fmaf(bsg, e, bmu);
+      const float t = colsum + glp * dlogp(p, bw);
+      Gb += t;
+      Hb = __builtin_fmaf(t, e, Hb);
+    }
+  }
+
+  // ---- g_mu = G;  g_rho = (H - cq / sigma) * sigmoid(rho)
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kt * 16 + q * 4 + i;
+      if (n_ok && k < K) {
+        const size_t off = (size_t)n * K + k;
+        p.g_wmu[off] = G[kt][i];
+        p.g_wrho[off] = (H[kt][i] - cq * __builtin_amdgcn_rcpf(sg[kt][i])) * sigmoidf(rh[kt][i]);
+      }
+    }
+  }
+  if (do_bias) {
+    p.g_bmu[n] = Gb;
+    p.g_brho[n] = (Hb - cq * __builtin_amdgcn_rcpf(bsg)) * sigmoidf(brh);
+  }
+}
+
+// gz = gy * (y > 0)  (or a plain copy when there was no ReLU)
+__global__ void relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gz,
+                                long n, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gz[i] = (!relu || y[i] > 0.f) ? gy[i] : 0.f;
+}
+
+}  // namespace bnn
+
+using namespace bnn;
+
+// defined in bbb_linear.hip: gx[S,B,K] = gz[S,B,N] . w_s  (w regenerated, transposed fragments)
+extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, void* stream);
+
+extern "C" size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features) {
+  if (n_samples <= 0 || batch <= 0 || out_features <= 0) return 0;
+  return (size_t)n_samples * batch * out_features * sizeof(float);
+}
+
+extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
+  if (!a) return BNN_ERR_NULL;
+  if (a->struct_bytes != sizeof(bnn_bbb_bwd_args)) return BNN_ERR_ABI;
+  if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
+  if (!a->x || !a->gy || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->g_w_mu || !a->g_w_rho || !a->g_b_mu ||
+      !a->g_b_rho)
+    return BNN_ERR_NULL;
+  if ((unsigned)a->eps_mode > 2u || (unsigned)a->prior.kind > 1u || (unsigned)a->math > 1u) return BNN_ERR_ENUM;
+  if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
+  if (a->relu && !a->y) return BNN_ERR_NULL;
+  if (!a->workspace || a->workspace_bytes < bnn_bbb_linear_bwd_workspace_bytes(a->n_samples, a->batch, a->out_features))
+    return BNN_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(a->workspace) & 15) return BNN_ERR_ALIGN;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  float* gz = reinterpret_cast<float*>(a->workspace);
+  const long cnt = (long)a->n_samples * a->batch * a->out_features;
+  long nb = (cnt + 255) / 256;
+  nb = nb > 2048 ? 2048 : nb;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a->gy, a->y, gz, cnt, a->relu ? 1 : 0);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+
+  BwdK k;
+  k.x = a->x;
+  k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
+  k.gz = gz;
+  k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.eps_w = a->eps_w; k.eps_b = a->eps_b; k.glp = a->g_log_prior; k.glq = a->g_log_q;
+  k.g_wmu = a->g_w_mu; k.g_wrho = a->g_w_rho; k.g_bmu = a->g_b_mu; k.g_brho = a->g_b_rho;
+  k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
+  k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind;
+  k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
+  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
+  k.inv_var_p = 0.f; k.a1 = k.a2 = k.inv2var1 = k.inv2var2 = k.invvar1 = k.invvar2 = 0.f;
+  if (a->prior.kind == BNN_PRIOR_MIXTURE) {
+    if (!(a->prior.sigma1 > 0.f) || !(a->prior.sigma2 > 0.f)) return BNN_ERR_SHAPE;
+    const double s1 = a->prior.sigma1, s2 = a->prior.sigma2;
+    k.a1 = (float)(a->prior.pi / s1);
+    k.a2 = (float)((1.0 - a->prior.pi) / s2);
+    k.inv2var1 = (float)(1.0 / (2.0 * s1 * s1));
+    k.inv2var2 = (float)(1.0 / (2.0 * s2 * s2));
+    k.invvar1 = (float)(1.0 / (s1 * s1));
+    k.invvar2 = (float)(1.0 / (s2 * s2));
+  } else {
+    if (!(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
+    k.inv_var_p = (float)(1.0 / ((double)a->prior.sigma_p * a->prior.sigma_p));
+  }
+  const dim3 grid((a->in_features + 63) / 64, (a->out_features + 63) / 64), block(256);
+  hipLaunchKernelGGL(bbb_bwd_weights_kernel, grid, block, 0, stream, k);
+  err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+  if (a->g_x) return bnn_bbb_input_grad_(a, gz, stream_);
+  return BNN_OK;
+}

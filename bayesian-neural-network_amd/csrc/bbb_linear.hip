@@ -51,6 +51,7 @@ struct BbbK {
   float4* ws;       // stats workspace (see above) or nullptr
   int S, B, K, N;
   int eps_mode, prior_kind, want_stats, relu, y_bf16, spb;
+  int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
   float inv2var1, c1, inv2var2, c2, pi;   // mixture: log N(w;0,s_i) = c_i - w^2 * inv2var_i
@@ -250,7 +251,11 @@ struct FinPack {
 // FINAL: this launch is the last layer of an ELBO evaluation (one 16-feature tile, batch <= 128):
 // the block of sample s finishes with that sample's NLL and log p / log q, i.e. the work of
 // bnn_elbo_finalize, without another launch.
-template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL>
+// TRANS: the same kernel computes the input gradient gx = gz . w (reduction over the ORIGINAL
+// output features): kernel "feature" n = original input index, kernel reduction index k =
+// original output index, weight element (k, n) lives at w[k * ldw + n]; its eps is slot n & 3 of
+// Philox group (k, n >> 2).  No bias, no statistics.
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false>
 __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -298,7 +303,14 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   float mu_n[8], rho_n[8];
   auto load_params = [&](int t) {
     const int k = (t * R + c) * 32 + q * 8;
-    if (ALIGNED) {
+    if (TRANS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const size_t woff = (size_t)min(k + j, K - 1) * p.ldw + nc;
+        mu_n[j] = p.w_mu[woff];
+        rho_n[j] = p.w_rho[woff];
+      }
+    } else if (ALIGNED) {
       const size_t woff = (size_t)nc * K + min(k, K - 8);
       load8<true>(p.w_mu + woff, 8, mu_n);
       load8<true>(p.w_rho + woff, 8, rho_n);
@@ -312,7 +324,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   if (t_lo + wave < t_hi) load_params(t_lo + wave);
   // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
+  if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
     beps_pre = bias_eps(p, n, s, gs, do_dump);
@@ -374,7 +386,20 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
     if (t == t_lo + wave) { asm volatile("" :: "v"(mu[0]), "v"(sg[0])); BNN_STAMP(1); }
 
     float e[8], w[8];
-    if (p.eps_mode == BNN_EPS_PHILOX) {
+    if (TRANS) {
+      const uint32_t gprw = (uint32_t)((p.ldw + 3) >> 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = 0.f;
+        if (p.eps_mode == BNN_EPS_PHILOX) {
+          float e4[4];
+          philox_normal4((uint32_t)(k + j) * gprw + (uint32_t)(n >> 2), gs, wid, p.k0, p.k1, e4);
+          e[j] = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+        } else if (p.eps_mode == BNN_EPS_MEMORY) {
+          if (j < valid) e[j] = p.eps_w[((size_t)s * K + k + j) * p.ldw + n];
+        }
+      }
+    } else if (p.eps_mode == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
       philox_normal4(g, gs, wid, p.k0, p.k1, e);
       philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
@@ -384,7 +409,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) e[j] = 0.f;
     }
-    if (p.eps_w_dump && do_dump) store8<ALIGNED>(p.eps_w_dump + ((size_t)s * N + n) * K + k, valid, e);
+    if (!TRANS && p.eps_w_dump && do_dump) store8<ALIGNED>(p.eps_w_dump + ((size_t)s * N + n) * K + k, valid, e);
 
     // ALIGNED: a lane's 8 weights are all real or all padding (valid is 8 or <= 0), so one mask
     // per step suffices: padded lanes compute on clamped (finite) data and are zeroed at the end.
@@ -471,7 +496,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   // ---- bias of the tile's F features: wave 0, lanes 0..F-1
   if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
-    if (lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    if (!TRANS && lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
     lds_bias[lane] = b;
   }
 #pragma unroll
@@ -611,6 +636,11 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
 template <int MATH, int XDT>
 __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const FinPack fp) {
   bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
+}
+
+template <int MATH, int R, bool ALIGNED>
+__global__ __launch_bounds__(768) void bbb_input_grad_kernel(const BbbK p) {
+  bbb_fwd_body<MATH, BNN_F32, R, ALIGNED, false, true>(p, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -880,6 +910,10 @@ Plan make_plan(int S, int B, int K, int N, bool aligned) {
   int spw = 1;                                       // super-steps per wave; waves divide them evenly
   while ((ssteps + spw - 1) / spw > 12) ++spw;
   int nw = (ssteps + spw - 1) / spw;
+  // Several hundred blocks in flight: smaller blocks (4 waves, 32 KiB of slabs) so that three of
+  // them share a CU and cover each other's load and barrier stalls; a lone sample instead wants
+  // the shortest per-wave chain (one or two k-steps per wave).
+  if ((long)((N + F - 1) / F) * S * mbs >= 400 && ssteps >= 8) nw = 4;
   if (forceNw > 0) nw = forceNw > 12 ? 12 : forceNw;
   if (nw > ssteps) nw = ssteps;
   pl.R = R;
@@ -1084,6 +1118,56 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
     if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_F32, BNN_F32); else BNN_FIN(BNN_MATH_F32, BNN_BF16);
   }
 #undef BNN_FIN
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+// gx[S,B,K] = gz[S,B,N] . w_s with w regenerated (TRANS form of the K-split kernel).  Called by
+// bnn_bbb_linear_bwd (bbb_bwd.hip).
+extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  BbbK k{};
+  k.x = gz;
+  k.x_sstride = (long)a->batch * a->out_features;
+  k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.eps_w = a->eps_w; k.eps_b = a->eps_b; k.eps_w_dump = nullptr; k.eps_b_dump = nullptr;
+  k.y = a->g_x;
+  k.ws = nullptr;
+  k.S = a->n_samples; k.B = a->batch;
+  k.K = a->out_features;            // reduction length
+  k.N = a->in_features;             // produced features
+  k.ldw = a->in_features;
+  k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = 0; k.relu = 0; k.y_bf16 = 0; k.spb = 1;
+  k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
+  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = nullptr;
+  k.inv2var1 = k.inv2var2 = k.c1 = k.c2 = k.pi = 0.f;
+#ifdef BNN_STAMPS
+  k.dbg = nullptr;
+#endif
+  if ((a->in_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->g_x) & 15)) return BNN_ERR_ALIGN;
+  const bool al = (k.K % 8 == 0) && aligned16(gz);
+  const Plan pl = make_plan(k.S, k.B, k.K, k.N, al);
+  const long total = (long)pl.tiles * k.S * ((k.B + 127) / 128);
+  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
+  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+  hipError_t err = hipSuccess;
+#define BNN_IG(MATH, RR, AL)                                                                    \
+  do {                                                                                          \
+    err = allow_big_lds(bbb_input_grad_kernel<MATH, RR, AL>, lds);                              \
+    if (err == hipSuccess)                                                                      \
+      hipLaunchKernelGGL((bbb_input_grad_kernel<MATH, RR, AL>), grid, block, lds, stream, k);   \
+  } while (0)
+#define BNN_IG_R(MATH)                                 \
+  do {                                                 \
+    if (!al) BNN_IG(MATH, 1, false);                   \
+    else if (pl.R == 1) BNN_IG(MATH, 1, true);         \
+    else if (pl.R == 2) BNN_IG(MATH, 2, true);         \
+    else BNN_IG(MATH, 4, true);                        \
+  } while (0)
+  if (a->math == BNN_MATH_BF16) BNN_IG_R(BNN_MATH_BF16); else BNN_IG_R(BNN_MATH_F32);
+#undef BNN_IG
+#undef BNN_IG_R
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;

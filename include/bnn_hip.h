@@ -273,6 +273,53 @@ size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bnn_bbb_linear_bwd — backward of BayesianLinear for n_samples MC samples (what autograd
+ * derives from networks.py:73-88 under classification/class_task.py:78 `loss.backward()`;
+ * closed forms in SURVEY Appendix A.5).  eps is REGENERATED from the Philox map (or re-read
+ * in BNN_EPS_MEMORY mode): no eps- or weight-sized tensor is kept from the forward pass.
+ *   gz = gy * (y > 0) if relu;  gW_s = gz_s^T x_s;  t_s = gW_s + g_log_prior[s] * dlogp/dw(w_s)
+ *   g_w_mu = sum_s t_s;  g_w_rho = (sum_s t_s eps_s - (sum_s g_log_q[s]) / sigma) * sigmoid(rho)
+ *   (bias likewise with column sums of gz);  g_x[s] = gz_s . w_s  (optional).
+ * All tensors fp32.  x [x_samples,batch,in]; gy, y [n_samples,batch,out]; g_x
+ * [n_samples,batch,in].  workspace: bnn_bbb_linear_bwd_workspace_bytes (holds gz).
+ * Weight gradients use the exact-fp32 matrix core; `math` selects the arithmetic of g_x only.
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_bbb_bwd_args {
+  uint32_t struct_bytes;
+  int32_t n_samples, batch, in_features, out_features;
+  const float* x;
+  int32_t x_per_sample;
+  int32_t relu;
+  const float* gy;
+  const float* y;             /* forward output (after ReLU); required when relu != 0 */
+  const float* w_mu;
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  int32_t eps_mode;
+  int32_t math;
+  const float* eps_w;
+  const float* eps_b;
+  uint64_t seed;
+  uint32_t layer_id;
+  uint32_t sample_offset;
+  bnn_prior prior;
+  int32_t reserved;
+  const float* g_log_prior;   /* [n_samples] or NULL (zeros) */
+  const float* g_log_q;       /* [n_samples] or NULL (zeros) */
+  float* g_w_mu;
+  float* g_w_rho;
+  float* g_b_mu;
+  float* g_b_rho;
+  float* g_x;                 /* optional */
+  void* workspace;
+  size_t workspace_bytes;
+} bnn_bbb_bwd_args;
+
+size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
+int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into
  * eps[n_samples, rows, cols]: used by the backward pass to regenerate eps instead of
  * storing it, and by tests to check the frozen counter->element map.
