@@ -47,6 +47,7 @@ class BbbFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved", C.c_int32),
+        ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
     ]
 
 

@@ -6,6 +6,7 @@ collective is a sum all-reduce of three scalars (RCCL over xGMI on a GPU node).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -17,6 +18,10 @@ from .runtime import state, take_samples
 
 
 CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it saves
+# BBB: K-sliced GEMM form (deterministic split-K + reduce kernel) for this range of samples per launch.
+# Measured on MI355X it only ties the K-split kernel at 4..24 samples (29+5 us vs 32 us per layer at 8
+# samples), so it is off unless BNN_HIP_SPLITK=1.
+SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = (4, 24) if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else (0, 0)
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
 
@@ -119,6 +124,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
                           sample_offset=first_sample, want_stats=want_stats)
+                if not last and h.dtype == torch.bfloat16 and SPLIT_MIN_SAMPLES <= n_local < SPLIT_MAX_SAMPLES:
+                    kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
                     out, fin = ops.bbb_final_fwd((h,) + pd, kw, dict(workspaces=stats, **fin_kw))
@@ -262,6 +269,9 @@ class GraphedElbo:
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]
+        self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
+                      if (not self.lr and i < len(self.specs) - 1 and hid == torch.bfloat16 and
+                          SPLIT_MIN_SAMPLES <= S < SPLIT_MAX_SAMPLES) else None for i, sp in enumerate(self.specs)]
         self.wfrag = [None] * len(self.specs)
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
@@ -313,7 +323,7 @@ class GraphedElbo:
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))
             else:
-                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, **common)
+                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], **common)
             h = self.bufs[i]
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)

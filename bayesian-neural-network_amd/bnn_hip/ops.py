@@ -83,6 +83,14 @@ def bbb_workspace(n_samples: int, out_features: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
+SPLIT_MAX_SLICES = 8
+
+
+def split_scratch(n_samples: int, batch: int, out_features: int, device) -> torch.Tensor:
+    """Scratch for the K-sliced GEMM form of K1 (fp32 partial tiles, up to 8 slices)."""
+    return torch.empty(SPLIT_MAX_SLICES * n_samples * batch * out_features, dtype=torch.float32, device=device)
+
+
 def final_scratch(n_samples: int, device) -> torch.Tensor:
     """Zeroed scratch for the fused last layer (K-range slices per sample)."""
     nbytes = L.load().bnn_bbb_final_scratch_bytes(n_samples)
@@ -98,7 +106,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
-               out=None):
+               out=None, split_scratch=None):
     """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -135,8 +143,11 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     a.workspace_bytes = workspace.numel() * 4 if (want_stats and workspace is not None) else 0
     a.log_prior, a.log_q = _ptr(lp), _ptr(lq)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    if split_scratch is not None:
+        a.split_scratch = split_scratch.data_ptr()
+        a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
     res = dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch)
     return a, res, keep
 
 

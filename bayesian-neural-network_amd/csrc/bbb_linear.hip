@@ -51,6 +51,8 @@ struct BbbK {
   float4* ws;       // stats workspace (see above) or nullptr
   int S, B, K, N;
   int eps_mode, prior_kind, want_stats, relu, y_bf16, spb;
+  int ksl;          // GEMM form: K-range slices per (tile group, sample); 1 = none
+  float* ks_part;   // GEMM form, ksl > 1: fp32 partial outputs [ksl][S][B][N] (bias in slice 0)
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
@@ -663,7 +665,10 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   const int K = p.K, N = p.N, B = p.B;
   const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
   int item;
-  if (!xcd_work_item(tbs * p.S * mbs, item)) return;          // block-uniform
+  const int KS = p.ksl;                                       // K-range slices (deterministic split-K)
+  if (!xcd_work_item(tbs * p.S * mbs * KS, item)) return;      // block-uniform
+  const int ks = item % KS;
+  item /= KS;
   const int tb = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int tile = tb * NW + wave;
   const int n = tile * 16 + r;
@@ -671,6 +676,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   const int nc = min(n, N - 1);
   const int m0 = mb * 128;
   const int ksteps = (K + 31) >> 5;
+  const int spb = (ksteps + KS - 1) / KS, t_lo = ks * spb, t_hi = min(ksteps, t_lo + spb);
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
   const bool do_stats = p.want_stats && mb == 0;
   const bool do_ls = do_stats && s == 0;
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
   const int T = (N + 15) >> 4;
 
-  if (do_stats && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+  if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T * KS), 0.f, 0.f, 0.f);
 
   // LDS-DMA staging: wave w brings batch tiles m = w, w + NW, ... of the k-step's x tile.
   size_t xrow[8 / NW];
@@ -704,14 +710,16 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 
   // bias of this wave's tile: eps now, applied in the epilogue
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (q == 0 && n_ok) {
+  if (q == 0 && n_ok && ks == 0) {
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
     beps_pre = bias_eps(p, n, s, gs, do_dump);
   }
 
-  load_params(0);
-  stage_dma(0, 0);
+  if (t_lo < t_hi) {
+    load_params(t_lo);
+    stage_dma(t_lo, t_lo & 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
 
 #pragma nounroll
-  for (int t = 0; t < ksteps; ++t) {
+  for (int t = t_lo; t < t_hi; ++t) {
     const int k = t * 32 + q * 8;
     const bool lane_ok = n_ok && k < K;
     float mu[8], sg[8];
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
       mu[j] = mu_n[j];
       sg[j] = rho_n[j];
     }
-    const bool more = t + 1 < ksteps;
+    const bool more = t + 1 < t_hi;
     if (more) {
       stage_dma(t + 1, (t + 1) & 1);     // buffer (t+1)&1 was last read in step t-1 (barrier since)
       load_params(t + 1);
@@ -786,12 +794,12 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
   if (q == 0) {
     float b = 0.f;
-    if (n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    if (n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
     bias_s[wave][r] = b;
   }
   if (do_stats) {
     const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
-    if (lane == 0 && tile < T) p.ws[1 + (size_t)s * T + tile] = make_float4(a, b, cc, 0.f);
+    if (lane == 0 && tile < T) p.ws[1 + ((size_t)s * T + tile) * KS + ks] = make_float4(a, b, cc, 0.f);
   }
   __syncthreads();
   const int nb = tile * 16 + q * 4;
@@ -803,7 +811,19 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int brow = m0 + m * 16 + r;
-      if (brow < B) {
+      if (brow < B && KS > 1) {                          // raw fp32 partial of this K slice
+        f32x4 v = acc[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += bq[i];
+        float* pp = p.ks_part + (((size_t)ks * p.S + s) * B + brow) * N + nb;
+        if (vec_ok) {
+          *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < N) pp[i] = v[i];
+        }
+      } else if (brow < B) {
         f32x4 v = acc[m];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -835,6 +855,39 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
           }
         }
       }
+    }
+  }
+}
+
+// Sum of the K-slice partials of the GEMM form (slice order), ReLU, down-conversion.
+__global__ void ks_reduce_kernel(const float* __restrict__ part, int KS, long cnt, int relu, void* __restrict__ y,
+                                 int y_bf16, int vec_ok) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
+  if (vec_ok) {
+    for (long i = tid; i < (cnt >> 2); i += nt) {
+      float4 v = reinterpret_cast<const float4*>(part)[i];
+      for (int j = 1; j < KS; ++j) {
+        const float4 u = reinterpret_cast<const float4*>(part + (size_t)j * cnt)[i];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (y_bf16) {
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4*>(y)[i] = o;
+      } else {
+        reinterpret_cast<float4*>(y)[i] = v;
+      }
+    }
+  } else {
+    for (long i = tid; i < cnt; i += nt) {
+      float v = part[i];
+      for (int j = 1; j < KS; ++j) v += part[(size_t)j * cnt + i];
+      if (relu) v = fmaxf(v, 0.f);
+      if (y_bf16) reinterpret_cast<__bf16*>(y)[i] = (__bf16)v;
+      else reinterpret_cast<float*>(y)[i] = v;
     }
   }
 }
@@ -956,7 +1009,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = a->want_stats ? 1 : 0;
-  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1;
+  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1; k.ksl = 1; k.ks_part = nullptr; k.ldw = 0;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
 #ifdef BNN_STAMPS
@@ -1000,11 +1053,43 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   // (feature-tile-group x sample) blocks to fill the chip several waves deep.
   const long gemm_blocks = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
   const int force = env_int("BNN_HIP_BBB_GEMM", -1);
-  const bool use_gemm = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8 &&
-                        (force == 1 || (force != 0 && gemm_blocks >= 450));
+  // K-range slices for the GEMM form when a modest number of samples would leave the chip
+  // under-filled: slices write fp32 partial tiles into the caller's split scratch and a tiny
+  // reduce kernel sums them in slice order (deterministic), applies ReLU and the down-conversion.
+  int ksl = 1;
+  const int ksteps_g = (K + 31) / 32;
+  const size_t part_bytes = (size_t)a->n_samples * a->batch * a->out_features * sizeof(float);
+  if (a->split_scratch && gemm_blocks < 450) {
+    ksl = (int)((600 + gemm_blocks - 1) / gemm_blocks);
+    if (ksl > 8) ksl = 8;
+    if (ksl > ksteps_g / 4) ksl = ksteps_g / 4;
+    // the stats workspace has ceil(N/4) entries per sample; the sliced form uses T*ksl of them
+    const int max_ks = ((a->out_features + 3) / 4) / ((a->out_features + 15) / 16);
+    if (ksl > max_ks) ksl = max_ks;
+    const int fk = env_int("BNN_HIP_BBB_GEMM_KS", 0);
+    if (fk >= 1 && fk <= max_ks) ksl = fk;
+    if (ksl < 1) ksl = 1;
+    if (a->split_scratch_bytes < (size_t)ksl * part_bytes || (reinterpret_cast<uintptr_t>(a->split_scratch) & 15)) ksl = 1;
+  }
+  const bool gemm_ok = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8;
+  const bool use_gemm = gemm_ok && (force == 1 || (force != 0 && (gemm_blocks >= 450 || (ksl > 1 && gemm_blocks * ksl >= 300))));
   if (use_gemm) {
-    const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
+    if (gemm_blocks >= 450 && !env_int("BNN_HIP_BBB_GEMM_KS", 0)) ksl = 1;
+    k.ksl = ksl;
+    k.ks_part = reinterpret_cast<float*>(a->split_scratch);
+    const long blocks = gemm_blocks * ksl;
+    const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(256);
     hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+    if (ksl > 1) {
+      err = hipGetLastError();
+      if (err != hipSuccess) return (int)err;
+      const long cnt = (long)a->n_samples * a->batch * a->out_features;
+      const int vec_ok = (cnt % 4 == 0) && !(reinterpret_cast<uintptr_t>(a->y) & 15);
+      long nb = (cnt / 4 + 255) / 256;
+      nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+      hipLaunchKernelGGL(ks_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, k.ks_part, ksl, cnt, k.relu, a->y,
+                         k.y_bf16, vec_ok);
+    }
   } else {
     const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al);
     const long total = (long)pl.tiles * a->n_samples * mbs;

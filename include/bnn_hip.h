@@ -136,6 +136,10 @@ typedef struct bnn_bbb_fwd_args {
   void* y;
   int32_t y_dtype;          /* bnn_dtype */
   int32_t reserved;
+  void* split_scratch;      /* optional, 16-byte aligned, >= 8 * n_samples*batch*out_features*4 bytes:
+                               lets a mid-sized launch split its K range over several blocks
+                               (fp32 partial tiles summed in a fixed order by a tiny second kernel) */
+  size_t split_scratch_bytes;
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
