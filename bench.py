@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
     ap.add_argument("--allreduce-every", type=int, default=16,
                     help="N>1: ELBO scalars of this many consecutive evaluations share one all-reduce call")
