@@ -22,7 +22,7 @@ EXPORTS = (
     "bnn_bbb_linear_bwd",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
 )
 
 
@@ -47,7 +47,7 @@ class BbbFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved", C.c_int32),
-        ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
+        ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
     ]
 
 
@@ -158,6 +158,8 @@ def load():
     lib.bnn_philox_normal.restype = C.c_int
     lib.bnn_philox_normal.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]
+    lib.bnn_softplus.restype = C.c_int
+    lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int
     lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     v = lib.bnn_version()

@@ -22,6 +22,7 @@ CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it s
 # Measured on MI355X it only ties the K-split kernel at 4..24 samples (29+5 us vs 32 us per layer at 8
 # samples), so it is off unless BNN_HIP_SPLITK=1.
 SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = (4, 24) if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else (0, 0)
+SIGMA_HOIST_MIN_SAMPLES = 24  # BBB: precompute sigma = softplus(rho) once per evaluation from here on
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
 
@@ -124,6 +125,9 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
                           sample_offset=first_sample, want_stats=want_stats)
+                if h.dtype == torch.bfloat16 and n_local >= SIGMA_HOIST_MIN_SAMPLES and eps_mode != L.EPS_ZERO and \
+                        ((sp.in_out[1] + 63) // 64) * n_local >= 450:
+                    kw["w_sigma"] = ops.softplus(pd[1])        # consumed by the throughput (GEMM) form only
                 if not last and h.dtype == torch.bfloat16 and SPLIT_MIN_SAMPLES <= n_local < SPLIT_MAX_SAMPLES:
                     kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
@@ -272,6 +276,9 @@ class GraphedElbo:
         self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
                       if (not self.lr and i < len(self.specs) - 1 and hid == torch.bfloat16 and
                           SPLIT_MIN_SAMPLES <= S < SPLIT_MAX_SAMPLES) else None for i, sp in enumerate(self.specs)]
+        self.wsigma = [torch.empty_like(sp.m.weight_rho.detach())
+                      if (not self.lr and hid == torch.bfloat16 and S >= SIGMA_HOIST_MIN_SAMPLES and
+                          ((sp.in_out[1] + 63) // 64) * S >= 450) else None for sp in self.specs]
         self.wfrag = [None] * len(self.specs)
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
@@ -323,7 +330,10 @@ class GraphedElbo:
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))
             else:
-                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], **common)
+                if self.wsigma[i] is not None:
+                    ops.softplus(p[1], out=self.wsigma[i])
+                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
+                                   w_sigma=self.wsigma[i], **common)
             h = self.bufs[i]
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)

@@ -106,7 +106,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
-               out=None, split_scratch=None):
+               out=None, split_scratch=None, w_sigma=None):
     """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -143,11 +143,13 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     a.workspace_bytes = workspace.numel() * 4 if (want_stats and workspace is not None) else 0
     a.log_prior, a.log_q = _ptr(lp), _ptr(lq)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    if w_sigma is not None:
+        a.w_sigma = w_sigma.data_ptr()
     if split_scratch is not None:
         a.split_scratch = split_scratch.data_ptr()
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
     res = dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma)
     return a, res, keep
 
 
@@ -393,3 +395,14 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(lib.bnn_bbb_linear_bwd(C.byref(a), _stream()), "bnn_bbb_linear_bwd")
     return g_wmu, g_wrho, g_bmu, g_brho, gx
+
+
+def softplus(rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sigma = log1p(exp(rho)) by bnn_softplus (one elementwise kernel)."""
+    lib = L.load()
+    require_device(rho)
+    rho = _f32c(rho, "rho")
+    if out is None:
+        out = torch.empty_like(rho)
+    L.check(lib.bnn_softplus(rho.data_ptr(), out.data_ptr(), rho.numel(), _stream()), "bnn_softplus")
+    return out

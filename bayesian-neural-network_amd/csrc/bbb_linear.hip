@@ -41,6 +41,7 @@ struct BbbK {
   long x_sstride;   // elements between samples of x (0: shared)
   const float* w_mu;
   const float* w_rho;
+  const float* w_sigma;   // optional: softplus(w_rho) precomputed once per evaluation (bnn_softplus)
   const float* b_mu;
   const float* b_rho;
   const float* eps_w;
@@ -603,7 +604,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
           fp->sums[0] = a; fp->sums[1] = b; fp->sums[2] = nll; fp->sums[3] = 1.f;
         }
         if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
-      } else {
+      } else if (fp->ticket) {
         // last-arriving sample block folds the per-sample scalars (sample order) and advances
         // the Philox sample counter: every block has read it by the time it takes a ticket.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(768) void bbb_input_grad_kernel(const BbbK p) {
 //   every wave's B-fragment read is one conflict-free ds_read_b128.  The DMA for tile t+1 is
 //   issued at the top of step t and drained (vmcnt(0)) just before the step's single barrier:
 //   a whole k-step of Philox/softplus work covers its latency.  ~115 VGPRs -> 4 waves/SIMD.
-template <int NW>
+template <int NW, bool SIG>
 __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) {
   __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];      // 2 x 8 KiB
   __shared__ float bias_s[NW][16];
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   auto load_params = [&](int t) {
     const size_t woff = (size_t)nc * K + min(t * 32 + q * 8, K - 8);
     load8<true>(p.w_mu + woff, 8, mu_n);
-    load8<true>(p.w_rho + woff, 8, rho_n);
+    load8<true>((SIG ? p.w_sigma : p.w_rho) + woff, 8, rho_n);
   };
 
   // bias of this wave's tile: eps now, applied in the epilogue
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
     float e2 = 0.f, a = 0.f, ls = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sg[j] = softplus(sg[j]);
+      if (!SIG) sg[j] = softplus(sg[j]);               // SIG: sigma arrives precomputed
       w[j] = __builtin_fmaf(sg[j], e[j], mu[j]);
       e2 = __builtin_fmaf(e[j], e[j], e2);
     }
@@ -1004,6 +1005,8 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.w_sigma = a->w_sigma;
+  if (a->w_sigma && (reinterpret_cast<uintptr_t>(a->w_sigma) & 15)) return BNN_ERR_ALIGN;
   k.eps_w = a->eps_w; k.eps_b = a->eps_b; k.eps_w_dump = a->eps_w_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
   k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
@@ -1079,7 +1082,10 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     k.ks_part = reinterpret_cast<float*>(a->split_scratch);
     const long blocks = gemm_blocks * ksl;
     const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(256);
-    hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4>), grid, block, 0, stream, k);
+    if (a->w_sigma)
+      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+    else
+      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
     if (ksl > 1) {
       err = hipGetLastError();
       if (err != hipSuccess) return (int)err;
@@ -1130,6 +1136,9 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
 
 static constexpr int kFinalMaxSlices = 8;
 
+// reduce.hip: sums over the per-sample outputs + sample-counter advance (one block)
+extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream);
+
 // Scratch of the fused last layer: per-sample tickets, per-slice stats and partial logits tiles.
 // Zero-initialised ONCE by the caller (the kernel leaves the tickets at zero again).
 extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
@@ -1153,7 +1162,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   const bool fuse = al && a->out_features <= 16 && a->batch <= 128 && a->want_stats && !f->local_reparam && nl >= 1 &&
                     f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
                     f->classes == a->out_features && f->batch == a->batch && a->y_dtype == BNN_F32 &&
-                    (a->n_samples == 1 || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
+                    (a->n_samples == 1 || a->n_samples > 16 || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
                     env_int("BNN_HIP_FUSE_FINAL", 1) != 0;
   if (!fuse) {
     rc = bnn_bbb_linear_fwd(a, stream_);
@@ -1162,13 +1171,18 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   fp.sums = f->sums;
-  fp.ticket = f->ticket;
+  // Few samples: the last-arriving sample block folds the sums and advances the counter (one
+  // release/acquire per block).  Many samples: those fences (an L2 write-back each) cost more
+  // than a launch, so a one-block follow-up kernel does it instead.
+  const bool tail_kernel = a->n_samples > 16;
+  fp.ticket = tail_kernel ? nullptr : f->ticket;
   const int K = a->in_features;
   const int ssteps = (K + 31) / 32;
   // K-range slices per sample: one k-step per wave where the scratch allows it (<= 12 waves per
   // block), so the last layer's latency chain is one step long instead of ceil(ssteps/12).
   int KS = (ssteps + 11) / 12;
   KS = KS > kFinalMaxSlices ? kFinalMaxSlices : KS;
+  if ((long)a->n_samples * KS > 128) KS = 1;           // enough sample blocks already: skip the hand-off
   const int forceKs = env_int("BNN_HIP_FINAL_KS", 0);
   if (forceKs >= 1 && forceKs <= kFinalMaxSlices) KS = forceKs;
   if (KS > 1 && (!f->scratch || f->scratch_bytes < bnn_bbb_final_scratch_bytes(a->n_samples) ||
@@ -1205,7 +1219,9 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
 #undef BNN_FIN
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
+  if (err != hipSuccess) return (int)err;
+  if (tail_kernel) return bnn_elbo_sums_(f, stream_);
+  return BNN_OK;
 }
 
 // gx[S,B,K] = gz[S,B,N] . w_s with w regenerated (TRANS form of the K-split kernel).  Called by
@@ -1216,6 +1232,7 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   k.x = gz;
   k.x_sstride = (long)a->batch * a->out_features;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.w_sigma = nullptr;
   k.eps_w = a->eps_w; k.eps_b = a->eps_b; k.eps_w_dump = nullptr; k.eps_b_dump = nullptr;
   k.y = a->g_x;
   k.ws = nullptr;

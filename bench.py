@@ -151,7 +151,7 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
         else:
             ops.bbb_linear_fwd(xin, *pd, n_samples=S_local, prior=l2._prior_spec, math_mode=mm, relu=True,
                                y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True,
-                               workspace=ws, out=out)
+                               workspace=ws, out=out, w_sigma=ev.wsigma[1], split_scratch=ev.split[1])
     us = kernel_alone_us(launch, torch.cuda.current_stream())
     abytes = S_local * algorithmic_bytes_layer(dims[1], dims[1], batch, hid_b, hid_b)
     achieved = abytes / (us * 1e-6) / 1e9

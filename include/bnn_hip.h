@@ -140,6 +140,8 @@ typedef struct bnn_bbb_fwd_args {
                                lets a mid-sized launch split its K range over several blocks
                                (fp32 partial tiles summed in a fixed order by a tiny second kernel) */
   size_t split_scratch_bytes;
+  const float* w_sigma;     /* optional [out,in]: softplus(w_rho) from bnn_softplus, computed once per
+                               evaluation; the throughput kernel then skips the per-sample softplus */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
@@ -336,6 +338,9 @@ int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sa
  * batch is cast once per ELBO evaluation when bf16 math runs many MC samples, so every
  * layer streams 2-byte activations.  (The reference keeps x in fp32, main.py / class_task.py:71.)
  * ---------------------------------------------------------------------------------- */
+/* sigma[i] = log1p(exp(rho[i])) (networks.py:39), n contiguous fp32 elements. */
+int bnn_softplus(const float* rho, float* sigma, int64_t n, void* stream);
+
 int bnn_cast_bf16(const float* src, void* dst_bf16, void* dst_sq_bf16 /* optional: x*x */, int64_t n, void* stream);
 
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */

@@ -476,3 +476,32 @@ def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape):
         scale = float(b.abs().max()) + 1e-12
         err = float((a - b).abs().max())
         assert err <= 3e-5 * scale + 1e-6, (name, err, scale)
+
+
+def test_bbb_throughput_forms_agree(dev, monkeypatch):
+    """24 MC samples per evaluation, on-chip eps: the LDS-DMA block-GEMM form with hoisted sigma
+    (and the tail-kernel sums) against the K-split kernel on the same Philox sample indices, and
+    both against the fp32-math K-split result."""
+    from bnn_hip import engine
+    S = 24
+    net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    res = {}
+    for name, math_mode, gemm in (("gemm", "bf16", "1"), ("ksplit", "bf16", "0"), ("f32", "f32", "0")):
+        monkeypatch.setenv("BNN_HIP_BBB_GEMM", gemm)
+        bnn_hip.set_math(math_mode)
+        bnn_hip.manual_seed(5, counter=300)
+        ev = engine.GraphedElbo(net, xd, yd, S, capture=False)
+        ev.replay()
+        res[name] = ({k: v.clone() for k, v in ev.out.items()}, ev.sums.clone(), int(ev.counter.item()))
+    for name in ("gemm", "ksplit"):
+        out, sums, ctr = res[name]
+        ref, rsums, rctr = res["f32"]
+        assert ctr == rctr == 300 + 2 * S
+        close(out["log_prior"], ref["log_prior"].cpu().numpy(), rtol=2e-6)      # statistics are fp32 in every form
+        close(out["log_q"], ref["log_q"].cpu().numpy(), rtol=2e-6)
+        close(out["nll"], ref["nll"].cpu().numpy(), rtol=5e-3)                  # bf16 logits
+        close(sums[:2], rsums[:2].cpu().numpy(), rtol=2e-6)
+        close(sums[2], float(out["nll"].double().sum()), rtol=1e-6)
+        assert float(sums[3]) == S
