@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void lr_prepare_kernel(const float* __restrict
 }
 
 template <int NW, bool PREP>
-__global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(const LrK p) {
+__global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_gemm_kernel(const LrK p) {
   __shared__ __attribute__((aligned(16))) float4 xt[2][2][8 * 64];   // [buffer][x | x^2][tile] = 32 KiB
   __shared__ float bias_s[NW][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -781,7 +781,13 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
       const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
       if (a->w_frag) {
         if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
-        hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+        if (lr_env_int("BNN_HIP_LR_NW8", 1) && N >= 128) {
+          // 8 waves share each x / x^2 tile: twice the MFMA work per LDS-DMA round trip
+          const long blocks8 = (long)((N + 127) / 128) * a->n_samples * mbs;
+          hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true>), dim3((unsigned)(((blocks8 + 7) / 8) * 8)), dim3(512), 0, stream, k);
+        } else {
+          hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+        }
       } else {
         hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
       }

@@ -288,9 +288,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, lr, args.batch)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and nstr > 1 and not args.no_extras:
+            e1 = make_evaluators(engine, net, x, y, S_global, 1)
+            d1 = run_steps(e1, 600, 60, 1, None, None)
+            out["single_evaluation_in_flight"] = {"samples_per_s": S_global * 600 / d1, "us_per_evaluation": d1 * 1e6 / 600,
+                                                  "note": "same workload, one hipGraph replayed back to back on one stream "
+                                                          "(latency of one ELBO evaluation)"}
+            del e1
         if world == 1 and not args.no_extras and args.net == "mnist":
             extras = []
-            for (S, ns, steps) in ((8, 2, 300), (64, 1, 100), (256, 1, 40)):
+            for (S, ns, steps) in ((8, 3, 300), (64, 1, 100), (256, 1, 40)):
                 e2 = make_evaluators(engine, net, x, y, S, ns)
                 d2 = run_steps(e2, steps, max(5, steps // 10), 1, None, None)
                 r2 = layer2_roofline(e2[0], net, dims, args.batch, S, lr, args.math)
