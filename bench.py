@@ -147,7 +147,7 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
         if lr:
             ops.lr_linear_fwd(xin, *pd, n_samples=S_local, sigma_p=1.0, math_mode=mm, relu=True, y_dtype=out.dtype,
                               eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_kl=True, workspace=ws, out=out,
-                              x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1])
+                              x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1])
         else:
             ops.bbb_linear_fwd(xin, *pd, n_samples=S_local, prior=l2._prior_spec, math_mode=mm, relu=True,
                                y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True,
