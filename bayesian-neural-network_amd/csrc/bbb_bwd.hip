@@ -16,9 +16,10 @@
 // n0 = 64*by + 16*j and the 4 k-tiles of the block's 64-wide k strip and walks the samples.
 // gW^T tiles come from the exact-fp32 matrix core (v_mfma_f32_16x16x4_f32): with the reduction
 // over the batch, A[i = k][kk = b] = x[b][k0 + i] and B[kk = b][j = n] = gz[b][n0 + j] are both
-// read along their contiguous dimension.  D[row = k][col = n] leaves a lane with 4 consecutive k
-// of one feature — exactly one Philox group — so eps is regenerated in the epilogue and neither
-// eps nor w ever exists in memory.  (G, H) = (sum t, sum t*eps) stay in registers across the
+// read along their contiguous dimension.  The four k-tiles of a strip interleave their k's (tile i
+// holds k = i mod 4) so one 16-byte x load feeds all four and each D register position, taken
+// across the tiles, is 4 consecutive k of one feature — exactly one Philox group — so eps is
+// regenerated in the epilogue and neither eps nor w ever exists in memory.  (G, H) = (sum t, sum t*eps) stay in registers across the
 // sample loop; one pass writes g_mu and g_rho.  No atomics.
 #include "bnn_device.h"
 #include "../../include/bnn_hip.h"
@@ -69,22 +70,29 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   const int n = n0 + r;                                   // this lane's feature (D column / B-operand column)
   const bool n_ok = n < N;
   const int gpr = (K + 3) >> 2;
+  const bool kvec = (K & 3) == 0;                         // rows of x are 16-byte aligned
 
-  // resident parameters of the lane's 4 x 4 weights: rows k = k0 + 16 kt + 4 q + i of column n
-  float mu[4][4], sg[4][4], rh[4][4];
-  f32x4 G[4], H[4];
+  // Tile i (i = 0..3) of the 64-wide k strip holds the k's congruent to i mod 4: A row r of tile i is
+  // k = k0 + 4 r + i, so ONE 16-byte load x[b][k0 + 4r .. +3] feeds all four tiles, and D register
+  // `reg` of lane quad q, taken across the four tiles, is the 4 consecutive k's
+  // k0 + 16 q + 4 reg + {0,1,2,3} of feature n: one Philox group.
+  float mu[4][4], sg[4][4], rh[4][4];                     // [reg][i]
+  f32x4 G[4], H[4];                                       // [i][reg]
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    G[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    H[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i) {
+    G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    H[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = k0 + kt * 16 + q * 4 + i;
+      const int k = k0 + q * 16 + reg * 4 + i;
       const bool ok = n_ok && k < K;
       const size_t off = (size_t)min(n, N - 1) * K + min(k, K - 1);
-      mu[kt][i] = ok ? p.w_mu[off] : 0.f;
-      rh[kt][i] = ok ? p.w_rho[off] : 0.f;
-      sg[kt][i] = softplus(rh[kt][i]);
+      mu[reg][i] = ok ? p.w_mu[off] : 0.f;
+      rh[reg][i] = ok ? p.w_rho[off] : 0.f;
+      sg[reg][i] = softplus(rh[reg][i]);
     }
   }
   const bool do_bias = blockIdx.x == 0 && q == 0 && n_ok;   // one lane per feature
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
     bsg = softplus(brh);
   }
   float cq = 0.f;
+  const int ka = k0 + 4 * r;                               // first k of this lane's A-operand quad
 
   for (int s = 0; s < p.S; ++s) {
     const float glp = p.glp ? p.glp[s] : 0.f;
@@ -104,25 +113,40 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
     const float* gzs = p.gz + (size_t)s * B * N;
     f32x4 acc[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.f;
-#pragma unroll 4
-    for (int b0 = 0; b0 < B; b0 += 4) {
-      const int brow = b0 + q;
-      const bool b_ok = brow < B;
-      const float bv = (b_ok && n_ok) ? gzs[(size_t)brow * N + n] : 0.f;
-      colsum += bv;
+    constexpr int U = 8;                                   // batch rows in flight per lane quad
+    for (int b0 = 0; b0 < B; b0 += 4 * U) {
+      float4 av[U];
+      float bv[U];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const int k = k0 + kt * 16 + r;
-        const float av = (b_ok && k < K) ? xs[(size_t)brow * K + k] : 0.f;
-        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kt], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        const int brow = b0 + 4 * u + q;
+        const bool b_ok = brow < B;
+        const float* xr = xs + (size_t)min(brow, B - 1) * K;
+        if (kvec && ka + 3 < K) {
+          av[u] = *reinterpret_cast<const float4*>(xr + ka);
+        } else {
+          av[u].x = (ka + 0 < K) ? xr[ka + 0] : 0.f;
+          av[u].y = (ka + 1 < K) ? xr[ka + 1] : 0.f;
+          av[u].z = (ka + 2 < K) ? xr[ka + 2] : 0.f;
+          av[u].w = (ka + 3 < K) ? xr[ka + 3] : 0.f;
+        }
+        bv[u] = (b_ok && n_ok) ? gzs[(size_t)brow * N + n] : 0.f;   // rows >= B contribute nothing
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        colsum += bv[u];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u], acc[3], 0, 0, 0);
       }
     }
     // ---- epilogue of sample s: regenerate eps of the lane's weights, fold into (G, H)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int kb = k0 + kt * 16 + q * 4;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int kb = k0 + q * 16 + reg * 4;
       if (n_ok && kb < K) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.eps_mode == BNN_EPS_PHILOX) {
@@ -134,10 +158,10 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float w = __builtin_fmaf(sg[kt][i], e[i], mu[kt][i]);
-          const float t = acc[kt][i] + glp * dlogp(p, w);
-          G[kt][i] += t;
-          H[kt][i] = __builtin_fmaf(t, e[i], H[kt][i]);
+          const float w = __builtin_fmaf(sg[reg][i], e[i], mu[reg][i]);
+          const float t = acc[i][reg] + glp * dlogp(p, w);
+          G[i][reg] += t;
+          H[i][reg] = __builtin_fmaf(t, e[i], H[i][reg]);
         }
       }
     }
@@ -162,14 +186,14 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
 
   // ---- g_mu = G;  g_rho = (H - cq / sigma) * sigmoid(rho)
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
+  for (int reg = 0; reg < 4; ++reg) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = k0 + kt * 16 + q * 4 + i;
+      const int k = k0 + q * 16 + reg * 4 + i;
       if (n_ok && k < K) {
         const size_t off = (size_t)n * K + k;
-        p.g_wmu[off] = G[kt][i];
-        p.g_wrho[off] = (H[kt][i] - cq * __builtin_amdgcn_rcpf(sg[kt][i])) * sigmoidf(rh[kt][i]);
+        p.g_wmu[off] = G[i][reg];
+        p.g_wrho[off] = (H[i][reg] - cq * __builtin_amdgcn_rcpf(sg[reg][i])) * sigmoidf(rh[reg][i]);
       }
     }
   }
