@@ -234,10 +234,14 @@ class GraphedElbo:
     sum nll, n_local}: the vector a sharded job all-reduces."""
 
     def __init__(self, net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0,
-                 capture: bool = True, counter_stride: int = 1, stream: Optional[torch.cuda.Stream] = None):
+                 capture: bool = True, counter_stride: int = 1, stream: Optional[torch.cuda.Stream] = None,
+                 sums_ring=None):
         """`counter_stride` > 1: this evaluator is one of several that run concurrently on their
         own streams and interleave the global MC sample index space (evaluator j of n starts j
-        evaluations in and advances by n evaluations per replay)."""
+        evaluations in and advances by n evaluations per replay).
+        `sums_ring` = (base, ring_len, stride_floats): replay k deposits its 4-vector at
+        base.view(-1)[(k % ring_len) * stride : +4] instead of a fixed tensor (device-side cursor), so
+        a sharded job can all-reduce many evaluations' scalars with one collective."""
         self.net, self.samples, self.sigma = net, int(samples), float(sigma)
         self.stride = int(counter_stride)
         self.stream = stream
@@ -264,7 +268,10 @@ class GraphedElbo:
             self.ws.append(ops.lr_workspace(fout, dev) if self.lr else ops.bbb_workspace(S, fout, dev))
         keys = ("kl",) if self.lr else ("log_prior", "log_q")
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
-        self.sums = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(4, dtype=torch.float32, device=dev) if sums_ring is None else sums_ring[0]
+        self.ring = None
+        if sums_ring is not None:
+            self.ring = (torch.zeros(1, dtype=torch.int32, device=dev), int(sums_ring[1]), int(sums_ring[2]))
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
@@ -290,6 +297,9 @@ class GraphedElbo:
         if self.stride > 1:                  # undo the warm-up's stride-sized advance: next index = first + S
             self.counter.fill_(first + self.samples)
             torch.cuda.synchronize()
+        if self.ring is not None:            # the warm-up used slot 0
+            self.ring[0].zero_()
+            torch.cuda.synchronize()
         if capture:
             side = self.stream if self.stream is not None else torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -314,7 +324,7 @@ class GraphedElbo:
                       local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
                       sample_counter_inc=self.samples * self.stride, out=self.out, sums=self.sums,
-                      ticket=self.ticket, scratch=self.scratch)
+                      ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring)
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,

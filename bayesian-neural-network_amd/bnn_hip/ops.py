@@ -234,7 +234,7 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
 def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
                logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
                nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
-               ticket=None, scratch=None):
+               ticket=None, scratch=None, sums_ring=None):
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -277,6 +277,13 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
             out["nll"] = torch.empty(n_samples, dtype=torch.float32, device=dev)
     a.sample_counter, a.sample_counter_inc = _ptr(sample_counter), int(sample_counter_inc)
     a.sums = _ptr(sums)
+    if sums_ring is not None:                       # (pos uint32[1] tensor, ring length, slot stride in floats)
+        if sums is None:
+            raise BnnHipError("sums_ring needs `sums` (the slab base of this evaluator)")
+        ring_pos, ring_len, ring_stride = sums_ring
+        require_device(ring_pos)
+        a.sums_ring_pos, a.sums_ring_len, a.sums_ring_stride = ring_pos.data_ptr(), int(ring_len), int(ring_stride)
+        keep.append(ring_pos)
     a.ticket = _ptr(ticket)
     a.scratch = _ptr(scratch)
     a.scratch_bytes = scratch.numel() * scratch.element_size() if scratch is not None else 0

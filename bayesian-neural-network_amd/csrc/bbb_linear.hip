@@ -601,7 +601,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       fin_store(fk, s, a, b, nll);
       if (fk.S == 1) {
         if (fp->sums) {
-          fp->sums[0] = a; fp->sums[1] = b; fp->sums[2] = nll; fp->sums[3] = 1.f;
+          float* so = fin_sums_slot(fk, fp->sums);
+          so[0] = a; so[1] = b; so[2] = nll; so[3] = 1.f;
         }
         if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
       } else if (fp->ticket) {
@@ -621,7 +622,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
               if (!fk.local_reparam && fk.log_q) tb += __hip_atomic_load(fk.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (fk.nll) tn += __hip_atomic_load(fk.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            fp->sums[0] = (float)ta; fp->sums[1] = (float)tb; fp->sums[2] = (float)tn; fp->sums[3] = (float)fk.S;
+            float* so = fin_sums_slot(fk, fp->sums);
+            so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)fk.S;
           }
           *fp->ticket = 0u;
           if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;

@@ -20,6 +20,8 @@ struct FinK {
   float *log_prior, *log_q, *kl, *nll;
   uint32_t* sample_counter;
   uint32_t sample_counter_inc;
+  uint32_t* ring_pos;            // optional slot cursor of the sums ring (bnn_finalize_args.sums_ring_pos)
+  uint32_t ring_len, ring_stride;
 };
 
 // All transcendental constants of the priors, precomputed on the host in fp64.
@@ -51,6 +53,7 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
     }
   }
   if (a->n_layers > 0 && !(a->prior.kind == BNN_PRIOR_MIXTURE) && !(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
+  if (a->sums_ring_pos && (!a->sums || a->sums_ring_len == 0 || a->sums_ring_stride < 4)) return BNN_ERR_SHAPE;
   if (a->nll) {
     if (!a->logits || !a->target) return BNN_ERR_NULL;
     if (a->batch <= 0 || a->classes <= 0) return BNN_ERR_SHAPE;
@@ -60,6 +63,7 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
   k.prior = a->prior; k.logits = a->logits; k.target = a->target; k.nll_mode = a->nll_mode;
   k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
   k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
+  k.ring_pos = a->sums_ring_pos; k.ring_len = a->sums_ring_len; k.ring_stride = a->sums_ring_stride;
   const double c0 = -0.91893853320467274178;
   const double sp = (a->prior.kind == BNN_PRIOR_MIXTURE) ? 1.0 : (double)a->prior.sigma_p;
   for (int l = 0; l < 8; ++l) cst.cnt_c0[l] = cst.lp_const[l] = cst.kl_const[l] = 0.0;
@@ -195,6 +199,14 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     out_b = b_tot;
     out_nll = (float)red(NV - 1);
   }
+}
+
+// Where this evaluation's 4-vector of sums goes; called by the ONE thread that writes it.
+__device__ __forceinline__ float* fin_sums_slot(const FinK& p, float* sums) {
+  if (!sums || !p.ring_pos) return sums;
+  const uint32_t k = *p.ring_pos;
+  *p.ring_pos = (k + 1u >= p.ring_len) ? 0u : k + 1u;
+  return sums + (size_t)k * p.ring_stride;
 }
 
 __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b, float nll) {

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
     if (s + 1 < s_end) __syncthreads();
   }
   if (single && sums && threadIdx.x == 0) {
+    sums = fin_sums_slot(p, sums);
     sums[0] = (float)tot_a;
     sums[1] = (float)tot_b;
     sums[2] = (float)tot_n;
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
 // Sum of the per-sample scalars over the local samples, in index order per thread and a
 // fixed tree across threads: the 4-vector a sharded job all-reduces.
 __global__ void sample_sums_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                   const float* __restrict__ c, int S, float* __restrict__ sums,
-                                   uint32_t* counter = nullptr, uint32_t counter_inc = 0) {
+                                   const float* __restrict__ c, int S, float* sums, uint32_t* counter,
+                                   uint32_t counter_inc, uint32_t* ring_pos, uint32_t ring_len, uint32_t ring_stride) {
   __shared__ double scratch[16];
   double x = 0, y = 0, z = 0;
   for (int i = threadIdx.x; i < S; i += blockDim.x) {
@@ -145,6 +146,11 @@ __global__ void sample_sums_kernel(const float* __restrict__ a, const float* __r
   z = block_sum(z, scratch);
   if (threadIdx.x == 0) {
     if (sums) {
+      if (ring_pos) {
+        const uint32_t k = *ring_pos;
+        *ring_pos = (k + 1u >= ring_len) ? 0u : k + 1u;
+        sums += (size_t)k * ring_stride;
+      }
       sums[0] = (float)x;
       sums[1] = (float)y;
       sums[2] = (float)z;
@@ -263,7 +269,8 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   if (a->sums && !single) {
     const float* first = a->local_reparam ? a->kl : a->log_prior;
     const float* second = a->local_reparam ? nullptr : a->log_q;
-    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples, a->sums);
+    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples, a->sums,
+                       (uint32_t*)nullptr, 0u, a->sums_ring_pos, a->sums_ring_len, a->sums_ring_stride);
     err = hipGetLastError();
   }
   return err == hipSuccess ? BNN_OK : (int)err;
@@ -286,7 +293,8 @@ extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream_) {
   const float* first = f->local_reparam ? f->kl : f->log_prior;
   const float* second = f->local_reparam ? nullptr : f->log_q;
   hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), first, second,
-                     f->nll, f->n_samples, f->sums, f->sample_counter, f->sample_counter_inc);
+                     f->nll, f->n_samples, f->sums, f->sample_counter, f->sample_counter_inc, f->sums_ring_pos,
+                     f->sums_ring_len, f->sums_ring_stride);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -59,34 +59,55 @@ def n_stochastic(dims):
     return sum(i * o + o for i, o in ((dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])))
 
 
-def run_steps(evs, steps, warmup, world, dist, results, ar_every=16):
+def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks).
 
-    Multi-GPU: every evaluation's 4 ELBO scalars are sum-all-reduced over RCCL; the collectives
-    of `ar_every` consecutive evaluations are issued as ONE call on a [ar_every, 4] slab (the
-    message is latency-bound either way), asynchronously, so they overlap later evaluations."""
+    Multi-GPU: every evaluation's 4 ELBO scalars are sum-all-reduced over RCCL.  The evaluators'
+    graphs deposit them in consecutive rows of `slab` [2*ar_every, n_evaluators, 4] (device-side
+    ring cursor, bnn_finalize_args.sums_ring_pos), and each time a half of the ring is full it is
+    all-reduced with ONE asynchronous call (the message is latency-bound either way) that overlaps
+    the evaluations filling the other half: the per-step host work is the graph launch alone."""
     nstr = len(evs)
     main = torch.cuda.current_stream()
+    per_flush = nstr * ar_every
+    works = [None, None]
+    flushed = []
 
-    def flush(lo, hi):
-        for e in evs:                                   # the slab rows were written on the evaluators' streams
+    def on_streams(fn):
+        for e in evs:
+            if e.stream is not None:
+                with torch.cuda.stream(e.stream):
+                    fn()
+            else:
+                fn()
+
+    def flush(half, partial=False):
+        for e in evs:                                   # the rows were written on the evaluators' streams
             if e.stream is not None:
                 main.wait_stream(e.stream)
-        dist.all_reduce(results[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        rows = slab[half * ar_every:(half + 1) * ar_every]
+        if partial:                                     # barrier in mid-ring: reduce a copy, the rows get their
+            rows = rows.clone()                         # own collective when the half completes
+        works[half] = dist.all_reduce(rows, op=dist.ReduceOp.SUM, async_op=True)
+        if not partial:
+            flushed.append(half)
+        other = works[1 - half]
+        if other is not None:                           # the evaluators overwrite the other half next
+            on_streams(other.wait)
+            works[1 - half] = None
 
     def step(i):
-        e = evs[i % nstr]
-        sums = e.replay()
-        if world > 1:
-            with torch.cuda.stream(e.stream) if e.stream is not None else contextlib.nullcontext():
-                results[i].copy_(sums)
-            if (i + 1) % ar_every == 0:
-                flush(i + 1 - ar_every, i + 1)
+        evs[i % nstr].replay()
+        if dist is not None and (i + 1) % per_flush == 0:
+            flush(((i + 1) // per_flush - 1) % 2)
 
     def barrier(n_done):
-        if world > 1:
-            if n_done % ar_every:
-                flush(n_done - n_done % ar_every, n_done)
+        if dist is not None:
+            if n_done % per_flush:
+                flush((n_done // per_flush) % 2, partial=True)
+            for w in works:
+                if w is not None:
+                    w.wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -98,16 +119,19 @@ def run_steps(evs, steps, warmup, world, dist, results, ar_every=16):
         step(warmup + i)
     barrier(warmup + steps)
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=results.device)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=slab.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    run_steps.last_flushed_half = flushed[-1] if flushed else None
     return dt
 
 
-def make_evaluators(engine, net, x, y, S_global, nstr, graph=True):
+def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None):
     streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
-    return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st) for st in streams]
+    ring = (lambda j: None) if slab is None else (lambda j: (slab.view(-1)[4 * j:], slab.shape[0], 4 * nstr))
+    return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st, sums_ring=ring(j))
+            for j, st in enumerate(streams)]
 
 
 def kernel_alone_us(launch, stream, per_graph=20, reps=50):
@@ -229,6 +253,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never a measurement):
+    # BNN_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges over gloo instead of RCCL
+    rehearsal = os.environ.get("BNN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -236,10 +265,15 @@ def main():
     from bnn_hip import engine
     bnn_hip.set_math(args.math)
     dist = None
-    if world > 1:
+    # BNN_BENCH_FORCE_DIST=1: take the N>1 code path (process group, slab all-reduces) with one rank
+    if world > 1 or os.environ.get("BNN_BENCH_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         bnn_hip.shard_samples(True)
 
     dims, lr = DIMS[args.net], args.variant == "lr"
@@ -247,10 +281,16 @@ def main():
     net, x, y = build_net(dims, lr, args.batch, dev, "regression" if args.net == "wide" else "classification")
     S_local, S_global = args.samples, args.samples * world
     nstr = max(1, args.streams)
-    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph)
+    ar_every = max(1, args.allreduce_every)
+    slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
+    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab)
     assert evs[0].n_local == S_local
-    results = torch.zeros((args.steps + args.warmup, 4), dtype=torch.float32, device=dev)
-    dt = run_steps(evs, args.steps, args.warmup, world, dist, results, max(1, args.allreduce_every))
+    dt = run_steps(evs, args.steps, args.warmup, dist, slab, ar_every)
+    if dist is not None and run_steps.last_flushed_half is not None:
+        # every all-reduced row carries the GLOBAL sample count in its 4th word
+        h = run_steps.last_flushed_half
+        got = slab[h * ar_every:(h + 1) * ar_every, :, 3]
+        assert bool((got == float(S_global)).all()), f"all-reduced sample counts {got.flatten().tolist()} != {S_global}"
     value = S_global * args.steps / dt
     nst = n_stochastic(dims)
     layers = "-".join(map(str, (dims[0], dims[1], dims[1], dims[2])))
@@ -261,6 +301,7 @@ def main():
         "value": value, "unit": "MC-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
+        **({"rehearsal": "all ranks on cuda:0 over gloo; NOT a measurement"} if rehearsal else {}),
         "config": {"workload": f"{layers} {'LR' if lr else 'BBB'} forward-only ELBO evaluation (3-layer forward + "
                                f"log p/log q reductions over {nst} stochastic params + NLL per MC sample), batch "
                                f"{args.batch}, {S_local} MC sample(s) per GPU per evaluation, {nstr} evaluation(s) in "
@@ -268,7 +309,7 @@ def main():
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
                    "parallelism": (f"mc-sample-shard x{world}; RCCL sum all-reduce of the 4 ELBO scalars of every evaluation, "
-                                   f"{args.allreduce_every} evaluations per call") if world > 1 else "single GPU"},
+                                   f"{args.allreduce_every * nstr} evaluations per call, asynchronous") if world > 1 else "single GPU"},
         "kl_elements_per_s": value * nst,
     }
 
@@ -290,7 +331,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and nstr > 1 and not args.no_extras:
             e1 = make_evaluators(engine, net, x, y, S_global, 1)
-            d1 = run_steps(e1, 600, 60, 1, None, None)
+            d1 = run_steps(e1, 600, 60, None)
             out["single_evaluation_in_flight"] = {"samples_per_s": S_global * 600 / d1, "us_per_evaluation": d1 * 1e6 / 600,
                                                   "note": "same workload, one hipGraph replayed back to back on one stream "
                                                           "(latency of one ELBO evaluation)"}
@@ -299,7 +340,7 @@ def main():
             extras = []
             for (S, ns, steps) in ((8, 3, 300), (64, 1, 100), (256, 1, 40)):
                 e2 = make_evaluators(engine, net, x, y, S, ns)
-                d2 = run_steps(e2, steps, max(5, steps // 10), 1, None, None)
+                d2 = run_steps(e2, steps, max(5, steps // 10), None)
                 r2 = layer2_roofline(e2[0], net, dims, args.batch, S, lr, args.math)
                 extras.append({"mc_samples_per_evaluation": S, "evaluations_in_flight": ns, "steps": steps,
                                "samples_per_s": S * steps / d2, "kl_elements_per_s": S * steps / d2 * nst,
@@ -308,7 +349,7 @@ def main():
                 del e2
             out["extras"] = extras
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -265,6 +265,13 @@ typedef struct bnn_finalize_args {
                                        aligned, ZEROED ONCE by the caller: lets the fused last layer
                                        split its K range over several blocks per sample */
   size_t scratch_bytes;
+  uint32_t* sums_ring_pos;          /* optional device word (zero-initialised by the caller): when set,
+                                       the 4-vector goes to sums + (*pos) * sums_ring_stride floats and
+                                       *pos advances modulo sums_ring_len.  Lets a captured hipGraph
+                                       deposit consecutive evaluations in consecutive slots of a slab
+                                       that a sharded job all-reduces once per many evaluations. */
+  uint32_t sums_ring_len;
+  uint32_t sums_ring_stride;        /* floats between consecutive slots (>= 4) */
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);

@@ -505,3 +505,30 @@ def test_bbb_throughput_forms_agree(dev, monkeypatch):
         close(sums[:2], rsums[:2].cpu().numpy(), rtol=2e-6)
         close(sums[2], float(out["nll"].double().sum()), rtol=1e-6)
         assert float(sums[3]) == S
+
+
+@pytest.mark.parametrize("lr,S", [(False, 1), (False, 5), (False, 24), (True, 3), (True, 24)])
+def test_sums_ring_deposits_consecutive_evaluations(dev, lr, S):
+    """bnn_finalize_args.sums_ring_pos: replay k of a captured graph writes its 4-vector into slot
+    k mod ring_len of a strided slab (what bench.py all-reduces once per many evaluations); the
+    values are those a plain evaluator returns for the same global sample indices."""
+    from bnn_hip import engine
+    bnn_hip.set_math("f32")
+    net, _ = build_net(dev, lr, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    ring_len, n_ev, me = 4, 3, 1
+    bnn_hip.manual_seed(11, counter=50)
+    plain = engine.GraphedElbo(net, xd, yd, S)
+    want = [plain.replay().clone() for _ in range(6)]
+    slab = torch.full((ring_len, n_ev, 4), -7.0, dtype=torch.float32, device=dev)
+    bnn_hip.manual_seed(11, counter=50)
+    ev = engine.GraphedElbo(net, xd, yd, S, sums_ring=(slab.view(-1)[4 * me:], ring_len, 4 * n_ev))
+    slab.fill_(-7.0)                                          # the warm-up wrote slot 0
+    for k in range(6):
+        ev.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(slab[k % ring_len, me], want[k]), (k, slab[k % ring_len, me], want[k])
+    assert int(ev.ring[0].item()) == 6 % ring_len
+    others = [j for j in range(n_ev) if j != me]
+    assert bool((slab[:, others] == -7.0).all())             # only this evaluator's column was touched
