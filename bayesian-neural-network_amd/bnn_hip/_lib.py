@@ -19,7 +19,7 @@ NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
 EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
-    "bnn_bbb_linear_bwd",
+    "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
@@ -66,7 +66,7 @@ class LrFwdArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
-        ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p),
+        ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
     ]
 
 
@@ -85,6 +85,23 @@ class BbbBwdArgs(C.Structure):
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class LrBwdArgs(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32),
+        ("n_samples", C.c_int32), ("batch", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
+        ("x", C.c_void_p), ("x_per_sample", C.c_int32), ("relu", C.c_int32),
+        ("gy", C.c_void_p), ("y", C.c_void_p), ("v", C.c_void_p),
+        ("w_mu", C.c_void_p), ("w_rho", C.c_void_p), ("b_mu", C.c_void_p), ("b_rho", C.c_void_p),
+        ("eps_mode", C.c_int32), ("reserved", C.c_int32),
+        ("eps_act", C.c_void_p), ("eps_b", C.c_void_p),
+        ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
+        ("sigma_p", C.c_float), ("reserved2", C.c_int32),
+        ("g_kl", C.c_void_p),
+        ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
+        ("g_x", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -134,6 +151,10 @@ def load():
     lib.bnn_bbb_linear_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.c_void_p]
     lib.bnn_bbb_linear_bwd_workspace_bytes.restype = C.c_size_t
     lib.bnn_bbb_linear_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.bnn_lr_linear_bwd_workspace_bytes.restype = C.c_size_t
+    lib.bnn_lr_linear_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.bnn_lr_linear_bwd.restype = C.c_int
+    lib.bnn_lr_linear_bwd.argtypes = [C.POINTER(LrBwdArgs), C.c_void_p]
     lib.bnn_bbb_linear_bwd.restype = C.c_int
     lib.bnn_bbb_linear_bwd.argtypes = [C.POINTER(BbbBwdArgs), C.c_void_p]
     lib.bnn_lr_linear_fwd_workspace_bytes.restype = C.c_size_t

@@ -235,8 +235,11 @@ class GraphedElbo:
 
     def __init__(self, net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0,
                  capture: bool = True, counter_stride: int = 1, stream: Optional[torch.cuda.Stream] = None,
-                 sums_ring=None):
-        """`counter_stride` > 1: this evaluator is one of several that run concurrently on their
+                 sums_ring=None, evals_per_replay: int = 1):
+        """`evals_per_replay` E > 1: one replay runs E consecutive evaluations (one graph of E times
+        the kernels; a hipGraph launch costs the host ~10 us + ~1 us per node, so short evaluations
+        are launch-bound one at a time); `sums`/`out`/`logits` then hold the LAST one, the ring all.
+        `counter_stride` > 1: this evaluator is one of several that run concurrently on their
         own streams and interleave the global MC sample index space (evaluator j of n starts j
         evaluations in and advances by n evaluations per replay).
         `sums_ring` = (base, ring_len, stride_floats): replay k deposits its 4-vector at
@@ -244,6 +247,7 @@ class GraphedElbo:
         a sharded job can all-reduce many evaluations' scalars with one collective."""
         self.net, self.samples, self.sigma = net, int(samples), float(sigma)
         self.stride = int(counter_stride)
+        self.per_replay = max(1, int(evals_per_replay))
         self.stream = stream
         self.rank, self.world = dist_info()
         self.lo, self.n_local = shard_range(self.samples, self.rank, self.world)
@@ -306,7 +310,8 @@ class GraphedElbo:
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    self._enqueue()
+                    for _ in range(self.per_replay):
+                        self._enqueue()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = g
 
@@ -348,15 +353,19 @@ class GraphedElbo:
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
 
+    def _eager(self):
+        for _ in range(self.per_replay):
+            self._enqueue()
+
     def replay(self) -> torch.Tensor:
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                self.graph.replay() if self.graph is not None else self._enqueue()
+                self.graph.replay() if self.graph is not None else self._eager()
         elif self.graph is not None:
             self.graph.replay()
         else:
-            self._enqueue()
-        take_samples(self.samples)           # keep the host-side counter in step
+            self._eager()
+        take_samples(self.samples * self.per_replay)     # keep the host-side counter in step
         return self.sums
 
     @property

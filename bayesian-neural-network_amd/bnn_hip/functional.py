@@ -138,10 +138,10 @@ class LRLinearFn(torch.autograd.Function):
                                 sigma_p=call.prior.sigma_p, math_mode=call.math_mode, relu=call.relu,
                                 y_dtype=call.y_dtype, eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b,
                                 seed=call.seed, layer_id=call.layer_id, sample_offset=call.sample_offset,
-                                want_kl=call.want_stats, want_scalars=call.want_stats)
+                                want_kl=call.want_stats, want_scalars=call.want_stats, want_v=HIP_BACKWARD)
         y = out["y"]
         ctx.call = call
-        ctx.save_for_backward(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y if call.relu else None)
+        ctx.save_for_backward(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y if call.relu else None, out["v"])
         if call.want_stats:
             return y, out["kl3"]
         z = torch.zeros(3, dtype=torch.float32, device=y.device)
@@ -151,10 +151,20 @@ class LRLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gkl3):
         call: LayerCall = ctx.call
-        x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y = ctx.saved_tensors
+        x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y, v = ctx.saved_tensors
         S = call.n_samples
         K, N = w_mu.shape
         dev = w_mu.device
+        if v is not None and x.dtype == torch.float32 and (y is None or y.dtype == torch.float32):
+            # F1: hand-written backward kernels, eps regenerated on chip, v saved by the forward
+            g_wmu, g_wrho, g_bmu, g_brho, gx = ops.lr_linear_bwd(
+                x, gy.float(), y, v, w_mu, w_rho, b_mu, b_rho, n_samples=S, sigma_p=call.prior.sigma_p, relu=call.relu,
+                eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b, seed=call.seed, layer_id=call.layer_id,
+                sample_offset=call.sample_offset, g_kl=gkl3 if call.want_stats else None,
+                want_gx=ctx.needs_input_grad[0])
+            if gx is not None and x.dim() == 2:
+                gx = gx.sum(0)
+            return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
         x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
         B = x3.shape[1]
         if call.eps_mode == L.EPS_PHILOX:

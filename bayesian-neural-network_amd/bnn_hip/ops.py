@@ -165,7 +165,7 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None, w_frag=None):
+                  out_sq=None, w_frag=None, want_v: bool = False):
     """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
     lib = L.load()
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -212,8 +212,12 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
         if out_sq.dtype != torch.bfloat16 or out_sq.numel() != y.numel():
             raise BnnHipError("out_sq must be bfloat16 shaped like y")
         a.y_sq = out_sq.data_ptr()
+    v = None
+    if want_v:                                       # the variance the kernel sampled from: saved for bnn_lr_linear_bwd
+        v = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
+        a.v_out = v.data_ptr()
     L.check(lib.bnn_lr_linear_fwd(C.byref(a), _stream()), "bnn_lr_linear_fwd")
-    return dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db)
+    return dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v)
 
 
 def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tensor:
@@ -401,6 +405,51 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(lib.bnn_bbb_linear_bwd(C.byref(a), _stream()), "bnn_bbb_linear_bwd")
+    return g_wmu, g_wrho, g_bmu, g_brho, gx
+
+
+def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
+                  eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
+                  want_gx: bool = True):
+    """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
+    saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
+    Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
+    lib = L.load()
+    require_device(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, g_kl)
+    w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
+    b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
+    K, N = w_mu.shape
+    xs, B, Kx, per_sample = _x3(_f32c(x, "x"), n_samples)
+    gy, v = _f32c(gy, "gy"), _f32c(v, "v")
+    if Kx != K or gy.numel() != n_samples * B * N or v.numel() != gy.numel():
+        raise BnnHipError("lr_linear_bwd: shape mismatch")
+    dev = xs.device
+    a = L.LrBwdArgs()
+    a.struct_bytes = C.sizeof(L.LrBwdArgs)
+    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+    a.x, a.x_per_sample, a.relu = xs.data_ptr(), per_sample, int(relu)
+    a.gy, a.v = gy.data_ptr(), v.data_ptr()
+    if relu:
+        y = _f32c(y, "y")
+        a.y = y.data_ptr()
+    a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+    a.eps_mode = eps_mode
+    if eps_mode == L.EPS_MEMORY:
+        eps_act, eps_b = _f32c(eps_act, "eps_act"), _f32c(eps_b, "eps_b")
+        a.eps_act, a.eps_b = eps_act.data_ptr(), eps_b.data_ptr()
+    a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
+    a.sigma_p = float(sigma_p)
+    gk = _f32c(g_kl, "g_kl") if g_kl is not None else None
+    a.g_kl = _ptr(gk)
+    g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
+    g_bmu, g_brho = torch.empty_like(b_mu), torch.empty_like(b_rho)
+    gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
+    a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
+    a.g_x = _ptr(gx)
+    ws = torch.empty(lib.bnn_lr_linear_bwd_workspace_bytes(n_samples, B, K, N, int(want_gx)) // 4, dtype=torch.float32,
+                     device=dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(lib.bnn_lr_linear_bwd(C.byref(a), _stream()), "bnn_lr_linear_bwd")
     return g_wmu, g_wrho, g_bmu, g_brho, gx
 
 

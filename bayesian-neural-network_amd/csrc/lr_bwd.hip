@@ -1,0 +1,408 @@
+// F1  backward of BayesianLinearLR (what autograd derives from reference networks.py:116-138
+// under classification/class_task.py:78 `loss.backward()`), closed forms of SURVEY Appendix A.5.
+//
+// Forward (per MC sample s):  m = x M,  v = x^2 sigma^2,  y = m + sqrt(v) eps_act + b_mu + sigma_b eps_b.
+// With gz_s = gy_s * (y_s > 0) and h_s = gz_s * eps_act_s / (2 sqrt(v_s))  (eps REGENERATED):
+//     g_M      = sum_s x_s^T gz_s            + c_w M / sigma_p^2
+//     g_sigma  = 2 sigma * sum_s (x_s^2)^T h_s + c_w (sigma / sigma_p^2 - 1 / sigma)
+//     g_rho    = g_sigma * sigmoid(rho)          (bias: column sums of gz, times eps_b for sigma_b)
+//     g_x[s]   = gz_s M^T + 2 x_s * (h_s (sigma^2)^T)
+// c_w = g_kl[0] + g_kl[1], c_b = g_kl[0] + g_kl[2] are the upstream gradients of the layer's
+// {kl, weight_kl, bias_kl} (the KL is the same for every sample, so it enters once).
+//
+// Three kernels, all on the exact-fp32 matrix core (v_mfma_f32_16x16x4_f32):
+//  * lr_bwd_prep_kernel     elementwise: ReLU mask, eps_act regenerated per Philox group -> gz, h.
+//  * lr_bwd_weights_kernel  both [in,out] GEMMs (reduction over samples x batch rows) in one pass
+//                           over x / gz / h with the parameter update terms fused in the epilogue.
+//                           A wave owns a 32 x 32 block as 2 x 2 tiles whose rows/cols interleave
+//                           (tile i holds k = i mod 2, tile j holds n = j mod 2), so every operand
+//                           is one 8-byte load along its contiguous dimension and x^2 is formed in
+//                           registers.  8 accumulators -> 32 VGPRs: several blocks share a CU.
+//  * lr_bwd_input_kernel    both [batch,in] GEMMs (reduction over out features, the contiguous
+//                           dimension of gz, h, M and sigma): a 16-byte load feeds 4 consecutive
+//                           MFMA k-steps; 8 waves split the reduction and fold through LDS.
+#include "bnn_device.h"
+#include "../../include/bnn_hip.h"
+
+namespace bnn {
+
+struct LrBwdK {
+  const float* x;        // [Sx, B, K]
+  long x_sstride;
+  const float* gz;       // [S, B, N]
+  const float* h;        // [S, B, N]
+  const float* w_mu;     // [K, N]
+  const float* w_rho;
+  const float* w_sigma;  // [K, N] softplus(rho) (input-gradient kernel)
+  const float* b_mu;
+  const float* b_rho;
+  const float* eps_b;    // BNN_EPS_MEMORY: [S, N]
+  const float* gkl;      // device float[3] or nullptr
+  float* g_wmu;
+  float* g_wrho;
+  float* g_bmu;
+  float* g_brho;
+  float* g_x;            // [S, B, K]
+  int S, B, K, N;
+  int eps_mode;
+  uint32_t k0, k1, layer_id, sample_offset;
+  float inv_var_p;
+};
+
+__device__ __forceinline__ float lr_sigmoid(float r) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-r)); }
+
+// gz = gy * (y > 0);  h = gz * eps_act / (2 sqrt(v))  (0 where v == 0, as the tensor-op form)
+__global__ void lr_bwd_prep_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ v,
+                                   const float* __restrict__ eps_act, float* __restrict__ gz, float* __restrict__ h, int S,
+                                   int B, int N, int relu, int eps_mode, uint32_t k0, uint32_t k1, uint32_t layer_id,
+                                   uint32_t sample_offset) {
+  const int gpr = (N + 3) >> 2;
+  const long total = (long)S * B * gpr;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % gpr);
+    const long sb = idx / gpr;
+    const int b = (int)(sb % B), s = (int)(sb / B);
+    const int nb = g * 4;
+    const size_t off = ((size_t)s * B + b) * N + nb;
+    float e4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (eps_mode == BNN_EPS_PHILOX) {
+      philox_normal4((uint32_t)b * (uint32_t)gpr + (uint32_t)g, sample_offset + (uint32_t)s, layer_id * 4u + 2u, k0, k1, e4);
+    } else if (eps_mode == BNN_EPS_MEMORY) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) e4[i] = eps_act[off + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (nb + i < N) {
+        float g_ = gy[off + i];
+        if (relu && !(y[off + i] > 0.f)) g_ = 0.f;
+        const float sd = __builtin_sqrtf(v[off + i]);
+        gz[off + i] = g_;
+        h[off + i] = sd > 0.f ? g_ * e4[i] / (2.f * sd) : 0.f;
+      }
+    }
+  }
+}
+
+// two consecutive floats of a row, zero beyond `len`; `vec` = 8-byte loads are aligned
+__device__ __forceinline__ float2 load_pair(const float* row, int i, int len, bool vec) {
+  if (vec && i + 1 < len) return *reinterpret_cast<const float2*>(row + i);
+  float2 r;
+  r.x = i < len ? row[i] : 0.f;
+  r.y = i + 1 < len ? row[i + 1] : 0.f;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int kb = blockIdx.x * 64 + (wave & 1) * 32;
+  const int nb = blockIdx.y * 64 + (wave >> 1) * 32;
+  if (kb >= K || nb >= N) return;                        // wave-uniform; the kernel has no barriers
+  const int ka = kb + 2 * c;                             // A operand: k pair of this lane (tile i <-> ka + i)
+  const int na = nb + 2 * c;                             // B operand: n pair of this lane (tile j <-> na + j)
+  const bool kvec = (K & 1) == 0, nvec = (N & 1) == 0;
+
+  f32x4 gM[2][2], gS[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      gM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gS[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const bool do_bias = blockIdx.x == 0 && (wave & 1) == 0;
+  float Gb[2] = {0.f, 0.f}, Hb[2] = {0.f, 0.f};
+
+  for (int s = 0; s < p.S; ++s) {
+    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+    const float* gzs = p.gz + (size_t)s * B * N;
+    const float* hs = p.h + (size_t)s * B * N;
+    float cs0 = 0.f, cs1 = 0.f;
+    constexpr int U = 8;                                  // batch-row quads in flight
+    for (int b0 = 0; b0 < B; b0 += 4 * U) {
+      float2 av[U], gv[U], hv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int brow = b0 + 4 * u + q;
+        const int rc = min(brow, B - 1);
+        av[u] = load_pair(xs + (size_t)rc * K, ka, K, kvec);
+        gv[u] = load_pair(gzs + (size_t)rc * N, na, N, nvec);
+        hv[u] = load_pair(hs + (size_t)rc * N, na, N, nvec);
+        if (brow >= B) {                                  // rows beyond the batch contribute nothing
+          gv[u] = make_float2(0.f, 0.f);
+          hv[u] = make_float2(0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cs0 += gv[u].x;
+        cs1 += gv[u].y;
+        const float a0 = av[u].x, a1 = av[u].y;
+        const float a0s = a0 * a0, a1s = a1 * a1;
+        gM[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, gv[u].x, gM[0][0], 0, 0, 0);
+        gM[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, gv[u].y, gM[0][1], 0, 0, 0);
+        gM[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, gv[u].x, gM[1][0], 0, 0, 0);
+        gM[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, gv[u].y, gM[1][1], 0, 0, 0);
+        gS[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s, hv[u].x, gS[0][0], 0, 0, 0);
+        gS[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s, hv[u].y, gS[0][1], 0, 0, 0);
+        gS[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s, hv[u].x, gS[1][0], 0, 0, 0);
+        gS[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s, hv[u].y, gS[1][1], 0, 0, 0);
+      }
+    }
+    if (do_bias) {                                        // per-sample column sums of gz (lane quads hold b = q mod 4)
+      cs0 += __shfl_xor(cs0, 16, kWave);
+      cs0 += __shfl_xor(cs0, 32, kWave);
+      cs1 += __shfl_xor(cs1, 16, kWave);
+      cs1 += __shfl_xor(cs1, 32, kWave);
+      float e0 = 0.f, e1 = 0.f;
+      if (p.eps_mode == BNN_EPS_PHILOX) {
+        float e4[4];
+        philox_normal4((uint32_t)(na >> 2), p.sample_offset + (uint32_t)s, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+        e0 = (na & 2) ? e4[2] : e4[0];                    // na is even: (na, na + 1) sit in one group of 4
+        e1 = (na & 2) ? e4[3] : e4[1];
+      } else if (p.eps_mode == BNN_EPS_MEMORY) {
+        e0 = na < N ? p.eps_b[(size_t)s * N + na] : 0.f;
+        e1 = na + 1 < N ? p.eps_b[(size_t)s * N + na + 1] : 0.f;
+      }
+      Gb[0] += cs0;
+      Gb[1] += cs1;
+      Hb[0] = __builtin_fmaf(cs0, e0, Hb[0]);
+      Hb[1] = __builtin_fmaf(cs1, e1, Hb[1]);
+    }
+  }
+
+  // ---- epilogue: D row 4q + reg of tile i is k = kb + 2 (4q + reg) + i; D col c of tile j is n = na + j
+  const float cw = p.gkl ? p.gkl[0] + p.gkl[1] : 0.f;
+  const float cb = p.gkl ? p.gkl[0] + p.gkl[2] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int k = kb + 8 * q + 2 * reg + i;
+      if (k >= K) continue;
+      const size_t off = (size_t)k * N + na;
+      const float2 mu = load_pair(p.w_mu + (size_t)k * N, na, N, nvec);
+      const float2 rh = load_pair(p.w_rho + (size_t)k * N, na, N, nvec);
+      float om[2], orh[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float m = j ? mu.y : mu.x, r = j ? rh.y : rh.x;
+        const float sg = softplus(r);
+        const float gsig = 2.f * sg * gS[i][j][reg] + cw * (sg * p.inv_var_p - __builtin_amdgcn_rcpf(sg));
+        om[j] = gM[i][j][reg] + cw * m * p.inv_var_p;
+        orh[j] = gsig * lr_sigmoid(r);
+      }
+      if (nvec && na + 1 < N) {
+        *reinterpret_cast<float2*>(p.g_wmu + off) = make_float2(om[0], om[1]);
+        *reinterpret_cast<float2*>(p.g_wrho + off) = make_float2(orh[0], orh[1]);
+      } else {
+        if (na < N) { p.g_wmu[off] = om[0]; p.g_wrho[off] = orh[0]; }
+        if (na + 1 < N) { p.g_wmu[off + 1] = om[1]; p.g_wrho[off + 1] = orh[1]; }
+      }
+    }
+  }
+  if (do_bias && q == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = na + j;
+      if (n < N) {
+        const float bm = p.b_mu[n], br = p.b_rho[n];
+        const float sb = softplus(br);
+        p.g_bmu[n] = Gb[j] + cb * bm * p.inv_var_p;
+        p.g_brho[n] = (Hb[j] + cb * (sb * p.inv_var_p - __builtin_amdgcn_rcpf(sb))) * lr_sigmoid(br);
+      }
+    }
+  }
+}
+
+// four consecutive floats of a row, zero beyond `len`; `vec` = 16-byte loads are aligned
+__device__ __forceinline__ float4 load_quad(const float* row, int i, int len, bool vec) {
+  if (vec && i + 3 < len) return *reinterpret_cast<const float4*>(row + i);
+  float4 r;
+  r.x = i < len ? row[i] : 0.f;
+  r.y = i + 1 < len ? row[i + 1] : 0.f;
+  r.z = i + 2 < len ? row[i + 2] : 0.f;
+  r.w = i + 3 < len ? row[i + 3] : 0.f;
+  return r;
+}
+
+// grid (ceil(K/32), ceil(B/32), S), 8 waves.  Block tile 32 batch rows x 32 input features as
+// 2 x 2 MFMA tiles for each of P = gz M^T and Q = h (sigma^2)^T; wave w takes the 16-wide
+// slices w, w + 8, ... of the out-feature range.  MFMA k-step t of a slice uses reduction
+// index n = 16 slice + 4 q + t on both operands, i.e. component t of one 16-byte load.
+__global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
+  __shared__ f32x4 red[4][8][64];                       // 32 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, s = blockIdx.z;
+  const float* gzs = p.gz + (size_t)s * B * N;
+  const float* hs = p.h + (size_t)s * B * N;
+  const bool nvec = (N & 3) == 0;
+  const int nslices = (N + 15) >> 4;
+
+  f32x4 P[2][2], Q[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      P[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      Q[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int ra0 = min(b0 + c, B - 1), ra1 = min(b0 + 16 + c, B - 1);        // A rows (clamped: those D rows are not stored)
+  const int kc0 = min(k0 + c, K - 1), kc1 = min(k0 + 16 + c, K - 1);        // B columns (likewise)
+  for (int sl = wave; sl < nslices; sl += 8) {
+    const int n = sl * 16 + 4 * q;
+    const float4 ga0 = load_quad(gzs + (size_t)ra0 * N, n, N, nvec), ga1 = load_quad(gzs + (size_t)ra1 * N, n, N, nvec);
+    const float4 ha0 = load_quad(hs + (size_t)ra0 * N, n, N, nvec), ha1 = load_quad(hs + (size_t)ra1 * N, n, N, nvec);
+    const float4 m0 = load_quad(p.w_mu + (size_t)kc0 * N, n, N, nvec), m1 = load_quad(p.w_mu + (size_t)kc1 * N, n, N, nvec);
+    float4 s0 = load_quad(p.w_sigma + (size_t)kc0 * N, n, N, nvec), s1 = load_quad(p.w_sigma + (size_t)kc1 * N, n, N, nvec);
+    s0.x *= s0.x; s0.y *= s0.y; s0.z *= s0.z; s0.w *= s0.w;
+    s1.x *= s1.x; s1.y *= s1.y; s1.z *= s1.z; s1.w *= s1.w;
+#define LR_STEP(F)                                                                 \
+    P[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0.F, m0.F, P[0][0], 0, 0, 0); \
+    P[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0.F, m1.F, P[0][1], 0, 0, 0); \
+    P[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1.F, m0.F, P[1][0], 0, 0, 0); \
+    P[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1.F, m1.F, P[1][1], 0, 0, 0); \
+    Q[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha0.F, s0.F, Q[0][0], 0, 0, 0); \
+    Q[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha0.F, s1.F, Q[0][1], 0, 0, 0); \
+    Q[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha1.F, s0.F, Q[1][0], 0, 0, 0); \
+    Q[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha1.F, s1.F, Q[1][1], 0, 0, 0);
+    LR_STEP(x)
+    LR_STEP(y)
+    LR_STEP(z)
+    LR_STEP(w)
+#undef LR_STEP
+  }
+
+  // ---- fold the 8 partial sums: waves 4..7 -> LDS -> waves 0..3 add; then 0..3 -> LDS -> wave `combo` sums
+  if (wave >= 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        red[wave - 4][i * 2 + j][lane] = P[i][j];
+        red[wave - 4][4 + i * 2 + j][lane] = Q[i][j];
+      }
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        P[i][j] += red[wave][i * 2 + j][lane];
+        Q[i][j] += red[wave][4 + i * 2 + j][lane];
+      }
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        red[wave][i * 2 + j][lane] = P[i][j];
+        red[wave][4 + i * 2 + j][lane] = Q[i][j];
+      }
+  }
+  __syncthreads();
+  if (wave < 4) {
+    const int combo = wave, ti = combo >> 1, tj = combo & 1;
+    f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f}, qs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      ps += red[w][combo][lane];
+      qs += red[w][4 + combo][lane];
+    }
+    const int k = k0 + 16 * tj + c;
+    if (k < K) {
+      const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int b = b0 + 16 * ti + 4 * q + reg;
+        if (b < B) {
+          const float xv = xs[(size_t)b * K + k];
+          p.g_x[((size_t)s * B + b) * K + k] = __builtin_fmaf(2.f * xv, qs[reg], ps[reg]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace bnn
+
+using namespace bnn;
+
+extern "C" int bnn_softplus(const float* rho, float* sigma, int64_t n, void* stream);
+
+static size_t lr_bwd_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t bnn_lr_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t in_features,
+                                                    int32_t out_features, int32_t want_gx) {
+  if (n_samples <= 0 || batch <= 0 || in_features <= 0 || out_features <= 0) return 0;
+  const size_t act = lr_bwd_align((size_t)n_samples * batch * out_features * sizeof(float));
+  const size_t sig = want_gx ? lr_bwd_align((size_t)in_features * out_features * sizeof(float)) : 0;
+  return 2 * act + sig;
+}
+
+extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
+  if (!a) return BNN_ERR_NULL;
+  if (a->struct_bytes != sizeof(bnn_lr_bwd_args)) return BNN_ERR_ABI;
+  if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
+  if (a->n_samples > 65535) return BNN_ERR_SHAPE;
+  if (!a->x || !a->gy || !a->v || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->g_w_mu || !a->g_w_rho ||
+      !a->g_b_mu || !a->g_b_rho)
+    return BNN_ERR_NULL;
+  if ((unsigned)a->eps_mode > 2u) return BNN_ERR_ENUM;
+  if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_act || !a->eps_b)) return BNN_ERR_NULL;
+  if (a->relu && !a->y) return BNN_ERR_NULL;
+  if (!(a->sigma_p > 0.f)) return BNN_ERR_SHAPE;
+  const int S = a->n_samples, B = a->batch, K = a->in_features, N = a->out_features;
+  if (!a->workspace || a->workspace_bytes < bnn_lr_linear_bwd_workspace_bytes(S, B, K, N, a->g_x ? 1 : 0))
+    return BNN_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(a->workspace) & 15) return BNN_ERR_ALIGN;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->w_mu) |
+                       reinterpret_cast<uintptr_t>(a->w_rho) | reinterpret_cast<uintptr_t>(a->g_w_mu) |
+                       reinterpret_cast<uintptr_t>(a->g_w_rho);
+  if (al & 15) return BNN_ERR_ALIGN;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const size_t act = lr_bwd_align((size_t)S * B * N * sizeof(float));
+  char* base = reinterpret_cast<char*>(a->workspace);
+  float* gz = reinterpret_cast<float*>(base);
+  float* h = reinterpret_cast<float*>(base + act);
+  float* sig = a->g_x ? reinterpret_cast<float*>(base + 2 * act) : nullptr;
+
+  const uint32_t k0 = (uint32_t)a->seed, k1 = (uint32_t)(a->seed >> 32);
+  const long groups = (long)S * B * ((N + 3) / 4);
+  long nb = (groups + 255) / 256;
+  nb = nb > 4096 ? 4096 : nb;
+  hipLaunchKernelGGL(lr_bwd_prep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a->gy, a->y, a->v, a->eps_act, gz, h, S, B,
+                     N, a->relu ? 1 : 0, a->eps_mode, k0, k1, a->layer_id, a->sample_offset);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+
+  LrBwdK k;
+  k.x = a->x;
+  k.x_sstride = a->x_per_sample ? (long)B * K : 0;
+  k.gz = gz; k.h = h;
+  k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.w_sigma = sig; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.eps_b = a->eps_b; k.gkl = a->g_kl;
+  k.g_wmu = a->g_w_mu; k.g_wrho = a->g_w_rho; k.g_bmu = a->g_b_mu; k.g_brho = a->g_b_rho; k.g_x = a->g_x;
+  k.S = S; k.B = B; k.K = K; k.N = N;
+  k.eps_mode = a->eps_mode; k.k0 = k0; k.k1 = k1; k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
+  k.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
+  hipLaunchKernelGGL(lr_bwd_weights_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, stream, k);
+  err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+  if (a->g_x) {
+    const int rc = bnn_softplus(a->w_rho, sig, (int64_t)K * N, stream_);
+    if (rc != BNN_OK) return rc;
+    hipLaunchKernelGGL(lr_bwd_input_kernel, dim3((K + 31) / 32, (B + 31) / 32, S), dim3(512), 0, stream, k);
+    err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+  }
+  return BNN_OK;
+}

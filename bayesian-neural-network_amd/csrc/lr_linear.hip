@@ -40,6 +40,7 @@ struct LrK {
   const void* x_sq; // optional bf16 x*x (same shape as x)
   const float4* w_frag;  // optional prepared weights (lr_prepare_kernel): [T][ksteps][2][64] x 16 B
   void* y_sq;       // optional bf16 y*y
+  float* v_out;     // optional fp32 variance
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
   int eps_mode, want_kl, relu, y_bf16;
@@ -330,6 +331,11 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+    }
+    if (p.v_out) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) p.v_out[yoff + i] = vv[ii][i];
     }
     if (p.y_bf16) {
       __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
@@ -761,7 +767,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
-  k.x_sq = a->x_sq; k.y_sq = a->y_sq;
+  k.x_sq = a->x_sq; k.y_sq = a->y_sq; k.v_out = a->v_out;
   k.w_frag = reinterpret_cast<const float4*>(a->w_frag);
   k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
@@ -775,7 +781,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   {
     const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
     const int force = lr_env_int("BNN_HIP_LR_GEMM", -1);
-    const bool can = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+    const bool can = !a->v_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                      !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
     if (can && (force == 1 || (force != 0 && gemm_blocks >= 300))) {
       const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);

@@ -22,6 +22,7 @@ algorithmic bytes; `cpu_baseline` is the parity-pinned CPU oracle timed on this 
 import argparse
 import contextlib
 import json
+import math
 import os
 import sys
 import time
@@ -60,7 +61,9 @@ def n_stochastic(dims):
 
 
 def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
-    """W untimed + K timed steps bracketed by barrier + synchronize; returns seconds (max over ranks).
+    """W untimed + K timed steps (a step = ONE ELBO evaluation) bracketed by barrier + synchronize;
+    returns seconds (max over ranks).  An evaluator replay runs `evs[0].per_replay` consecutive
+    evaluations (one hipGraph launch): steps and warmup must be multiples of it.
 
     Multi-GPU: every evaluation's 4 ELBO scalars are sum-all-reduced over RCCL.  The evaluators'
     graphs deposit them in consecutive rows of `slab` [2*ar_every, n_evaluators, 4] (device-side
@@ -68,8 +71,10 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     all-reduced with ONE asynchronous call (the message is latency-bound either way) that overlaps
     the evaluations filling the other half: the per-step host work is the graph launch alone."""
     nstr = len(evs)
+    E = evs[0].per_replay
+    assert steps % E == 0 and warmup % E == 0 and (dist is None or ar_every % E == 0)
     main = torch.cuda.current_stream()
-    per_flush = nstr * ar_every
+    per_flush = nstr * ar_every // E                    # replays between two all-reduces
     works = [None, None]
     flushed = []
 
@@ -96,7 +101,7 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
             on_streams(other.wait)
             works[1 - half] = None
 
-    def step(i):
+    def replay(i):
         evs[i % nstr].replay()
         if dist is not None and (i + 1) % per_flush == 0:
             flush(((i + 1) // per_flush - 1) % 2)
@@ -111,13 +116,14 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(warmup):
-        step(i)
-    barrier(warmup)
+    nw, ns = warmup // E, steps // E
+    for i in range(nw):
+        replay(i)
+    barrier(nw)
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i)
-    barrier(warmup + steps)
+    for i in range(ns):
+        replay(nw + i)
+    barrier(nw + ns)
     dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=slab.device)
@@ -127,10 +133,11 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     return dt
 
 
-def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None):
+def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None, per_replay=1):
     streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
     ring = (lambda j: None) if slab is None else (lambda j: (slab.view(-1)[4 * j:], slab.shape[0], 4 * nstr))
-    return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st, sums_ring=ring(j))
+    return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st, sums_ring=ring(j),
+                               evals_per_replay=per_replay)
             for j, st in enumerate(streams)]
 
 
@@ -237,10 +244,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
     ap.add_argument("--allreduce-every", type=int, default=16,
                     help="N>1: ELBO scalars of this many consecutive evaluations share one all-reduce call")
+    ap.add_argument("--evals-per-graph", type=int, default=4,
+                    help="consecutive ELBO evaluations captured in one hipGraph (amortises the ~10 us host cost of a "
+                         "graph launch); reduced to a common divisor of --steps, --warmup and --allreduce-every")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--net", default="mnist", choices=list(DIMS))
     ap.add_argument("--variant", default="bbb", choices=["bbb", "lr"])
@@ -282,8 +292,10 @@ def main():
     S_local, S_global = args.samples, args.samples * world
     nstr = max(1, args.streams)
     ar_every = max(1, args.allreduce_every)
+    per_replay = math.gcd(max(1, args.evals_per_graph), args.steps, args.warmup or args.steps,
+                          *((ar_every,) if dist is not None else ()))
     slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
-    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab)
+    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay)
     assert evs[0].n_local == S_local
     dt = run_steps(evs, args.steps, args.warmup, dist, slab, ar_every)
     if dist is not None and run_steps.last_flushed_half is not None:
@@ -308,6 +320,7 @@ def main():
                                f"flight per GPU, Gaussian prior, on-chip Philox eps",
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
+                   "evaluations_per_graph_launch": per_replay,
                    "parallelism": (f"mc-sample-shard x{world}; RCCL sum all-reduce of the 4 ELBO scalars of every evaluation, "
                                    f"{args.allreduce_every * nstr} evaluations per call, asynchronous") if world > 1 else "single GPU"},
         "kl_elements_per_s": value * nst,

@@ -196,6 +196,9 @@ typedef struct bnn_lr_fwd_args {
   const void* w_frag;       /* optional output of bnn_lr_prepare for these weights: the throughput
                                kernel then streams ready bf16 (M, sigma^2) fragments and the KL
                                workspace is the one bnn_lr_prepare filled (want_kl still set) */
+  float* v_out;             /* optional fp32 [n_samples,batch,out]: the pre-activation variance v
+                               (networks.py:121) as the kernel computed it; bnn_lr_linear_bwd needs
+                               it.  Selects the latency form of the kernel. */
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
@@ -331,6 +334,56 @@ typedef struct bnn_bbb_bwd_args {
 
 size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
 int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * bnn_lr_linear_bwd — backward of BayesianLinearLR for n_samples MC samples (what autograd
+ * derives from networks.py:116-138 under class_task.py:78 `loss.backward()`; closed forms in
+ * SURVEY Appendix A.5).  eps_act / eps_b are REGENERATED from the Philox map.
+ *   gz = gy * (y > 0) if relu;   h = gz * eps_act / (2 sqrt(v))
+ *   g_w_mu  = sum_s x_s^T gz_s + c_w M / sigma_p^2
+ *   g_w_rho = (2 sigma sum_s (x_s^2)^T h_s + c_w (sigma / sigma_p^2 - 1 / sigma)) * sigmoid(rho)
+ *   g_b_mu  = sum_s colsum(gz_s) + c_b b_mu / sigma_p^2;   g_b_rho likewise with eps_b
+ *   g_x[s]  = gz_s M^T + 2 x_s * (h_s (sigma^2)^T)          (optional)
+ * with c_w = g_kl[0] + g_kl[1], c_b = g_kl[0] + g_kl[2]: the upstream gradients of the layer's
+ * kl_out triple {kl, weight_kl, bias_kl} (device float[3]; NULL = zeros).
+ * All tensors fp32.  x [x_samples,batch,in]; gy, y, v [n_samples,batch,out] (v = the v_out of
+ * the forward call); weights [in,out]; g_x [n_samples,batch,in].  Exact-fp32 matrix core.
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_lr_bwd_args {
+  uint32_t struct_bytes;
+  int32_t n_samples, batch, in_features, out_features;
+  const float* x;
+  int32_t x_per_sample;
+  int32_t relu;
+  const float* gy;
+  const float* y;             /* forward output (after ReLU); required when relu != 0 */
+  const float* v;             /* pre-activation variance saved by bnn_lr_linear_fwd (v_out) */
+  const float* w_mu;
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  int32_t eps_mode;
+  int32_t reserved;
+  const float* eps_act;       /* BNN_EPS_MEMORY */
+  const float* eps_b;
+  uint64_t seed;
+  uint32_t layer_id;
+  uint32_t sample_offset;
+  float sigma_p;
+  int32_t reserved2;
+  const float* g_kl;          /* device float[3] or NULL */
+  float* g_w_mu;
+  float* g_w_rho;
+  float* g_b_mu;
+  float* g_b_rho;
+  float* g_x;                 /* optional */
+  void* workspace;
+  size_t workspace_bytes;
+} bnn_lr_bwd_args;
+
+size_t bnn_lr_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t in_features,
+                                         int32_t out_features, int32_t want_gx);
+int bnn_lr_linear_bwd(const bnn_lr_bwd_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into

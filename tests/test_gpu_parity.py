@@ -478,6 +478,40 @@ def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape):
         assert err <= 3e-5 * scale + 1e-6, (name, err, scale)
 
 
+@pytest.mark.parametrize("eps_mode", ["philox", "memory"])
+@pytest.mark.parametrize("shape", [(3, 20, 72, 38, True), (2, 128, 1200, 1200, True), (2, 128, 784, 1200, True),
+                                   (1, 8, 50, 1, False), (2, 5, 33, 65, False), (1, 7, 1, 50, True)])
+def test_lr_backward_kernels_match_tensor_op_gradients(dev, shape, eps_mode):
+    """F1: bnn_lr_linear_bwd (eps regenerated on chip, v saved by the forward, fp32 matrix core)
+    against the closed-form gradients evaluated with tensor ops on the same eps (the path golden
+    G5 pins against autograd of the oracle)."""
+    from bnn_hip import functional as Fn
+    S, B, K, N, relu = shape
+    rs = np.random.RandomState(6)
+    mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+    x = mk(S, B, K, lo=-1, hi=1)
+    w_mu, w_rho, b_mu, b_rho = mk(K, N), mk(K, N, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
+    mem = eps_mode == "memory"
+    eps_act = torch.from_numpy(rs.standard_normal((S, B, N)).astype(np.float32)).to(dev) if mem else None
+    eps_b = torch.from_numpy(rs.standard_normal((S, N)).astype(np.float32)).to(dev) if mem else None
+    call = Fn.LayerCall(n_samples=S, prior=ops.PriorSpec(False, 0.8), math_mode=L.MATH_F32, relu=relu,
+                        eps_mode=L.EPS_MEMORY if mem else L.EPS_PHILOX, seed=13, layer_id=1, sample_offset=70,
+                        want_stats=True)
+    gy, gkl = mk(S, B, N, lo=-1, hi=1), mk(3, lo=0.1, hi=0.5)
+    grads = {}
+    for hip in (True, False):
+        Fn.HIP_BACKWARD = hip
+        leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
+        y, kl3 = Fn.LRLinearFn.apply(*leaves, eps_act, eps_b, call)
+        ((y * gy).sum() + (kl3 * gkl).sum()).backward()
+        grads[hip] = [l.grad.clone() for l in leaves]
+    Fn.HIP_BACKWARD = True
+    for name, a, b in zip(("x", "w_mu", "w_rho", "b_mu", "b_rho"), grads[True], grads[False]):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        assert err <= 5e-5 * scale + 1e-6, (name, err, scale)
+
+
 def test_bbb_throughput_forms_agree(dev, monkeypatch):
     """24 MC samples per evaluation, on-chip eps: the LDS-DMA block-GEMM form with hoisted sigma
     (and the tail-kernel sums) against the K-split kernel on the same Philox sample indices, and

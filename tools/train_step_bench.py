@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for lr in (False, True):
     for math_mode in ("bf16", "f32"):
-        for hip in ((True, False) if not lr else (False,)):
+        for hip in (True, False):
             bnn_hip.set_math(math_mode); Fn.HIP_BACKWARD = hip
             mp = dict(input_shape=784, classes=10, batch_size=128, hidden_units=1200, mode="classification",
                       mu_init=[-0.2, 0.2], rho_init=[-5, -4], prior_init=[1.0], mixture_prior=False, local_reparam=lr)
