@@ -5,6 +5,8 @@
 `functional` autograd bridges (forward = HIP kernels)
 `engine`     batched-samples launcher + MC-sample sharding over torch.distributed
 `runtime`    process-wide knobs: math mode, Philox seed / sample counter, sharding switch
+`optim`      FusedAdam: torch.optim.Adam's update in one launch (F2)
+`train`      GraphedTrainStep: zero_grad -> sample_elbo -> backward -> Adam as one hipGraph
 `synth`      synthetic inputs with the reference's distributions (numpy only)
 """
 from .runtime import get_math, manual_seed, set_host_eps, set_math, shard_samples  # noqa: F401

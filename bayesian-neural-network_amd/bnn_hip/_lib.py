@@ -19,7 +19,7 @@ NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
 EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
-    "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd",
+    "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
@@ -85,6 +85,7 @@ class BbbBwdArgs(C.Structure):
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("sample_counter", C.c_void_p),
     ]
 
 
@@ -102,6 +103,22 @@ class LrBwdArgs(C.Structure):
         ("g_kl", C.c_void_p),
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("sample_counter", C.c_void_p),
+    ]
+
+
+ADAM_MAX_TENSORS = 16
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("n_tensors", C.c_int32),
+        ("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+        ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+        ("numel", C.c_int64 * ADAM_MAX_TENSORS),
+        ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+        ("step", C.c_uint32), ("reserved0", C.c_uint32),
+        ("lr_device", C.c_void_p), ("step_device", C.c_void_p), ("step_advance", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -155,6 +172,11 @@ def load():
     lib.bnn_lr_linear_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.bnn_lr_linear_bwd.restype = C.c_int
     lib.bnn_lr_linear_bwd.argtypes = [C.POINTER(LrBwdArgs), C.c_void_p]
+    lib.bnn_adam_step.restype = C.c_int
+    lib.bnn_adam_step.argtypes = [C.POINTER(AdamArgs), C.c_void_p]
+    lib.bnn_nll_bwd.restype = C.c_int
+    lib.bnn_nll_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_float, C.c_void_p]
     lib.bnn_bbb_linear_bwd.restype = C.c_int
     lib.bnn_bbb_linear_bwd.argtypes = [C.POINTER(BbbBwdArgs), C.c_void_p]
     lib.bnn_lr_linear_fwd_workspace_bytes.restype = C.c_size_t

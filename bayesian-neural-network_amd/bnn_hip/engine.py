@@ -98,7 +98,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
             eps_mode, e_w, e_b = L.EPS_PHILOX, None, None
         call = LayerCall(n_samples=n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
                          eps_mode=eps_mode, seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
-                         want_stats=want_stats, y_dtype=torch.float32 if last else hidden_dtype)
+                         want_stats=want_stats, y_dtype=torch.float32 if last else hidden_dtype,
+                         sample_counter=state.device_counter if (differentiable and eps_mode == L.EPS_PHILOX) else None)
         p = (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)
         if differentiable:
             if sp.lr:

@@ -32,6 +32,7 @@ class LayerCall:
     sample_offset: int
     want_stats: bool
     y_dtype: torch.dtype = torch.float32
+    sample_counter: Optional[torch.Tensor] = None   # device int32[1] added to sample_offset at run time
 
 
 # F1 switch: True = HIP backward kernels (bnn_bbb_linear_bwd); False = the closed-form gradients
@@ -52,6 +53,7 @@ class BBBLinearFn(torch.autograd.Function):
                                  math_mode=call.math_mode, relu=call.relu, y_dtype=call.y_dtype,
                                  eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
                                  layer_id=call.layer_id, sample_offset=call.sample_offset,
+                                 sample_counter=call.sample_counter,
                                  want_stats=call.want_stats, want_scalars=call.want_stats)
         y = out["y"]
         ctx.call = call
@@ -75,12 +77,14 @@ class BBBLinearFn(torch.autograd.Function):
             g_wmu, g_wrho, g_bmu, g_brho, gx = ops.bbb_linear_bwd(
                 x, gy.float(), y, w_mu, w_rho, b_mu, b_rho, n_samples=S, prior=call.prior, math_mode=call.math_mode,
                 relu=call.relu, eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
-                layer_id=call.layer_id, sample_offset=call.sample_offset,
+                layer_id=call.layer_id, sample_offset=call.sample_offset, sample_counter=call.sample_counter,
                 g_log_prior=glp if call.want_stats else None, g_log_q=glq if call.want_stats else None,
                 want_gx=ctx.needs_input_grad[0])
             if gx is not None and x.dim() == 2:
                 gx = gx.sum(0)
             return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
+        if call.sample_counter is not None:
+            raise ops.BnnHipError("a device sample counter needs the HIP backward kernels (fp32 activations)")
         if call.eps_mode == L.EPS_PHILOX:
             eps_w = ops.philox_normal(call.seed, call.layer_id * 4 + 0, call.sample_offset, S, N, K, dev)
             eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)
@@ -138,6 +142,7 @@ class LRLinearFn(torch.autograd.Function):
                                 sigma_p=call.prior.sigma_p, math_mode=call.math_mode, relu=call.relu,
                                 y_dtype=call.y_dtype, eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b,
                                 seed=call.seed, layer_id=call.layer_id, sample_offset=call.sample_offset,
+                                sample_counter=call.sample_counter,
                                 want_kl=call.want_stats, want_scalars=call.want_stats, want_v=HIP_BACKWARD)
         y = out["y"]
         ctx.call = call
@@ -160,11 +165,13 @@ class LRLinearFn(torch.autograd.Function):
             g_wmu, g_wrho, g_bmu, g_brho, gx = ops.lr_linear_bwd(
                 x, gy.float(), y, v, w_mu, w_rho, b_mu, b_rho, n_samples=S, sigma_p=call.prior.sigma_p, relu=call.relu,
                 eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b, seed=call.seed, layer_id=call.layer_id,
-                sample_offset=call.sample_offset, g_kl=gkl3 if call.want_stats else None,
-                want_gx=ctx.needs_input_grad[0])
+                sample_offset=call.sample_offset, sample_counter=call.sample_counter,
+                g_kl=gkl3 if call.want_stats else None, want_gx=ctx.needs_input_grad[0])
             if gx is not None and x.dim() == 2:
                 gx = gx.sum(0)
             return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
+        if call.sample_counter is not None:
+            raise ops.BnnHipError("a device sample counter needs the HIP backward kernels (fp32 activations)")
         x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
         B = x3.shape[1]
         if call.eps_mode == L.EPS_PHILOX:
@@ -226,6 +233,8 @@ class NLLFn(torch.autograd.Function):
     def backward(ctx, gnll):
         logits, target = ctx.saved_tensors
         S = logits.shape[0]
+        if HIP_BACKWARD and logits.dtype == torch.float32:
+            return ops.nll_bwd(logits, target, gnll, ctx.mode, ctx.sigma), None, None, None
         if ctx.mode == "classification":
             p = torch.softmax(logits.float(), dim=-1)
             onehot = torch.zeros_like(p[0]).scatter_(1, target.view(-1, 1).to(torch.int64), 1.0)

@@ -366,7 +366,7 @@ def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None):
 
 def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
                    eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
-                   g_log_prior=None, g_log_q=None, want_gx: bool = True):
+                   g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None):
     """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
     (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
     lib = L.load()
@@ -404,13 +404,14 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     a.g_x = _ptr(gx)
     ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    a.sample_counter = _ptr(sample_counter)
     L.check(lib.bnn_bbb_linear_bwd(C.byref(a), _stream()), "bnn_bbb_linear_bwd")
     return g_wmu, g_wrho, g_bmu, g_brho, gx
 
 
 def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
                   eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
-                  want_gx: bool = True):
+                  want_gx: bool = True, sample_counter=None):
     """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
     saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
     Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
@@ -449,8 +450,61 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
     ws = torch.empty(lib.bnn_lr_linear_bwd_workspace_bytes(n_samples, B, K, N, int(want_gx)) // 4, dtype=torch.float32,
                      device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    a.sample_counter = _ptr(sample_counter)
     L.check(lib.bnn_lr_linear_bwd(C.byref(a), _stream()), "bnn_lr_linear_bwd")
     return g_wmu, g_wrho, g_bmu, g_brho, gx
+
+
+def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
+    """Gradient of the per-sample summed NLL w.r.t. logits[S,B,C] scaled by g_nll[S] (bnn_nll_bwd)."""
+    lib = L.load()
+    require_device(logits, target, g_nll)
+    lg = _f32c(logits, "logits")
+    S, B, Cc = lg.shape
+    gn = _f32c(g_nll.reshape(-1), "g_nll")
+    if gn.numel() != S:
+        raise BnnHipError("g_nll must have one element per MC sample")
+    if mode == "classification":
+        tg, m = target.to(torch.int64).contiguous(), L.NLL_CLASSIFICATION
+        if tg.numel() != B:
+            raise BnnHipError("classification target must have `batch` elements")
+    elif mode == "regression":
+        tg, m = _f32c(target.to(torch.float32), "target"), L.NLL_REGRESSION
+        if tg.numel() != B * Cc:
+            raise BnnHipError("regression target must match the output shape")
+    else:
+        raise Exception("Training mode must be either 'regression' or 'classification'")
+    out = torch.empty_like(lg)
+    L.check(lib.bnn_nll_bwd(lg.data_ptr(), tg.data_ptr(), gn.data_ptr(), out.data_ptr(), S, B, Cc, m, float(sigma), _stream()),
+            "bnn_nll_bwd")
+    return out
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: float, weight_decay: float, step: int = 0,
+              lr_device=None, step_device=None):
+    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch)."""
+    lib = L.load()
+    n = len(params)
+    for lo in range(0, n, L.ADAM_MAX_TENSORS):
+        hi = min(n, lo + L.ADAM_MAX_TENSORS)
+        a = L.AdamArgs()
+        a.struct_bytes = C.sizeof(L.AdamArgs)
+        a.n_tensors = hi - lo
+        for j in range(lo, hi):
+            p, g, m, v = params[j], grads[j], exp_avgs[j], exp_avg_sqs[j]
+            require_device(p, g, m, v)
+            for t_ in (p, g, m, v):
+                if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.numel() != p.numel():
+                    raise BnnHipError("adam_step: tensors must be contiguous float32 of the parameter's size")
+            a.param[j - lo], a.grad[j - lo] = p.data_ptr(), g.data_ptr()
+            a.exp_avg[j - lo], a.exp_avg_sq[j - lo] = m.data_ptr(), v.data_ptr()
+            a.numel[j - lo] = p.numel()
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        a.step = int(step)
+        a.lr_device = _ptr(lr_device)
+        a.step_device = _ptr(step_device)
+        a.step_advance = int(lo == 0)                   # the first launch of the step advances the device counter
+        L.check(lib.bnn_adam_step(C.byref(a), _stream()), "bnn_adam_step")
 
 
 def softplus(rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

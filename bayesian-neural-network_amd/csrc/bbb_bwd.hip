@@ -45,6 +45,7 @@ struct BwdK {
   int S, B, K, N;
   int eps_mode, prior_kind;
   uint32_t k0, k1, layer_id, sample_offset;
+  const uint32_t* sample_counter;
   float inv_var_p;                                   // Gaussian prior: 1 / sigma_p^2
   float a1, a2, inv2var1, inv2var2, invvar1, invvar2; // mixture: a_i = pi_i / sigma_i
 };
@@ -103,12 +104,13 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
     bsg = softplus(brh);
   }
   float cq = 0.f;
+  const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   const int ka = k0 + 4 * r;                               // first k of this lane's A-operand quad
 
   for (int s = 0; s < p.S; ++s) {
     const float glp = p.glp ? p.glp[s] : 0.f;
     cq += p.glq ? p.glq[s] : 0.f;
-    const uint32_t gs = p.sample_offset + (uint32_t)s;
+    const uint32_t gs = sample_base + (uint32_t)s;
     const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
     const float* gzs = p.gz + (size_t)s * B * N;
     f32x4 acc[4];
@@ -254,7 +256,7 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
-  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
+  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
   k.inv_var_p = 0.f; k.a1 = k.a2 = k.inv2var1 = k.inv2var2 = k.invvar1 = k.invvar2 = 0.f;
   if (a->prior.kind == BNN_PRIOR_MIXTURE) {
     if (!(a->prior.sigma1 > 0.f) || !(a->prior.sigma2 > 0.f)) return BNN_ERR_SHAPE;

@@ -1244,7 +1244,7 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   k.ldw = a->in_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = 0; k.relu = 0; k.y_bf16 = 0; k.spb = 1;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
-  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = nullptr;
+  k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
   k.inv2var1 = k.inv2var2 = k.c1 = k.c2 = k.pi = 0.f;
 #ifdef BNN_STAMPS
   k.dbg = nullptr;

@@ -46,6 +46,7 @@ struct LrBwdK {
   int S, B, K, N;
   int eps_mode;
   uint32_t k0, k1, layer_id, sample_offset;
+  const uint32_t* sample_counter;
   float inv_var_p;
 };
 
@@ -55,7 +56,8 @@ __device__ __forceinline__ float lr_sigmoid(float r) { return __builtin_amdgcn_r
 __global__ void lr_bwd_prep_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ v,
                                    const float* __restrict__ eps_act, float* __restrict__ gz, float* __restrict__ h, int S,
                                    int B, int N, int relu, int eps_mode, uint32_t k0, uint32_t k1, uint32_t layer_id,
-                                   uint32_t sample_offset) {
+                                   uint32_t sample_offset, const uint32_t* sample_counter) {
+  if (sample_counter) sample_offset += *sample_counter;
   const int gpr = (N + 3) >> 2;
   const long total = (long)S * B * gpr;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
       gS[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   const bool do_bias = blockIdx.x == 0 && (wave & 1) == 0;
+  const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   float Gb[2] = {0.f, 0.f}, Hb[2] = {0.f, 0.f};
 
   for (int s = 0; s < p.S; ++s) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
       float e0 = 0.f, e1 = 0.f;
       if (p.eps_mode == BNN_EPS_PHILOX) {
         float e4[4];
-        philox_normal4((uint32_t)(na >> 2), p.sample_offset + (uint32_t)s, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+        philox_normal4((uint32_t)(na >> 2), sample_base + (uint32_t)s, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
         e0 = (na & 2) ? e4[2] : e4[0];                    // na is even: (na, na + 1) sit in one group of 4
         e1 = (na & 2) ? e4[3] : e4[1];
       } else if (p.eps_mode == BNN_EPS_MEMORY) {
@@ -380,7 +383,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   long nb = (groups + 255) / 256;
   nb = nb > 4096 ? 4096 : nb;
   hipLaunchKernelGGL(lr_bwd_prep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a->gy, a->y, a->v, a->eps_act, gz, h, S, B,
-                     N, a->relu ? 1 : 0, a->eps_mode, k0, k1, a->layer_id, a->sample_offset);
+                     N, a->relu ? 1 : 0, a->eps_mode, k0, k1, a->layer_id, a->sample_offset, a->sample_counter);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
 
@@ -393,6 +396,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   k.g_wmu = a->g_w_mu; k.g_wrho = a->g_w_rho; k.g_bmu = a->g_b_mu; k.g_brho = a->g_b_rho; k.g_x = a->g_x;
   k.S = S; k.B = B; k.K = K; k.N = N;
   k.eps_mode = a->eps_mode; k.k0 = k0; k.k1 = k1; k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
+  k.sample_counter = a->sample_counter;
   k.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
   hipLaunchKernelGGL(lr_bwd_weights_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, stream, k);
   err = hipGetLastError();

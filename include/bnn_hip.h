@@ -330,6 +330,8 @@ typedef struct bnn_bbb_bwd_args {
   float* g_x;                 /* optional */
   void* workspace;
   size_t workspace_bytes;
+  const uint32_t* sample_counter; /* optional device word added to sample_offset at run time (the value
+                                     the forward of the same step read), as in bnn_bbb_fwd_args */
 } bnn_bbb_bwd_args;
 
 size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
@@ -379,11 +381,53 @@ typedef struct bnn_lr_bwd_args {
   float* g_x;                 /* optional */
   void* workspace;
   size_t workspace_bytes;
+  const uint32_t* sample_counter; /* optional device word, as in bnn_bbb_bwd_args */
 } bnn_lr_bwd_args;
 
 size_t bnn_lr_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t in_features,
                                          int32_t out_features, int32_t want_gx);
 int bnn_lr_linear_bwd(const bnn_lr_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * F2  bnn_adam_step — torch.optim.Adam.step() (the optimiser the reference's trainers build,
+ * classification/class_task.py:60, :79; regression/reg_task.py:53) over up to
+ * BNN_ADAM_MAX_TENSORS parameter tensors in ONE launch:
+ *     g = grad + weight_decay * p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * t = step (host) or, when step_device != NULL, the device word *step_device, advanced first if
+ * step_advance != 0 (so a captured hipGraph of the training step counts by itself).  lr_device (optional device float)
+ * overrides lr, so StepLR (class_task.py:61) can change the rate of a captured graph.
+ * All tensors fp32, contiguous, 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+#define BNN_ADAM_MAX_TENSORS 16
+typedef struct bnn_adam_args {
+  uint32_t struct_bytes;
+  int32_t n_tensors;
+  float* param[BNN_ADAM_MAX_TENSORS];
+  const float* grad[BNN_ADAM_MAX_TENSORS];
+  float* exp_avg[BNN_ADAM_MAX_TENSORS];
+  float* exp_avg_sq[BNN_ADAM_MAX_TENSORS];
+  int64_t numel[BNN_ADAM_MAX_TENSORS];
+  double lr, beta1, beta2, eps, weight_decay;   /* doubles, as torch holds them: 1 - beta2 must not be
+                                                   formed from a float-rounded beta2 */
+  uint32_t step;                 /* 1-based step number when step_device == NULL */
+  uint32_t reserved0;
+  const float* lr_device;
+  uint32_t* step_device;
+  int32_t step_advance;          /* with step_device: 1 = ++(*step_device) before the update, 0 = use it
+                                    as it is (second and later launches of one optimiser step) */
+  int32_t reserved;
+} bnn_adam_args;
+
+int bnn_adam_step(const bnn_adam_args* args, void* stream);
+
+/* bnn_nll_bwd — gradient of the summed NLL (networks.py:183-190) w.r.t. the logits of every MC
+ * sample, scaled by g_nll[s] (device float[n_samples]):
+ *   classification: (softmax(logits_s) - onehot(target)) * g_nll[s]
+ *   regression:     (logits_s - target) / nll_sigma^2 * g_nll[s]
+ * logits, g_logits fp32 [n_samples,batch,classes]; target as for bnn_elbo_finalize. */
+int bnn_nll_bwd(const float* logits, const void* target, const float* g_nll, float* g_logits, int32_t n_samples,
+                int32_t batch, int32_t classes, int32_t nll_mode, float nll_sigma, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into

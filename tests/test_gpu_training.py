@@ -60,3 +60,105 @@ def test_regression_training_reduces_loss_and_fits(local_reparam):
         a = net(Xd[:8])
         b = net2(Xd[:8])
     assert torch.equal(a, b)                                              # eval & sample=False: deterministic mean weights
+
+
+def test_fused_adam_matches_torch_adam():
+    """F2: bnn_adam_step against torch.optim.Adam (class_task.py:60) over several steps, odd
+    tensor sizes, weight decay, a learning-rate change (StepLR, class_task.py:61) and more
+    than 16 tensors."""
+    from bnn_hip.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    shapes = [(1200, 784), (1200,), (7,), (33, 5), (1,), (4096,), (1025,)] + [(3, 3)] * 12
+    for wd, capturable in ((0.0, False), (0.01, False), (0.0, True)):
+        base = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)).to(dev) for s in shapes]
+        pa = [torch.nn.Parameter(b.clone()) for b in base]
+        pb = [torch.nn.Parameter(b.clone()) for b in base]
+        oa = torch.optim.Adam(pa, lr=1e-3, weight_decay=wd)
+        ob = FusedAdam(pb, lr=1e-3, weight_decay=wd, capturable=capturable)
+        sa = torch.optim.lr_scheduler.StepLR(oa, step_size=3, gamma=0.5)
+        sb = torch.optim.lr_scheduler.StepLR(ob, step_size=3, gamma=0.5)
+        for it in range(7):
+            for a, b in zip(pa, pb):
+                g = torch.from_numpy(rs.standard_normal(tuple(a.shape)).astype(np.float32)).to(dev) * (10.0 ** (it % 3 - 1))
+                a.grad, b.grad = g.clone(), g.clone()
+            oa.step(); ob.step(); sa.step(); sb.step()
+        if capturable:
+            assert ob.device_step() == 7
+        for a, b in zip(pa, pb):
+            err = float((a.detach() - b.detach()).abs().max())
+            assert err <= 2e-6 * (float(a.detach().abs().max()) + 1.0), err
+        for a, b in zip(pa, pb):
+            close_m = float((oa.state[a]["exp_avg"] - ob.state[b]["exp_avg"]).abs().max())
+            close_v = float((oa.state[a]["exp_avg_sq"] - ob.state[b]["exp_avg_sq"]).abs().max())
+            assert close_m <= 1e-6 * (float(oa.state[a]["exp_avg"].abs().max()) + 1e-6) + 1e-9
+            assert close_v <= 1e-6 * (float(oa.state[a]["exp_avg_sq"].abs().max()) + 1e-6) + 1e-12
+
+
+@pytest.mark.parametrize("mode", ["classification", "regression"])
+def test_nll_backward_kernel_matches_autograd(mode):
+    from bnn_hip import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(4)
+    S, B, C = 3, 37, (10 if mode == "classification" else 4)
+    logits = torch.from_numpy(rs.standard_normal((S, B, C)).astype(np.float32) * 3).to(dev).requires_grad_(True)
+    g = torch.from_numpy(rs.uniform(0.2, 1.0, S).astype(np.float32)).to(dev)
+    if mode == "classification":
+        tgt = torch.from_numpy(rs.randint(0, C, B)).to(dev)
+        nll = torch.stack([torch.nn.functional.cross_entropy(logits[s], tgt, reduction="sum") for s in range(S)])
+    else:
+        tgt = torch.from_numpy(rs.standard_normal((B, C)).astype(np.float32)).to(dev)
+        sig = 0.7
+        nll = torch.stack([-torch.distributions.Normal(logits[s], sig).log_prob(tgt).sum() for s in range(S)])
+    (nll * g).sum().backward()
+    got = ops.nll_bwd(logits.detach(), tgt, g, mode, 0.7)
+    assert float((got - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
+
+
+@pytest.mark.parametrize("local_reparam", [False, True])
+def test_graphed_train_step_equals_eager_steps(local_reparam):
+    """train.GraphedTrainStep (zero_grad -> sample_elbo -> backward -> Adam in one hipGraph, device
+    sample counter / Adam step / beta) reproduces the eager loop of class_task.py:66-79 step by
+    step: same parameters after every step (same Philox sample indices, fp32 math)."""
+    import networks
+    from bnn_hip.optim import FusedAdam
+    from bnn_hip.train import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    bnn_hip.set_math("f32")
+    mp = dict(input_shape=784, classes=10, batch_size=64, hidden_units=96, mode="classification", mu_init=[-0.2, 0.2],
+              rho_init=[-5, -4], prior_init=[1.0], mixture_prior=False, local_reparam=local_reparam)
+    torch.manual_seed(1)
+    net_a = networks.BayesianNetwork(mp).to(dev).train()
+    net_b = networks.BayesianNetwork(mp).to(dev).train()
+    net_b.load_state_dict(net_a.state_dict())
+    rs = np.random.RandomState(2)
+    xs = [torch.from_numpy(rs.uniform(0, 1, (64, 1, 28, 28)).astype(np.float32)).to(dev) for _ in range(4)]
+    ys = [torch.from_numpy(rs.randint(0, 10, 64)).to(dev) for _ in range(4)]
+    S, M = 2, 4
+    oa = FusedAdam(net_a.parameters(), lr=1e-3)
+    ob = FusedAdam(net_b.parameters(), lr=1e-3, capturable=True)
+    sched = torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.5)
+    sched_a = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5)
+    bnn_hip.manual_seed(99, counter=500)
+    before = {k: v.clone() for k, v in net_b.state_dict().items()}
+    graphed = GraphedTrainStep(net_b, ob, xs[0], ys[0], S)
+    for k, v in net_b.state_dict().items():                    # building the graph left the model untouched
+        assert torch.equal(v, before[k]), k
+    assert ob.device_step() == 0
+    outs_b = []
+    for idx in range(M):
+        outs_b.append([o.clone() for o in graphed.step(xs[idx], ys[idx], _beta(M, idx))])
+        sched.step()
+    assert ob.device_step() == M and int(graphed.counter.item()) == M * S
+    bnn_hip.manual_seed(99, counter=500)
+    elbo = net_a.sample_elbo_lr if local_reparam else net_a.sample_elbo
+    for idx in range(M):
+        oa.zero_grad()
+        out = elbo(xs[idx], ys[idx], _beta(M, idx), S)
+        out[0].backward()
+        oa.step()
+        sched_a.step()
+        for got, want in zip(outs_b[idx], out):
+            assert float((got - want.detach()).abs().max()) <= 1e-5 * (float(want.detach().abs().max()) + 1e-6), idx
+    for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), k

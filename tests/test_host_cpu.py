@@ -34,17 +34,24 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_the_header(tmp_path):
+    """Every ctypes mirror in bnn_hip/_lib.py has the size and the field offsets of its C struct."""
     from bnn_hip import _lib
+    pairs = [("bnn_bbb_fwd_args", _lib.BbbFwdArgs), ("bnn_lr_fwd_args", _lib.LrFwdArgs),
+             ("bnn_finalize_args", _lib.FinalizeArgs), ("bnn_bbb_bwd_args", _lib.BbbBwdArgs),
+             ("bnn_lr_bwd_args", _lib.LrBwdArgs), ("bnn_adam_args", _lib.AdamArgs), ("bnn_prior", _lib.Prior)]
+    lines, want = [], []
+    for cname, cls in pairs:
+        lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
+        want.append(C.sizeof(cls))
+        for fname, _t in cls._fields_:
+            lines.append('printf("%%zu\\n", offsetof(%s, %s));' % (cname, fname))
+            want.append(getattr(cls, fname).offset)
     prog = tmp_path / "sz.c"
-    prog.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
-                    'sizeof(bnn_bbb_fwd_args),sizeof(bnn_lr_fwd_args),sizeof(bnn_finalize_args),'
-                    'offsetof(bnn_bbb_fwd_args,prior),offsetof(bnn_lr_fwd_args,sigma_p),offsetof(bnn_finalize_args,sums));}' % HEADER)
+    prog.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){%s return 0;}' % (HEADER, "".join(lines)))
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(prog), "-o", str(exe)], check=True)   # header is plain C
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    got = [C.sizeof(_lib.BbbFwdArgs), C.sizeof(_lib.LrFwdArgs), C.sizeof(_lib.FinalizeArgs),
-           _lib.BbbFwdArgs.prior.offset, _lib.LrFwdArgs.sigma_p.offset, _lib.FinalizeArgs.sums.offset]
-    assert [int(v) for v in out] == got
+    assert [int(v) for v in out] == want
 
 
 def test_argument_validation_without_a_device():
@@ -64,6 +71,15 @@ def test_argument_validation_without_a_device():
     assert lib.bnn_philox_normal(None, 1, 0, 0, 1, 1, 1, None) == -1
     assert lib.bnn_bbb_linear_fwd_workspace_bytes(2, 1200) == (1 + 2 * 300) * 16
     assert lib.bnn_lr_linear_fwd_workspace_bytes(1200) == (1 + 300) * 16
+    lb = L.LrBwdArgs()
+    assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -5
+    lb.struct_bytes = C.sizeof(L.LrBwdArgs)
+    assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -2
+    ad = L.AdamArgs()
+    assert lib.bnn_adam_step(C.byref(ad), None) == -5
+    ad.struct_bytes = C.sizeof(L.AdamArgs)
+    assert lib.bnn_adam_step(C.byref(ad), None) == -2
+    assert lib.bnn_nll_bwd(None, None, None, None, 1, 1, 1, 0, 1.0, None) == -1
 
 
 def test_cpu_tensors_are_refused():
