@@ -225,6 +225,41 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
     return sums[0], sums[1], sums[2], samples
 
 
+def mc_forward(layers: Sequence[LayerSpec], x: torch.Tensor, samples: int) -> torch.Tensor:
+    """Outputs of `samples` stochastic forward passes in ONE launch per layer: what the reference
+    collects by calling net(x, sample=True) in a Python loop (regression/reg_task.py:76-83,
+    classification/class_task.py:83-85).  Returns this rank's [n_local, B, out] fp32 block."""
+    rank, world = dist_info()
+    first_global = take_samples(samples)
+    lo, n_local = shard_range(samples, rank, world)
+    if n_local == 0:
+        return torch.empty((0, x.shape[0], layers[-1].in_out[1]), dtype=torch.float32, device=x.device)
+    injected = collect_injected(layers, x.shape[0], samples, x.device)
+    if injected is not None and world > 1:
+        injected = [t[lo:lo + n_local].contiguous() for t in injected]
+    with torch.no_grad():
+        logits, _ = run_layers(layers, x, n_local, first_global + lo, want_stats=False, sample=True, injected=injected,
+                               differentiable=False)
+    return logits
+
+
+def mc_predict(layers: Sequence[LayerSpec], x: torch.Tensor, samples: int):
+    """F3: (preds[B], probs[B,C]) with probs = mean_s softmax(net(x, sample=True)) (class_task.py:81-87),
+    the samples batched per launch and, when sharding is on, split over the ranks."""
+    logits = mc_forward(layers, x, samples)
+    rank, world = dist_info()
+    if world > 1:
+        import torch.distributed as dist
+        if logits.shape[0]:
+            probs, _ = ops.mc_softmax_mean(logits, 1.0 / samples, want_preds=False)
+        else:
+            probs = torch.zeros((x.shape[0], layers[-1].in_out[1]), dtype=torch.float32, device=x.device)
+        dist.all_reduce(probs, op=dist.ReduceOp.SUM)
+        return torch.argmax(probs, dim=1), probs
+    probs, preds = ops.mc_softmax_mean(logits, 1.0 / samples)
+    return preds, probs
+
+
 class GraphedElbo:
     """One forward-only ELBO evaluation (all local MC samples: one launch per layer + the
     finalize launch) captured once as a hipGraph and replayed.  The Philox sample index has

@@ -455,6 +455,19 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
     return g_wmu, g_wrho, g_bmu, g_brho, gx
 
 
+def mc_softmax_mean(logits: torch.Tensor, scale: float, want_preds: bool = True):
+    """F3: probs[B,C] = scale * sum_s softmax(logits[s]), preds[B] = argmax (bnn_mc_softmax_mean)."""
+    lib = L.load()
+    require_device(logits)
+    lg = _f32c(logits, "logits")
+    S, B, Cc = lg.shape
+    probs = torch.empty((B, Cc), dtype=torch.float32, device=lg.device)
+    preds = torch.empty(B, dtype=torch.int64, device=lg.device) if want_preds else None
+    L.check(lib.bnn_mc_softmax_mean(lg.data_ptr(), S, B, Cc, float(scale), probs.data_ptr(), _ptr(preds), _stream()),
+            "bnn_mc_softmax_mean")
+    return probs, preds
+
+
 def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
     """Gradient of the per-sample summed NLL w.r.t. logits[S,B,C] scaled by g_nll[S] (bnn_nll_bwd)."""
     lib = L.load()

@@ -65,8 +65,14 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
-  const int k0 = blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64 + wave * 16;
+  // XCD-aware order: an XCD walks a few feature blocks (its slice of gz) across all k strips, so
+  // x and that slice stay in its own L2 instead of every L2 holding everything
+  const int nkb = (K + 63) >> 6;
+  int item;
+  if (!xcd_work_item(nkb * ((N + 63) >> 6), item)) return;
+  const int kblk = item % nkb, nblk = item / nkb;
+  const int k0 = kblk * 64;
+  const int n0 = nblk * 64 + wave * 16;
   if (n0 >= N) return;                                   // wave-uniform; no barriers below
   const int n = n0 + r;                                   // this lane's feature (D column / B-operand column)
   const bool n_ok = n < N;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
       sg[reg][i] = softplus(rh[reg][i]);
     }
   }
-  const bool do_bias = blockIdx.x == 0 && q == 0 && n_ok;   // one lane per feature
+  const bool do_bias = kblk == 0 && q == 0 && n_ok;         // one lane per feature
   float bmu = 0.f, brh = 0.f, bsg = 1.f, Gb = 0.f, Hb = 0.f;
   if (do_bias) {
     bmu = p.b_mu[n];
@@ -271,7 +277,8 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
     if (!(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
     k.inv_var_p = (float)(1.0 / ((double)a->prior.sigma_p * a->prior.sigma_p));
   }
-  const dim3 grid((a->in_features + 63) / 64, (a->out_features + 63) / 64), block(256);
+  const int nblocks = ((a->in_features + 63) / 64) * ((a->out_features + 63) / 64);
+  const dim3 grid((unsigned)(((nblocks + 7) / 8) * 8)), block(256);
   hipLaunchKernelGGL(bbb_bwd_weights_kernel, grid, block, 0, stream, k);
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;

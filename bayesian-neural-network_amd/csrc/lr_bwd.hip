@@ -100,8 +100,14 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
-  const int kb = blockIdx.x * 64 + (wave & 1) * 32;
-  const int nb = blockIdx.y * 64 + (wave >> 1) * 32;
+  // XCD-aware order: an XCD walks a few out-feature blocks (its slice of gz, h) across all k
+  // blocks, so x and that slice stay in its own L2
+  const int nkb = (K + 63) >> 6;
+  int item;
+  if (!xcd_work_item(nkb * ((N + 63) >> 6), item)) return;
+  const int kblk = item % nkb, nblk = item / nkb;
+  const int kb = kblk * 64 + (wave & 1) * 32;
+  const int nb = nblk * 64 + (wave >> 1) * 32;
   if (kb >= K || nb >= N) return;                        // wave-uniform; the kernel has no barriers
   const int ka = kb + 2 * c;                             // A operand: k pair of this lane (tile i <-> ka + i)
   const int na = nb + 2 * c;                             // B operand: n pair of this lane (tile j <-> na + j)
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
       gM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       gS[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  const bool do_bias = blockIdx.x == 0 && (wave & 1) == 0;
+  const bool do_bias = kblk == 0 && (wave & 1) == 0;
   const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   float Gb[2] = {0.f, 0.f}, Hb[2] = {0.f, 0.f};
 
@@ -124,9 +130,11 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
     const float* gzs = p.gz + (size_t)s * B * N;
     const float* hs = p.h + (size_t)s * B * N;
     float cs0 = 0.f, cs1 = 0.f;
-    constexpr int U = 8;                                  // batch-row quads in flight
-    for (int b0 = 0; b0 < B; b0 += 4 * U) {
-      float2 av[U], gv[U], hv[U];
+    constexpr int U = 8;                                  // batch-row quads per group
+    // two register buffers: the loads of group g + 1 are in flight while the 64 MFMAs of group g
+    // issue (clamped rows make a load past the batch harmless; its MFMAs are skipped)
+    float2 avA[U], gvA[U], hvA[U], avB[U], gvB[U], hvB[U];
+    auto load_group = [&](int b0, float2 (&av)[U], float2 (&gv)[U], float2 (&hv)[U]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int brow = b0 + 4 * u + q;
@@ -139,6 +147,8 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
           hv[u] = make_float2(0.f, 0.f);
         }
       }
+    };
+    auto mfma_group = [&](const float2 (&av)[U], const float2 (&gv)[U], const float2 (&hv)[U]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         cs0 += gv[u].x;
@@ -153,6 +163,15 @@ __global__ __launch_bounds__(256) void lr_bwd_weights_kernel(const LrBwdK p) {
         gS[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s, hv[u].y, gS[0][1], 0, 0, 0);
         gS[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s, hv[u].x, gS[1][0], 0, 0, 0);
         gS[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s, hv[u].y, gS[1][1], 0, 0, 0);
+      }
+    };
+    load_group(0, avA, gvA, hvA);
+    for (int b0 = 0; b0 < B; b0 += 8 * U) {
+      if (b0 + 4 * U < B) load_group(b0 + 4 * U, avB, gvB, hvB);
+      mfma_group(avA, gvA, hvA);
+      if (b0 + 4 * U < B) {
+        if (b0 + 8 * U < B) load_group(b0 + 8 * U, avA, gvA, hvA);
+        mfma_group(avB, gvB, hvB);
       }
     }
     if (do_bias) {                                        // per-sample column sums of gz (lane quads hold b = q mod 4)
@@ -398,7 +417,8 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   k.eps_mode = a->eps_mode; k.k0 = k0; k.k1 = k1; k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
   k.sample_counter = a->sample_counter;
   k.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
-  hipLaunchKernelGGL(lr_bwd_weights_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, stream, k);
+  const int wblocks = ((K + 63) / 64) * ((N + 63) / 64);
+  hipLaunchKernelGGL(lr_bwd_weights_kernel, dim3((unsigned)(((wblocks + 7) / 8) * 8)), dim3(256), 0, stream, k);
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) {

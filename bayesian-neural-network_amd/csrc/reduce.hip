@@ -226,6 +226,46 @@ __global__ void philox_normal_kernel(float* __restrict__ eps, uint32_t k0, uint3
   }
 }
 
+// ----------------------------------------------------------------------------- F3
+// MC-averaged class probabilities (reference classification/class_task.py:81-87): one wave per
+// batch row walks the samples; lanes stride over the classes.
+__global__ __launch_bounds__(256) void mc_softmax_mean_kernel(const float* __restrict__ logits, int S, int B, int C,
+                                                              float scale, float* __restrict__ probs,
+                                                              long long* __restrict__ preds) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B) return;                                    // wave-uniform
+  float* out = probs + (size_t)row * C;
+  for (int c = lane; c < C; c += 64) out[c] = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* lg = logits + ((size_t)s * B + row) * C;
+    float mx = -3.0e38f;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(lg[c] - mx);
+    se = wave_sum(se);
+    const float inv = scale / se;                          // out / test_samples (class_task.py:85)
+    for (int c = lane; c < C; c += 64) out[c] += expf(lg[c] - mx) * inv;   // lane c owns out[c]: no race
+  }
+  if (preds) {                                             // argmax, lowest index on ties
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = out[c];
+      if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) preds[row] = bi;
+  }
+}
+
 }  // namespace bnn
 
 using namespace bnn;
@@ -252,6 +292,16 @@ extern "C" int bnn_gauss_kl(const float* mu, const float* rho, int64_t n, float 
   hipLaunchKernelGGL(gauss_kl_final_kernel, dim3(1), dim3(256), 0, stream,
                      reinterpret_cast<const float4*>(workspace), nb, (long)n, sigma_p, out4);
   err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+extern "C" int bnn_mc_softmax_mean(const float* logits, int32_t n_samples, int32_t batch, int32_t classes, float scale,
+                                  float* probs, long long* preds, void* stream_) {
+  if (!logits || !probs) return BNN_ERR_NULL;
+  if (n_samples <= 0 || batch <= 0 || classes <= 0) return BNN_ERR_SHAPE;
+  hipLaunchKernelGGL(mc_softmax_mean_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), logits, n_samples, batch, classes, scale, probs, preds);
+  hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 

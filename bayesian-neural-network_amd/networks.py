@@ -244,6 +244,18 @@ class BayesianNetwork(nn.Module):
                 sp.m.log_prior, sp.m.log_variational_posterior = (st[0][0], st[1][0]) if training else (0, 0)
         return out[0]
 
+    def forward_mc(self, x, samples):
+        """Extension (not in the reference): the outputs of `samples` stochastic forward passes,
+        [samples, batch, classes], with the samples batched into one launch per layer — what
+        regression/reg_task.py:76-83 collects by calling net(x, sample=True) in a Python loop."""
+        return _engine.mc_forward(self._specs(), self._flat(x), int(samples))
+
+    def predict_mc(self, x, samples):
+        """Extension (not in the reference): classification/class_task.py:81-87 in one call —
+        (preds[batch], probs[batch, classes]) with probs = mean over `samples` stochastic passes of
+        softmax(net(x, sample=True)).  Same eps order as that loop when eps is injected."""
+        return _engine.mc_predict(self._specs(), self._flat(x), int(samples))
+
     def log_prior(self):
         return self.l1.log_prior + self.l2.log_prior + self.l3.log_prior
 

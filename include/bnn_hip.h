@@ -430,6 +430,16 @@ int bnn_nll_bwd(const float* logits, const void* target, const float* g_nll, flo
                 int32_t batch, int32_t classes, int32_t nll_mode, float nll_sigma, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * F3  bnn_mc_softmax_mean — the MC-averaged prediction of classification/class_task.py:81-87:
+ *     probs[b, :] = scale * sum_s softmax(logits[s, b, :]),   preds[b] = argmax_c probs[b, c]
+ * (scale = 1 / test_samples; a rank of a sharded job passes its local samples and the global
+ * scale, then sum-all-reduces probs).  logits fp32 [n_samples,batch,classes]; probs fp32
+ * [batch,classes]; preds int64[batch] or NULL.
+ * ---------------------------------------------------------------------------------- */
+int bnn_mc_softmax_mean(const float* logits, int32_t n_samples, int32_t batch, int32_t classes, float scale,
+                        float* probs, long long* preds, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into
  * eps[n_samples, rows, cols]: used by the backward pass to regenerate eps instead of
  * storing it, and by tests to check the frozen counter->element map.

@@ -566,3 +566,35 @@ def test_sums_ring_deposits_consecutive_evaluations(dev, lr, S):
     assert int(ev.ring[0].item()) == 6 % ring_len
     others = [j for j in range(n_ev) if j != me]
     assert bool((slab[:, others] == -7.0).all())             # only this evaluator's column was touched
+
+
+@pytest.mark.parametrize("lr", [False, True])
+def test_mc_predict_equals_the_reference_loop(dev, lr):
+    """F3: predict_mc (samples batched per launch + bnn_mc_softmax_mean) against the loop of
+    classification/class_task.py:81-87 run through the oracle on the same injected eps, and
+    against the drop-in's own per-call loop."""
+    bnn_hip.set_math("f32")
+    B, S = 128, 6
+    net, sd = build_net(dev, lr, (784, 1200, 10), "classification")
+    net.eval()
+    x, _ = synth.synth_batch("classification", B, 784, 10)
+    p = O.NetParams.from_state_dict(sd, "classification", 784, lr, O.Prior.from_init([1.0], False))
+    probs_ref = np.zeros((B, 10), dtype=np.float32)
+    for s in range(S):
+        eps = [t(a) for a in synth.synth_eps(p.eps_shapes(B), s)]
+        out = O.network_forward(p, t(x).view(B, -1), eps)[0]
+        probs_ref = probs_ref + (torch.softmax(out, dim=1) / S).numpy()
+    install_eps(net, B, S, lr)
+    preds, probs = net.predict_mc(t(x).to(dev), S)
+    close(probs, probs_ref, rtol=1e-4, atol=1e-7)            # probabilities: logits carry fp32 sum-order noise
+    assert np.array_equal(preds.cpu().numpy(), probs.cpu().numpy().argmax(1))
+    install_eps(net, B, S, lr)
+    loop = torch.zeros((B, 10), device=dev)
+    with torch.no_grad():
+        for _ in range(S):
+            loop = loop + torch.softmax(net(t(x).to(dev), sample=True), dim=1) / S
+    close(probs, loop.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    install_eps(net, B, S, lr)
+    outs = net.forward_mc(t(x).to(dev), S)                    # reg_task.py:76-83 style collection
+    assert tuple(outs.shape) == (S, B, 10)
+    close(torch.softmax(outs, dim=2).mean(0), probs_ref, rtol=1e-4, atol=1e-7)
