@@ -61,6 +61,10 @@ __device__ __forceinline__ float dlogp(const BwdK& p, float w) {
 
 __device__ __forceinline__ float sigmoidf(float r) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-r)); }
 
+// VEC: K % 4 == 0 and 16-byte aligned rows.  No load sits under per-lane control flow (a load in a
+// divergent branch gets its own basic block and the waits between blocks serialise the batch):
+// indices are clamped and the result selected afterwards.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -77,7 +81,6 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   const int n = n0 + r;                                   // this lane's feature (D column / B-operand column)
   const bool n_ok = n < N;
   const int gpr = (K + 3) >> 2;
-  const bool kvec = (K & 3) == 0;                         // rows of x are 16-byte aligned
 
   // Tile i (i = 0..3) of the 64-wide k strip holds the k's congruent to i mod 4: A row r of tile i is
   // k = k0 + 4 r + i, so ONE 16-byte load x[b][k0 + 4r .. +3] feeds all four tiles, and D register
@@ -92,15 +95,22 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   }
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
+    const int kq = k0 + q * 16 + reg * 4;                 // 4 consecutive k of feature n: one 16-byte access
+    const size_t rowoff = (size_t)min(n, N - 1) * K;
+    if (VEC) {
+      const float4 m4 = *reinterpret_cast<const float4*>(p.w_mu + rowoff + min(kq, K - 4));
+      const float4 r4 = *reinterpret_cast<const float4*>(p.w_rho + rowoff + min(kq, K - 4));
+      mu[reg][0] = m4.x; mu[reg][1] = m4.y; mu[reg][2] = m4.z; mu[reg][3] = m4.w;
+      rh[reg][0] = r4.x; rh[reg][1] = r4.y; rh[reg][2] = r4.z; rh[reg][3] = r4.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + q * 16 + reg * 4 + i;
-      const bool ok = n_ok && k < K;
-      const size_t off = (size_t)min(n, N - 1) * K + min(k, K - 1);
-      mu[reg][i] = ok ? p.w_mu[off] : 0.f;
-      rh[reg][i] = ok ? p.w_rho[off] : 0.f;
-      sg[reg][i] = softplus(rh[reg][i]);
+      for (int i = 0; i < 4; ++i) {
+        mu[reg][i] = p.w_mu[rowoff + min(kq + i, K - 1)];
+        rh[reg][i] = p.w_rho[rowoff + min(kq + i, K - 1)];
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[reg][i] = softplus(rh[reg][i]);
   }
   const bool do_bias = kblk == 0 && q == 0 && n_ok;         // one lane per feature
   float bmu = 0.f, brh = 0.f, bsg = 1.f, Gb = 0.f, Hb = 0.f;
@@ -130,18 +140,21 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int brow = b0 + 4 * u + q;
-        const bool b_ok = brow < B;
         const float* xr = xs + (size_t)min(brow, B - 1) * K;
-        if (kvec && ka + 3 < K) {
-          av[u] = *reinterpret_cast<const float4*>(xr + ka);
+        if (VEC) {
+          av[u] = *reinterpret_cast<const float4*>(xr + min(ka, K - 4));   // k >= K: rows of D that are never stored
         } else {
-          av[u].x = (ka + 0 < K) ? xr[ka + 0] : 0.f;
-          av[u].y = (ka + 1 < K) ? xr[ka + 1] : 0.f;
-          av[u].z = (ka + 2 < K) ? xr[ka + 2] : 0.f;
-          av[u].w = (ka + 3 < K) ? xr[ka + 3] : 0.f;
+          av[u].x = xr[min(ka + 0, K - 1)];
+          av[u].y = xr[min(ka + 1, K - 1)];
+          av[u].z = xr[min(ka + 2, K - 1)];
+          av[u].w = xr[min(ka + 3, K - 1)];
         }
-        bv[u] = (b_ok && n_ok) ? gzs[(size_t)brow * N + n] : 0.f;   // rows >= B contribute nothing
+        const float gzv = gzs[(size_t)min(brow, B - 1) * N + min(n, N - 1)];
+        bv[u] = brow < B ? gzv : 0.f;                                       // rows >= B contribute nothing
       }
+      // keep the batch a batch: without this the scheduler sinks every load next to its MFMAs to
+      // shorten live ranges, and the group costs U round trips instead of one
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         colsum += bv[u];
@@ -195,14 +208,22 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   // ---- g_mu = G;  g_rho = (H - cq / sigma) * sigmoid(rho)
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
+    const int kq = k0 + q * 16 + reg * 4;
+    if (!n_ok || kq >= K) continue;
+    float gr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + q * 16 + reg * 4 + i;
-      if (n_ok && k < K) {
-        const size_t off = (size_t)n * K + k;
-        p.g_wmu[off] = G[i][reg];
-        p.g_wrho[off] = (H[i][reg] - cq * __builtin_amdgcn_rcpf(sg[reg][i])) * sigmoidf(rh[reg][i]);
-      }
+    for (int i = 0; i < 4; ++i) gr[i] = (H[i][reg] - cq * __builtin_amdgcn_rcpf(sg[reg][i])) * sigmoidf(rh[reg][i]);
+    const size_t off = (size_t)n * K + kq;
+    if (VEC) {
+      *reinterpret_cast<float4*>(p.g_wmu + off) = make_float4(G[0][reg], G[1][reg], G[2][reg], G[3][reg]);
+      *reinterpret_cast<float4*>(p.g_wrho + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (kq + i < K) {
+          p.g_wmu[off + i] = G[i][reg];
+          p.g_wrho[off + i] = gr[i];
+        }
     }
   }
   if (do_bias) {
@@ -243,6 +264,9 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   if (!a->workspace || a->workspace_bytes < bnn_bbb_linear_bwd_workspace_bytes(a->n_samples, a->batch, a->out_features))
     return BNN_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(a->workspace) & 15) return BNN_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->w_mu) | reinterpret_cast<uintptr_t>(a->w_rho) |
+       reinterpret_cast<uintptr_t>(a->g_w_mu) | reinterpret_cast<uintptr_t>(a->g_w_rho)) & 15)
+    return BNN_ERR_ALIGN;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   float* gz = reinterpret_cast<float*>(a->workspace);
   const long cnt = (long)a->n_samples * a->batch * a->out_features;
@@ -279,7 +303,8 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   }
   const int nblocks = ((a->in_features + 63) / 64) * ((a->out_features + 63) / 64);
   const dim3 grid((unsigned)(((nblocks + 7) / 8) * 8)), block(256);
-  hipLaunchKernelGGL(bbb_bwd_weights_kernel, grid, block, 0, stream, k);
+  if ((a->in_features & 3) == 0) hipLaunchKernelGGL(bbb_bwd_weights_kernel<true>, grid, block, 0, stream, k);
+  else hipLaunchKernelGGL(bbb_bwd_weights_kernel<false>, grid, block, 0, stream, k);
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) return bnn_bbb_input_grad_(a, gz, stream_);
