@@ -185,12 +185,18 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
                                workspace=ws, out=out, w_sigma=ev.wsigma[1], split_scratch=ev.split[1])
     us = kernel_alone_us(launch, torch.cuda.current_stream())
     abytes = S_local * algorithmic_bytes_layer(dims[1], dims[1], batch, hid_b, hid_b)
+    note = "un-amortised 8 B/param/sample formula of SURVEY 8(d)"
+    if lr and ev.wfrag[1] is not None:
+        # prepared-operand form: the sample loop streams bf16 (M, sigma^2) = 4 B/param/sample plus bf16 x, x^2, y, y^2;
+        # the fp32 (M, rho) pass and the KL sums are hoisted into bnn_lr_prepare, once per evaluation (not in this kernel)
+        abytes = S_local * (dims[1] * dims[1] * 4 + batch * dims[1] * 4 + batch * dims[1] * 4)
+        note = "prepared bf16 operands: 4 B/param/sample + bf16 x, x^2, y, y^2 (the 8 B/param fp32 pass runs once per evaluation in bnn_lr_prepare)"
     achieved = abytes / (us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "kernel": ("lr_linear_fwd_kernel" if lr else "K1 bbb_linear_fwd") + f" layer 2 ({dims[1]}x{dims[1]})",
             "algorithmic_bytes_per_launch": abytes, "mc_samples_per_launch": S_local, "avg_launch_us": us,
             "note": "HIP events around back-to-back graph launches of this kernel on its stream (incl. the "
-                    "dependent-launch boundary); un-amortised 8 B/param/sample formula of SURVEY 8(d)"}
+                    "dependent-launch boundary); " + note}
 
 
 def cpu_baseline(dims, lr, batch, budget_s=15.0):
@@ -244,7 +250,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
     ap.add_argument("--allreduce-every", type=int, default=16,
                     help="N>1: ELBO scalars of this many consecutive evaluations share one all-reduce call")
@@ -258,6 +264,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the isolated launches of the dominant (layer-2) kernel: run under `rocprofv3 --kernel-trace "
+                         "--stats` to get a per-kernel average that is directly comparable with roofline.avg_launch_us")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,6 +306,11 @@ def main():
     slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
     evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay)
     assert evs[0].n_local == S_local
+    if args.roofline_only:
+        torch.cuda.synchronize()
+        roof = layer2_roofline(evs[0], net, dims, args.batch, S_local, lr, args.math)
+        print(json.dumps({"roofline": roof, "mc_samples_per_launch": S_local, "variant": args.variant}), flush=True)
+        return
     dt = run_steps(evs, args.steps, args.warmup, dist, slab, ar_every)
     if dist is not None and run_steps.last_flushed_half is not None:
         # every all-reduced row carries the GLOBAL sample count in its 4th word
