@@ -468,6 +468,23 @@ def mc_softmax_mean(logits: torch.Tensor, scale: float, want_preds: bool = True)
     return probs, preds
 
 
+def elbo_loss(a, b, nll, beta, total_samples: int, local_reparam: bool):
+    """bnn_elbo_loss: returns (out4 {loss, mean a, mean b, mean nll}, g_a, g_b, g_nll, g_kl3)."""
+    lib = L.load()
+    require_device(a, b, nll, beta)
+    S = nll.numel()
+    dev = nll.device
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    g_a = torch.empty(S, dtype=torch.float32, device=dev)
+    g_b = torch.empty(S, dtype=torch.float32, device=dev)
+    g_nll = torch.empty(S, dtype=torch.float32, device=dev)
+    g_kl3 = torch.empty(3, dtype=torch.float32, device=dev)
+    L.check(lib.bnn_elbo_loss(a.data_ptr(), _ptr(b), nll.data_ptr(), beta.data_ptr(), S, float(total_samples),
+                              int(local_reparam), out4.data_ptr(), g_a.data_ptr(), g_b.data_ptr(), g_nll.data_ptr(),
+                              g_kl3.data_ptr(), _stream()), "bnn_elbo_loss")
+    return out4, g_a, g_b, g_nll, g_kl3
+
+
 def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
     """Gradient of the per-sample summed NLL w.r.t. logits[S,B,C] scaled by g_nll[S] (bnn_nll_bwd)."""
     lib = L.load()

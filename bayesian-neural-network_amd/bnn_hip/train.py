@@ -8,11 +8,18 @@ buffers), beta (a 0-dim tensor: class_task.py:70 computes it on the host per min
 Philox sample counter (so every replay draws fresh eps and the backward kernels regenerate
 exactly the eps of that step's forward), Adam's step number and learning rate (FusedAdam
 capturable mode; StepLR keeps working through FusedAdam.sync_lr()).
+
+Two forms of the captured step: `autograd=True` records exactly what the eager loop runs
+(torch.autograd over the HIP-kernel Functions); the default chains the same kernels by hand —
+layer forwards, bnn_elbo_finalize, bnn_elbo_loss (loss + backward seeds), bnn_nll_bwd, the layer
+backwards, bnn_adam_step — without autograd's bookkeeping kernels (zero fills, gradient
+accumulation, per-layer scalar launches): about a third fewer microseconds per step.
 """
 from __future__ import annotations
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .optim import FusedAdam
 from .runtime import state, take_samples
@@ -20,7 +27,7 @@ from .runtime import state, take_samples
 
 class GraphedTrainStep:
     def __init__(self, net, optimizer: FusedAdam, x: torch.Tensor, y: torch.Tensor, samples: int, sigma: float = 1.0,
-                 warmup: int = 2):
+                 warmup: int = 2, autograd: bool = False):
         """`x`, `y`: an example minibatch (shape/dtype of every later one).  The warm-up steps run with
         the optimiser's learning rate forced to zero and its state restored afterwards, so building
         the graph leaves the model and the optimiser as they were."""
@@ -31,6 +38,7 @@ class GraphedTrainStep:
         if state.shard_samples:
             raise ops.BnnHipError("GraphedTrainStep: shard MC samples outside the captured step")
         self.net, self.opt, self.samples, self.sigma = net, optimizer, int(samples), float(sigma)
+        self.autograd = bool(autograd)
         dev = x.device
         self.x, self.y = x.clone(), y.clone()
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
@@ -80,7 +88,56 @@ class GraphedTrainStep:
         finally:
             state.device_counter = None
 
+    def _chain(self):
+        """zero_grad -> sample_elbo -> backward, as a hand-made chain of the C-ABI kernels (no autograd).
+        Leaves the gradients in p.grad and returns what sample_elbo* returns."""
+        net, S = self.net, self.samples
+        specs = net._specs()
+        lr = bool(net.local_reparam)
+        h = net._flat(self.x)
+        first = take_samples(S)
+        saved, wss = [], []
+        for sp in specs:
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            common = dict(n_samples=S, math_mode=state.math, relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
+                          seed=state.seed, layer_id=sp.layer_id, sample_offset=first, sample_counter=self.counter)
+            if sp.lr:
+                out = ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True, **common)
+            else:
+                out = ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, **common)
+            saved.append((h, out["y"], out.get("v"), p))
+            wss.append(out["workspace"])
+            h = out["y"]
+        fin = ops.elbo_finalize(workspaces=wss, layer_in=[sp.in_out[0] for sp in specs],
+                                layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr, prior=specs[0].m._prior_spec,
+                                n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma)
+        out4, g_a, g_b, g_nll, g_kl3 = ops.elbo_loss(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
+                                                     fin["nll"], self.beta, S, lr)
+        g = ops.nll_bwd(h, self.y, g_nll, net.mode, self.sigma)
+        for i in reversed(range(len(specs))):
+            sp = specs[i]
+            xin, y, v, p = saved[i]
+            kw = dict(n_samples=S, relu=sp.relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
+                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0)
+            if sp.lr:
+                grads = ops.lr_linear_bwd(xin, g, y if sp.relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
+                                          **kw)
+            else:
+                grads = ops.bbb_linear_bwd(xin, g, y if sp.relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
+                                           g_log_prior=g_a, g_log_q=g_b, **kw)
+            sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
+            g = grads[4]
+        if lr:
+            return out4[0:1], out4[1], out4[3:4]
+        return out4[0:1], out4[1], out4[2], out4[3:4]
+
     def _one_step(self):
+        if not self.autograd:
+            with torch.no_grad():
+                out = self._chain()
+                self.opt.step()
+                self.counter.add_(self.samples)
+            return out
         state.device_counter = self.counter
         try:
             self.opt.zero_grad(set_to_none=True)

@@ -115,8 +115,9 @@ def test_nll_backward_kernel_matches_autograd(mode):
     assert float((got - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
 
 
+@pytest.mark.parametrize("autograd", [False, True])
 @pytest.mark.parametrize("local_reparam", [False, True])
-def test_graphed_train_step_equals_eager_steps(local_reparam):
+def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
     """train.GraphedTrainStep (zero_grad -> sample_elbo -> backward -> Adam in one hipGraph, device
     sample counter / Adam step / beta) reproduces the eager loop of class_task.py:66-79 step by
     step: same parameters after every step (same Philox sample indices, fp32 math)."""
@@ -141,7 +142,7 @@ def test_graphed_train_step_equals_eager_steps(local_reparam):
     sched_a = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5)
     bnn_hip.manual_seed(99, counter=500)
     before = {k: v.clone() for k, v in net_b.state_dict().items()}
-    graphed = GraphedTrainStep(net_b, ob, xs[0], ys[0], S)
+    graphed = GraphedTrainStep(net_b, ob, xs[0], ys[0], S, autograd=autograd)
     for k, v in net_b.state_dict().items():                    # building the graph left the model untouched
         assert torch.equal(v, before[k]), k
     assert ob.device_step() == 0

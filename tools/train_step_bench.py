@@ -15,7 +15,7 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 rows = []
 for lr in (False, True):
     for math_mode in ("bf16", "f32"):
-        for form in ("graph", "eager+FusedAdam", "eager+torch.Adam", "tensor-op backward"):
+        for form in ("graph", "graph(autograd)", "eager+FusedAdam", "eager+torch.Adam", "tensor-op backward"):
             if only and only != form:
                 continue
             bnn_hip.set_math(math_mode); Fn.HIP_BACKWARD = form != "tensor-op backward"
@@ -24,9 +24,9 @@ for lr in (False, True):
             net = networks.BayesianNetwork(mp).to(dev).train()
             x, y = synth.synth_batch("classification", 128, 784, 10)
             x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
-            if form == "graph":
+            if form.startswith("graph"):
                 opt = FusedAdam(net.parameters(), lr=1e-4, capturable=True)
-                g = GraphedTrainStep(net, opt, x, y, S)
+                g = GraphedTrainStep(net, opt, x, y, S, autograd=form != "graph")
                 step = lambda: g.step(x, y, 0.5)
             else:
                 opt = (FusedAdam if form == "eager+FusedAdam" else torch.optim.Adam)(net.parameters(), lr=1e-4)
@@ -36,7 +36,7 @@ for lr in (False, True):
                     out[0].backward(); opt.step()
             for _ in range(5): step()
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            n = 200 if form == "graph" else 30
+            n = 200 if form.startswith("graph") else 30
             for _ in range(n): step()
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
             rows.append(dict(variant="LR" if lr else "BBB", mc_samples=S, math=math_mode, form=form, ms_per_step=dt * 1e3))
