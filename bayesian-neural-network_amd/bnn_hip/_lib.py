@@ -177,7 +177,7 @@ def load():
     lib.bnn_mc_softmax_mean.restype = C.c_int
     lib.bnn_mc_softmax_mean.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bnn_elbo_loss.restype = C.c_int
-    lib.bnn_elbo_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32,
+    lib.bnn_elbo_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bnn_nll_bwd.restype = C.c_int
     lib.bnn_nll_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -364,9 +364,19 @@ def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None):
     return out, workspace
 
 
+def _grad_outputs(out, w_mu, w_rho, b_mu, b_rho):
+    """Gradient destinations: fresh tensors, or the caller's (e.g. views of one flat all-reduce bucket)."""
+    if out is None:
+        return torch.empty_like(w_mu), torch.empty_like(w_rho), torch.empty_like(b_mu), torch.empty_like(b_rho)
+    for o, p_ in zip(out, (w_mu, w_rho, b_mu, b_rho)):
+        if o.dtype != torch.float32 or tuple(o.shape) != tuple(p_.shape) or not o.is_contiguous() or o.device != p_.device:
+            raise BnnHipError("gradient outputs must be contiguous float32 tensors shaped like their parameters")
+    return tuple(out)
+
+
 def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
                    eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
-                   g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None):
+                   g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None, out=None):
     """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
     (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
     lib = L.load()
@@ -397,8 +407,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     glp = _f32c(g_log_prior, "g_log_prior") if g_log_prior is not None else None
     glq = _f32c(g_log_q, "g_log_q") if g_log_q is not None else None
     a.g_log_prior, a.g_log_q = _ptr(glp), _ptr(glq)
-    g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
-    g_bmu, g_brho = torch.empty_like(b_mu), torch.empty_like(b_rho)
+    g_wmu, g_wrho, g_bmu, g_brho = _grad_outputs(out, w_mu, w_rho, b_mu, b_rho)
     gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
     a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
     a.g_x = _ptr(gx)
@@ -411,7 +420,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
 
 def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
                   eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
-                  want_gx: bool = True, sample_counter=None):
+                  want_gx: bool = True, sample_counter=None, out=None):
     """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
     saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
     Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
@@ -442,8 +451,7 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
     a.sigma_p = float(sigma_p)
     gk = _f32c(g_kl, "g_kl") if g_kl is not None else None
     a.g_kl = _ptr(gk)
-    g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
-    g_bmu, g_brho = torch.empty_like(b_mu), torch.empty_like(b_rho)
+    g_wmu, g_wrho, g_bmu, g_brho = _grad_outputs(out, w_mu, w_rho, b_mu, b_rho)
     gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
     a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
     a.g_x = _ptr(gx)
@@ -468,7 +476,7 @@ def mc_softmax_mean(logits: torch.Tensor, scale: float, want_preds: bool = True)
     return probs, preds
 
 
-def elbo_loss(a, b, nll, beta, total_samples: int, local_reparam: bool):
+def elbo_loss(a, b, nll, beta, total_samples: int, local_reparam: bool, grad_scale: float = 1.0):
     """bnn_elbo_loss: returns (out4 {loss, mean a, mean b, mean nll}, g_a, g_b, g_nll, g_kl3)."""
     lib = L.load()
     require_device(a, b, nll, beta)
@@ -480,7 +488,7 @@ def elbo_loss(a, b, nll, beta, total_samples: int, local_reparam: bool):
     g_nll = torch.empty(S, dtype=torch.float32, device=dev)
     g_kl3 = torch.empty(3, dtype=torch.float32, device=dev)
     L.check(lib.bnn_elbo_loss(a.data_ptr(), _ptr(b), nll.data_ptr(), beta.data_ptr(), S, float(total_samples),
-                              int(local_reparam), out4.data_ptr(), g_a.data_ptr(), g_b.data_ptr(), g_nll.data_ptr(),
+                              float(grad_scale), int(local_reparam), out4.data_ptr(), g_a.data_ptr(), g_b.data_ptr(), g_nll.data_ptr(),
                               g_kl3.data_ptr(), _stream()), "bnn_elbo_loss")
     return out4, g_a, g_b, g_nll, g_kl3
 

@@ -27,10 +27,17 @@ from .runtime import state, take_samples
 
 class GraphedTrainStep:
     def __init__(self, net, optimizer: FusedAdam, x: torch.Tensor, y: torch.Tensor, samples: int, sigma: float = 1.0,
-                 warmup: int = 2, autograd: bool = False):
+                 warmup: int = 2, autograd: bool = False, data_parallel: bool = False):
         """`x`, `y`: an example minibatch (shape/dtype of every later one).  The warm-up steps run with
         the optimiser's learning rate forced to zero and its state restored afterwards, so building
-        the graph leaves the model and the optimiser as they were."""
+        the graph leaves the model and the optimiser as they were.
+
+        `data_parallel`: every rank of the default torch.distributed group (RCCL on GPUs) holds a replica
+        and feeds its own minibatch; the backward kernels write all gradients into ONE flat fp32
+        bucket (2 x 2.4 M floats at the MNIST config) that is sum-all-reduced in a single collective
+        between two captured graphs (forward+backward | Adam); the backward seeds carry the 1/ranks,
+        rank r draws MC-sample indices [first + r*S, first + (r+1)*S) of every step.  Replicas must
+        start identical (`broadcast_parameters`)."""
         if not all(g.get("capturable") for g in optimizer.param_groups):
             raise ops.BnnHipError("GraphedTrainStep needs FusedAdam(capturable=True)")
         if state.host_eps or any(sp.m._eps_stubbed() for sp in net._specs()):
@@ -39,10 +46,25 @@ class GraphedTrainStep:
             raise ops.BnnHipError("GraphedTrainStep: shard MC samples outside the captured step")
         self.net, self.opt, self.samples, self.sigma = net, optimizer, int(samples), float(sigma)
         self.autograd = bool(autograd)
+        self.rank, self.world = 0, 1
+        if data_parallel:
+            import torch.distributed as dist
+            if self.autograd:
+                raise ops.BnnHipError("data_parallel uses the kernel chain (autograd=False)")
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.dp = bool(data_parallel)
         dev = x.device
         self.x, self.y = x.clone(), y.clone()
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
+        self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
+        offs, tot = [], 0
+        for p in self.params:
+            offs.append(tot)
+            tot += (p.numel() + 63) // 64 * 64
+        self.bucket = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.grad_views = [self.bucket[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self._elbo = net.sample_elbo_lr if net.local_reparam else net.sample_elbo
         self.first = take_samples(0)
 
@@ -79,11 +101,20 @@ class GraphedTrainStep:
 
         # ---- capture
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_update = None
         state.device_counter = self.counter
         try:
             take_before = state.counter
-            with torch.cuda.graph(self.graph):
-                self.out = self._one_step()
+            if self.dp:
+                with torch.cuda.graph(self.graph):
+                    with torch.no_grad():
+                        self.out = self._chain()
+                self.graph_update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+                    self._update()
+            else:
+                with torch.cuda.graph(self.graph):
+                    self.out = self._one_step()
             state.counter = take_before              # capture ran nothing: the indices are still unused
         finally:
             state.device_counter = None
@@ -95,7 +126,7 @@ class GraphedTrainStep:
         specs = net._specs()
         lr = bool(net.local_reparam)
         h = net._flat(self.x)
-        first = take_samples(S)
+        first = take_samples(S * self.world) + self.rank * S
         saved, wss = [], []
         for sp in specs:
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
@@ -112,13 +143,13 @@ class GraphedTrainStep:
                                 layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr, prior=specs[0].m._prior_spec,
                                 n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma)
         out4, g_a, g_b, g_nll, g_kl3 = ops.elbo_loss(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
-                                                     fin["nll"], self.beta, S, lr)
+                                                     fin["nll"], self.beta, S, lr, grad_scale=1.0 / self.world)
         g = ops.nll_bwd(h, self.y, g_nll, net.mode, self.sigma)
         for i in reversed(range(len(specs))):
             sp = specs[i]
             xin, y, v, p = saved[i]
             kw = dict(n_samples=S, relu=sp.relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
-                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0)
+                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4])
             if sp.lr:
                 grads = ops.lr_linear_bwd(xin, g, y if sp.relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
                                           **kw)
@@ -131,12 +162,22 @@ class GraphedTrainStep:
             return out4[0:1], out4[1], out4[3:4]
         return out4[0:1], out4[1], out4[2], out4[3:4]
 
+    def _update(self):
+        with torch.no_grad():
+            self.opt.step()
+            self.counter.add_(self.samples * self.world)
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)      # seeds already carry 1 / ranks
+
     def _one_step(self):
         if not self.autograd:
             with torch.no_grad():
                 out = self._chain()
-                self.opt.step()
-                self.counter.add_(self.samples)
+            if self.dp:
+                self._allreduce()
+            self._update()
             return out
         state.device_counter = self.counter
         try:
@@ -157,5 +198,16 @@ class GraphedTrainStep:
         self.beta.fill_(float(beta))
         self.opt.sync_lr()
         self.graph.replay()
-        take_samples(self.samples)
+        if self.dp:
+            self._allreduce()
+            self.graph_update.replay()
+        take_samples(self.samples * self.world)
         return self.out
+
+
+def broadcast_parameters(net, src: int = 0):
+    """Make every rank's replica identical to rank `src`'s (call once before data-parallel training)."""
+    import torch.distributed as dist
+    with torch.no_grad():
+        for p in net.parameters():
+            dist.broadcast(p, src=src)

@@ -230,7 +230,7 @@ __global__ void philox_normal_kernel(float* __restrict__ eps, uint32_t k0, uint3
 // scalars, and the seeds of the backward chain: d loss / d log p[s] = -beta/S, d loss / d log q[s] =
 // beta/S, d loss / d nll[s] = 1/S; LR: d loss / d (a layer's KL) = beta.  One block.
 __global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nll,
-                                 const float* __restrict__ beta_p, int S, float total, int local_reparam,
+                                 const float* __restrict__ beta_p, int S, float total, float grad_scale, int local_reparam,
                                  float* __restrict__ out4, float* __restrict__ g_a, float* __restrict__ g_b,
                                  float* __restrict__ g_nll, float* __restrict__ g_kl3) {
   __shared__ double scratch[16];
@@ -244,7 +244,7 @@ __global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __res
   y = block_sum(y, scratch);
   z = block_sum(z, scratch);
   const float beta = *beta_p;
-  const float inv = 1.0f / total;
+  const float inv = grad_scale / total;                 // grad_scale = 1 / (data-parallel ranks): the seeds of a SUM all-reduce
   for (int i = threadIdx.x; i < S; i += blockDim.x) {
     if (g_a) g_a[i] = local_reparam ? 0.f : -beta * inv;
     if (g_b) g_b[i] = beta * inv;
@@ -257,7 +257,7 @@ __global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __res
     out4[1] = am;
     out4[2] = bm;
     out4[3] = nm;
-    if (g_kl3) { g_kl3[0] = beta; g_kl3[1] = 0.f; g_kl3[2] = 0.f; }
+    if (g_kl3) { g_kl3[0] = beta * grad_scale; g_kl3[1] = 0.f; g_kl3[2] = 0.f; }
   }
 }
 
@@ -331,13 +331,13 @@ extern "C" int bnn_gauss_kl(const float* mu, const float* rho, int64_t n, float 
 }
 
 extern "C" int bnn_elbo_loss(const float* a, const float* b, const float* nll, const float* beta, int32_t n_samples,
-                             float total_samples, int32_t local_reparam, float* out4, float* g_a, float* g_b, float* g_nll,
-                             float* g_kl3, void* stream_) {
+                             float total_samples, float grad_scale, int32_t local_reparam, float* out4, float* g_a, float* g_b,
+                             float* g_nll, float* g_kl3, void* stream_) {
   if (!a || !nll || !beta || !out4) return BNN_ERR_NULL;
   if (!local_reparam && !b) return BNN_ERR_NULL;
   if (n_samples <= 0 || !(total_samples > 0.f)) return BNN_ERR_SHAPE;
   hipLaunchKernelGGL(elbo_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a, b, nll, beta,
-                     n_samples, total_samples, local_reparam, out4, g_a, g_b, g_nll, g_kl3);
+                     n_samples, total_samples, grad_scale, local_reparam, out4, g_a, g_b, g_nll, g_kl3);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

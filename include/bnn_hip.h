@@ -425,10 +425,11 @@ int bnn_adam_step(const bnn_adam_args* args, void* stream);
  * :222-224 (LR: a = KL per sample, b = NULL) from per-sample scalars and a DEVICE beta, with
  * total_samples = S of the whole job:  out4 = {loss, mean a, mean b, mean nll}, and the seeds of the
  * backward chain g_a[s] = -beta/S (0 for LR), g_b[s] = beta/S, g_nll[s] = 1/S, g_kl3 = {beta, 0, 0}
- * (what bnn_*_linear_bwd / bnn_nll_bwd take).  Any seed pointer may be NULL. */
+ * (what bnn_*_linear_bwd / bnn_nll_bwd take), all times grad_scale (1, or 1 / ranks when the
+ * gradients of data-parallel minibatches are then SUM-all-reduced).  Any seed pointer may be NULL. */
 int bnn_elbo_loss(const float* a, const float* b, const float* nll, const float* beta, int32_t n_samples,
-                  float total_samples, int32_t local_reparam, float* out4, float* g_a, float* g_b, float* g_nll,
-                  float* g_kl3, void* stream);
+                  float total_samples, float grad_scale, int32_t local_reparam, float* out4, float* g_a, float* g_b,
+                  float* g_nll, float* g_kl3, void* stream);
 
 /* bnn_nll_bwd — gradient of the summed NLL (networks.py:183-190) w.r.t. the logits of every MC
  * sample, scaled by g_nll[s] (device float[n_samples]):

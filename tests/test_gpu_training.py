@@ -163,3 +163,82 @@ def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
             assert float((got - want.detach()).abs().max()) <= 1e-5 * (float(want.detach().abs().max()) + 1e-6), idx
     for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), k
+
+
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, r"{repo}"); sys.path.insert(0, os.path.join(r"{repo}", "bayesian-neural-network_amd"))
+import numpy as np, torch, torch.distributed as dist
+import bnn_hip, networks
+from bnn_hip.optim import FusedAdam
+from bnn_hip.train import GraphedTrainStep, broadcast_parameters
+rank, world, lr_flag = int(sys.argv[1]), int(sys.argv[2]), sys.argv[4] == "lr"
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks on cuda:0 (one-GPU box): gloo, not RCCL
+dev = torch.device("cuda:0")
+bnn_hip.set_math("f32")
+mp = dict(input_shape=784, classes=10, batch_size=32, hidden_units=64, mode="classification", mu_init=[-0.2, 0.2],
+          rho_init=[-5, -4], prior_init=[1.0], mixture_prior=False, local_reparam=lr_flag)
+torch.manual_seed(100 + rank)                                    # replicas start DIFFERENT ...
+net = networks.BayesianNetwork(mp).to(dev).train()
+broadcast_parameters(net)                                        # ... and are made identical here
+init = {{k: v.clone() for k, v in net.state_dict().items()}}
+rs = np.random.RandomState(7)
+T, S, M = 3, 2, 4
+xs = [[torch.from_numpy(rs.uniform(0, 1, (32, 1, 28, 28)).astype(np.float32)).to(dev) for _ in range(T)] for _ in range(world)]
+ys = [[torch.from_numpy(rs.randint(0, 10, 32)).to(dev) for _ in range(T)] for _ in range(world)]
+beta = lambda idx: 2 ** (M - (idx + 1)) / (2 ** M - 1)
+bnn_hip.manual_seed(5, counter=1000)
+opt = FusedAdam(net.parameters(), lr=1e-3, capturable=True)
+step = GraphedTrainStep(net, opt, xs[rank][0], ys[rank][0], S, data_parallel=True)
+for t in range(T):
+    step.step(xs[rank][t], ys[rank][t], beta(t))
+torch.cuda.synchronize()
+# every replica ends identical
+flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+other = flat.clone()
+dist.all_reduce(other, op=dist.ReduceOp.SUM)
+assert float((other - world * flat).abs().max()) <= 1e-6 * float(flat.abs().max()), "replicas diverged"
+if rank == 0:
+    # single-process reference: average the eager gradients of the ranks' minibatches at the very same
+    # Philox sample indices, one Adam step per round
+    ref = networks.BayesianNetwork(mp).to(dev).train()
+    ref.load_state_dict(init)
+    ropt = FusedAdam(ref.parameters(), lr=1e-3)
+    elbo = ref.sample_elbo_lr if lr_flag else ref.sample_elbo
+    for t in range(T):
+        acc = [torch.zeros_like(p) for p in ref.parameters()]
+        for r in range(world):
+            bnn_hip.manual_seed(5, counter=1000 + t * S * world + r * S)
+            ropt.zero_grad()
+            elbo(xs[r][t], ys[r][t], beta(t), S)[0].backward()
+            for a, p in zip(acc, ref.parameters()):
+                a += p.grad / world
+        for a, p in zip(acc, ref.parameters()):
+            p.grad = a
+        ropt.step()
+    for (k, a), (_, b) in zip(ref.state_dict().items(), net.state_dict().items()):
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * float(a.abs().max()), (k, err)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("variant", ["bbb", "lr"])
+def test_data_parallel_train_step_two_ranks(tmp_path, variant):
+    """F2, second half: GraphedTrainStep(data_parallel=True) on 2 ranks (both on this one GPU, so
+    gloo instead of RCCL): one flat gradient bucket, one sum all-reduce per step between the two
+    captured graphs; replicas stay identical and match a single-process run that averages the
+    ranks' gradients."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER.format(repo=repo))
+    port = str(31500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, variant], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
