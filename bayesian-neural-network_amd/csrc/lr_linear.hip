@@ -818,6 +818,14 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   while ((ssteps + spw - 1) / spw > 8) ++spw;
   int nw = (ssteps + spw - 1) / spw;
   nw = nw < 1 ? 1 : nw;
+  {
+    // the epilogue gives every thread at most 2 output items (batch row x 4 features): a short k range
+    // must not leave the block with fewer threads than that needs (extra waves own no k-step and
+    // contribute zero slabs)
+    const int mt = a->batch >= 128 ? 8 : (a->batch + 15) / 16;
+    const int need = (mt * 16 * (F / 4) + 127) / 128;
+    if (nw < need) nw = need;
+  }
   const long total = (long)((N + F - 1) / F) * a->n_samples * mbs;
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
   const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);

@@ -598,3 +598,32 @@ def test_mc_predict_equals_the_reference_loop(dev, lr):
     outs = net.forward_mc(t(x).to(dev), S)                    # reg_task.py:76-83 style collection
     assert tuple(outs.shape) == (S, B, 10)
     close(torch.softmax(outs, dim=2).mean(0), probs_ref, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(1, 50, 128, 1), (4, 50, 128, 2), (8, 64, 128, 1), (64, 1200, 128, 1), (33, 7, 100, 3), (1, 1, 128, 1),
+                                   (50, 1, 128, 1), (1200, 10, 128, 1), (784, 1200, 300, 1), (16, 16, 513, 1), (128, 600, 64, 2),
+                                   (96, 1200, 16, 1), (200, 40, 129, 1)])
+def test_launch_geometry_over_odd_shapes(dev, shape):
+    """Tile / wave / block decomposition of K1 and K3 over shapes far from the benchmark's: with eps
+    switched off y = x W^T + b_mu (BBB) or x M + b_mu (LR) exactly, so any output item a launch
+    geometry fails to cover shows up (a short k range once left the LR block with fewer threads than
+    output items)."""
+    K, N, B, S = shape
+    gen = torch.Generator(device="cpu").manual_seed(K * 7919 + N)
+    x = torch.randn(B, K, generator=gen).to(dev)
+    for lr in (False, True):
+        for mm, tol in ((L.MATH_F32, 2e-5), (L.MATH_BF16, 2e-2)):
+            wm = (torch.randn((K, N) if lr else (N, K), generator=gen) * 0.3).to(dev)
+            wr = torch.full_like(wm, -3.0)
+            bm = torch.randn(N, generator=gen).to(dev)
+            br = torch.full((N,), -3.0, device=dev)
+            if lr:
+                out = ops.lr_linear_fwd(x, wm, wr, bm, br, n_samples=S, sigma_p=1.0, math_mode=mm, relu=False,
+                                        y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_kl=True)
+                ref = x @ wm + bm
+            else:
+                out = ops.bbb_linear_fwd(x, wm, wr, bm, br, n_samples=S, prior=ops.PriorSpec(False, 1.0), math_mode=mm,
+                                         relu=False, y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=True)
+                ref = x @ wm.t() + bm
+            err = float((out["y"] - ref.unsqueeze(0)).abs().max())
+            assert err <= tol * (float(ref.abs().max()) + 1e-6), (shape, "LR" if lr else "BBB", mm, err)
