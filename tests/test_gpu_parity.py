@@ -617,13 +617,61 @@ def test_launch_geometry_over_odd_shapes(dev, shape):
             wr = torch.full_like(wm, -3.0)
             bm = torch.randn(N, generator=gen).to(dev)
             br = torch.full((N,), -3.0, device=dev)
+            sig_w, sig_b = torch.log1p(torch.exp(wr.double())), torch.log1p(torch.exp(br.double()))
+            cnt = wm.numel() + bm.numel()
+            c0 = -0.9189385332046727
             if lr:
-                out = ops.lr_linear_fwd(x, wm, wr, bm, br, n_samples=S, sigma_p=1.0, math_mode=mm, relu=False,
-                                        y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_kl=True)
+                out = ops.lr_linear_fwd(x, wm, wr, bm, br, n_samples=S, sigma_p=0.9, math_mode=mm, relu=False,
+                                        y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_kl=True, want_scalars=True)
                 ref = x @ wm + bm
+                sp = 0.9                                                   # closed-form KL (networks.py:109-114)
+                kl = sum(0.5 * (2 * torch.log(torch.tensor(sp, dtype=torch.float64) / sg) - 1 + (sg / sp) ** 2 + (mu.double() / sp) ** 2).sum()
+                         for mu, sg in ((wm, sig_w), (bm, sig_b)))
+                close(out["kl3"][0], float(kl), rtol=2e-5)
             else:
-                out = ops.bbb_linear_fwd(x, wm, wr, bm, br, n_samples=S, prior=ops.PriorSpec(False, 1.0), math_mode=mm,
-                                         relu=False, y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=True)
+                out = ops.bbb_linear_fwd(x, wm, wr, bm, br, n_samples=S, prior=ops.PriorSpec(False, 0.9), math_mode=mm,
+                                         relu=False, y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=True, want_scalars=True)
                 ref = x @ wm.t() + bm
+                # eps = 0: w = mu, so log q = count * c0 - sum log sigma and log p is the Gaussian at mu
+                lq = cnt * c0 - float(torch.log(sig_w).sum() + torch.log(sig_b).sum())
+                lp = cnt * (c0 - math.log(0.9)) - float((wm.double() ** 2).sum() + (bm.double() ** 2).sum()) / (2 * 0.81)
+                close(out["log_q"], np.full(S, lq), rtol=2e-5)
+                close(out["log_prior"], np.full(S, lp), rtol=2e-5)
             err = float((out["y"] - ref.unsqueeze(0)).abs().max())
             assert err <= tol * (float(ref.abs().max()) + 1e-6), (shape, "LR" if lr else "BBB", mm, err)
+
+
+@pytest.mark.parametrize("shape", [(64, 100, 128, 12), (200, 1000, 100, 8), (784, 1200, 128, 24), (1200, 72, 130, 9), (8, 16, 16, 40),
+                                   (96, 200, 257, 5)])
+def test_throughput_forms_over_odd_shapes(dev, monkeypatch, shape):
+    """The LDS-DMA block-GEMM forms (K1b, K3b with and without prepared fragments), forced on at
+    shapes that are not multiples of their tiles: with eps off y must equal the plain product."""
+    K, N, B, S = shape
+    monkeypatch.setenv("BNN_HIP_BBB_GEMM", "1")
+    monkeypatch.setenv("BNN_HIP_LR_GEMM", "1")
+    gen = torch.Generator(device="cpu").manual_seed(K * 31 + N)
+    x = torch.randn(S, B, K, generator=gen).to(dev)
+    x16 = x.to(torch.bfloat16)
+    xf = x16.float()
+    for lr in (False, True):
+        wm = (torch.randn((K, N) if lr else (N, K), generator=gen) * 0.3).to(dev)
+        wr = torch.full_like(wm, -3.0)
+        bm = torch.randn(N, generator=gen).to(dev)
+        br = torch.full((N,), -3.0, device=dev)
+        if lr:
+            ref = torch.matmul(xf, wm.to(torch.bfloat16).float()) + bm
+            for prep in (False, True):
+                wfrag, ws = ops.lr_prepare(wm, wr, bm, br) if prep else (None, None)
+                out = ops.lr_linear_fwd(x16, wm, wr, bm, br, n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=False,
+                                        y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_kl=True, x_sq=(x16 * x16),
+                                        w_frag=wfrag, workspace=ws)
+                err = float((out["y"] - ref).abs().max())
+                assert err <= 3e-3 * (float(ref.abs().max()) + 1e-6), (shape, "LR", prep, err)
+        else:
+            ref = torch.matmul(xf, wm.to(torch.bfloat16).float().t()) + bm
+            for hoist in (False, True):
+                out = ops.bbb_linear_fwd(x16, wm, wr, bm, br, n_samples=S, prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_BF16,
+                                         relu=False, y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=True,
+                                         w_sigma=ops.softplus(wr) if hoist else None)
+                err = float((out["y"] - ref).abs().max())
+                assert err <= 3e-3 * (float(ref.abs().max()) + 1e-6), (shape, "BBB", hoist, err)
