@@ -27,6 +27,16 @@ import os
 import sys
 import time
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With 4, a
+# fourth evaluator stream shares a queue with another one and the one-sample rate drops by a third;
+# with 5 the null stream and four evaluator streams map one-to-one.  More than four busy queues is
+# slower again (tools/stream_sweep.py).  Read by the runtime at its first HIP call.
+# With N > 1 ranks RCCL's own stream joins in and the cross-stream waits of the all-reduce hand-off make
+# every mapping but the plain one (4 queues, 3 evaluator streams) slow, so the job keeps the defaults.
+_MULTI = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BNN_BENCH_FORCE_DIST", "0") == "1"
+if not _MULTI:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "bayesian-neural-network_amd"))
 sys.path.insert(0, REPO)
@@ -250,8 +260,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each); "
+                         "default 4 on one GPU, 3 per rank in a multi-rank job (see GPU_MAX_HW_QUEUES above)")
     ap.add_argument("--allreduce-every", type=int, default=16,
                     help="N>1: ELBO scalars of this many consecutive evaluations share one all-reduce call")
     ap.add_argument("--evals-per-graph", type=int, default=4,
@@ -299,7 +310,7 @@ def main():
     # the wide stack has no task attached in BASELINE: Gaussian NLL over its 4096 outputs
     net, x, y = build_net(dims, lr, args.batch, dev, "regression" if args.net == "wide" else "classification")
     S_local, S_global = args.samples, args.samples * world
-    nstr = max(1, args.streams)
+    nstr = args.streams if args.streams > 0 else (3 if _MULTI else 4)
     ar_every = max(1, args.allreduce_every)
     per_replay = math.gcd(max(1, args.evals_per_graph), args.steps, args.warmup or args.steps,
                           *((ar_every,) if dist is not None else ()))
@@ -334,6 +345,7 @@ def main():
                                f"flight per GPU, Gaussian prior, on-chip Philox eps",
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
+                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "evaluations_per_graph_launch": per_replay,
                    "parallelism": (f"mc-sample-shard x{world}; RCCL sum all-reduce of the 4 ELBO scalars of every evaluation, "
                                    f"{args.allreduce_every * nstr} evaluations per call, asynchronous") if world > 1 else "single GPU"},
