@@ -27,16 +27,6 @@ import os
 import sys
 import time
 
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With 4, a
-# fourth evaluator stream shares a queue with another one and the one-sample rate drops by a third;
-# with 5 the null stream and four evaluator streams map one-to-one.  More than four busy queues is
-# slower again (tools/stream_sweep.py).  Read by the runtime at its first HIP call.
-# With N > 1 ranks RCCL's own stream joins in and the cross-stream waits of the all-reduce hand-off make
-# every mapping but the plain one (4 queues, 3 evaluator streams) slow, so the job keeps the defaults.
-_MULTI = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BNN_BENCH_FORCE_DIST", "0") == "1"
-if not _MULTI:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "bayesian-neural-network_amd"))
 sys.path.insert(0, REPO)
@@ -143,8 +133,9 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     return dt
 
 
-def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None, per_replay=1):
-    streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
+def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None, per_replay=1, streams=None):
+    if streams is None:
+        streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
     ring = (lambda j: None) if slab is None else (lambda j: (slab.view(-1)[4 * j:], slab.shape[0], 4 * nstr))
     return [engine.GraphedElbo(net, x, y, S_global, capture=graph, counter_stride=nstr, stream=st, sums_ring=ring(j),
                                evals_per_replay=per_replay)
@@ -260,9 +251,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per ELBO evaluation")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each); "
-                         "default 4 on one GPU, 3 per rank in a multi-rank job (see GPU_MAX_HW_QUEUES above)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent ELBO evaluations in flight per GPU (one hipGraph + HIP stream each)")
     ap.add_argument("--allreduce-every", type=int, default=16,
                     help="N>1: ELBO scalars of this many consecutive evaluations share one all-reduce call")
     ap.add_argument("--evals-per-graph", type=int, default=4,
@@ -294,6 +284,16 @@ def main():
     import bnn_hip
     from bnn_hip import engine
     bnn_hip.set_math(args.math)
+    # HIP multiplexes a process's streams onto 4 hardware queues, bound at first use.  The evaluator
+    # streams are created and used FIRST, before RCCL or any helper stream exists: then the four of
+    # them (and the idle null stream) map onto distinct queues in the single-GPU and the multi-rank path
+    # alike (16.3 / 16.9 us per one-sample evaluation); bound later, two evaluators end up sharing a
+    # queue (24.7 us), and a fifth busy queue is slower again.
+    pre_streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    for st in pre_streams:
+        with torch.cuda.stream(st):
+            torch.zeros(16, device=dev).add_(1.0)
+    torch.cuda.synchronize()
     dist = None
     # BNN_BENCH_FORCE_DIST=1: take the N>1 code path (process group, slab all-reduces) with one rank
     if world > 1 or os.environ.get("BNN_BENCH_FORCE_DIST", "0") == "1":
@@ -310,12 +310,13 @@ def main():
     # the wide stack has no task attached in BASELINE: Gaussian NLL over its 4096 outputs
     net, x, y = build_net(dims, lr, args.batch, dev, "regression" if args.net == "wide" else "classification")
     S_local, S_global = args.samples, args.samples * world
-    nstr = args.streams if args.streams > 0 else (3 if _MULTI else 4)
+    nstr = max(1, args.streams)
     ar_every = max(1, args.allreduce_every)
     per_replay = math.gcd(max(1, args.evals_per_graph), args.steps, args.warmup or args.steps,
                           *((ar_every,) if dist is not None else ()))
     slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
-    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay)
+    evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay,
+                          streams=pre_streams[:nstr] if nstr > 1 else None)
     assert evs[0].n_local == S_local
     if args.roofline_only:
         torch.cuda.synchronize()
@@ -345,7 +346,6 @@ def main():
                                f"flight per GPU, Gaussian prior, on-chip Philox eps",
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
-                   "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "evaluations_per_graph_launch": per_replay,
                    "parallelism": (f"mc-sample-shard x{world}; RCCL sum all-reduce of the 4 ELBO scalars of every evaluation, "
                                    f"{args.allreduce_every * nstr} evaluations per call, asynchronous") if world > 1 else "single GPU"},
@@ -378,7 +378,7 @@ def main():
         if world == 1 and not args.no_extras and args.net == "mnist":
             extras = []
             for (S, ns, steps) in ((8, 3, 300), (64, 1, 100), (256, 1, 40)):
-                e2 = make_evaluators(engine, net, x, y, S, ns)
+                e2 = make_evaluators(engine, net, x, y, S, ns, streams=pre_streams[:ns] if ns > 1 else None)
                 d2 = run_steps(e2, steps, max(5, steps // 10), None)
                 r2 = layer2_roofline(e2[0], net, dims, args.batch, S, lr, args.math)
                 extras.append({"mc_samples_per_evaluation": S, "evaluations_in_flight": ns, "steps": steps,
