@@ -48,23 +48,26 @@ struct LrK {
   const uint32_t* sample_counter;
 };
 
-template <int MATH, int XDT, int R>
-__global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
+// MT = batch tiles (of 16 rows) per block: 8, or 2 for a narrow layer (the 10-class output layer is
+// 3 feature tiles: with 128 rows per block three blocks would each ingest all of x; 32-row blocks
+// make 12 of them, each with a quarter of x, 8 accumulators and room for 12 waves).
+template <int MATH, int XDT, int R, int MT>
+__global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p) {
   constexpr int F = 16 / R, FG = F / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int c = r / F, f = r % F;
   const int K = p.K, N = p.N, B = p.B;
-  const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
+  const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
   int item;
   if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int n = nt * F + f;
   const bool n_ok = n < N;
   const int nc = min(n, N - 1);
-  const int m0 = mb * 128;
-  const int mtiles = min(8, (B - m0 + 15) >> 4);
+  const int m0 = mb * 16 * MT;
+  const int mtiles = min(MT, (B - m0 + 15) >> 4);
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
   const bool do_kl = p.want_kl && mb == 0 && s == 0;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
   const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
 
   f32x4* slab = reinterpret_cast<f32x4*>(lds);
-  float* lds_bias = lds + (size_t)nw * 8 * 64 * 4;
+  float* lds_bias = lds + (size_t)nw * MT * 64 * 4;
   float* lds_red = lds_bias + 16;
 
   if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
     if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
   }
 
-  f32x4 am[8], av[8];
+  f32x4 am[MT], av[MT];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < MT; ++m) {
     am[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     av[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
   for (int t = wave; t < ssteps; t += nw) {
     const int k = (t * R + c) * 32 + q * 8;
     constexpr int FR = (XDT == BNN_F32) ? 2 : 1;
-    constexpr int MC = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));
+    constexpr int MC0 = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));
+    constexpr int MC = MC0 > MT ? MT : MC0;
     float4 xraw[MC * R * FR];
     auto stage = [&](int ch) {
 #pragma unroll
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
       }
     }
 #pragma unroll
-    for (int ch = 0; ch < 8 / MC; ++ch) {
+    for (int ch = 0; ch < MT / MC; ++ch) {
       if (ch * MC < mtiles) {
 #pragma unroll
         for (int mm = 0; mm < MC; ++mm) {
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
             }
           }
         }
-        if ((ch + 1) * MC < 8 && (ch + 1) * MC < mtiles) stage(ch + 1);
+        if ((ch + 1) * MC < MT && (ch + 1) * MC < mtiles) stage(ch + 1);
       }
     }
   }
@@ -267,15 +271,15 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
 #pragma unroll 4
         for (int wv = 0; wv < nw; ++wv) {
 #pragma unroll
-          for (int cc = 0; cc < R; ++cc) v += slab[(wv * 8 + m) * 64 + (cc * FG + fg) * 16 + b];
+          for (int cc = 0; cc < R; ++cc) v += slab[(wv * MT + m) * 64 + (cc * FG + fg) * 16 + b];
         }
       }
       out[ii] = v;
     }
   };
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = am[m];
+  for (int m = 0; m < MT; ++m)
+    if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = am[m];
   __syncthreads();
   reduce_items(vm);
   if (do_kl && threadIdx.x == 0) {
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(512) void lr_fwd_kernel(const LrK p) {
   }
   __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = av[m];
+  for (int m = 0; m < MT; ++m)
+    if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = av[m];
   __syncthreads();
   reduce_items(vv);
 
@@ -814,33 +818,45 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
   const int F = 16 / R;
   const int ssteps = (K + 32 * R - 1) / (32 * R);
+  // a narrow layer in few samples: 32-row blocks (MT = 2), so that more than a handful of blocks exist
+  // and each ingests a quarter of x; its weights are small enough that re-reading them per block is free
+  int MT = ((long)((N + F - 1) / F) * a->n_samples * mbs < 64 && N <= 64 && a->batch > 32) ? 2 : 8;
+  const int forceMT = lr_env_int("BNN_HIP_LR_MT", 0);
+  if (forceMT == 2 || forceMT == 8) MT = forceMT;
+  const int max_nw = MT == 2 ? 12 : 8;
   int spw = 1;
-  while ((ssteps + spw - 1) / spw > 8) ++spw;
+  while ((ssteps + spw - 1) / spw > max_nw) ++spw;
   int nw = (ssteps + spw - 1) / spw;
   nw = nw < 1 ? 1 : nw;
   {
     // the epilogue gives every thread at most 2 output items (batch row x 4 features): a short k range
     // must not leave the block with fewer threads than that needs (extra waves own no k-step and
     // contribute zero slabs)
-    const int mt = a->batch >= 128 ? 8 : (a->batch + 15) / 16;
+    const int mt = a->batch >= 16 * MT ? MT : (a->batch + 15) / 16;
     const int need = (mt * 16 * (F / 4) + 127) / 128;
     if (nw < need) nw = need;
   }
-  const long total = (long)((N + F - 1) / F) * a->n_samples * mbs;
+  const int mbs_t = (a->batch + 16 * MT - 1) / (16 * MT);
+  const long total = (long)((N + F - 1) / F) * a->n_samples * mbs_t;
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
-  const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw) * sizeof(float);
-#define BNN_LR(MATH, XDT, RR)                                                                       \
-  do {                                                                                              \
-    if (lds > 64 * 1024)                                                                            \
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fwd_kernel<MATH, XDT, RR>),        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
-    if (err == hipSuccess) hipLaunchKernelGGL((lr_fwd_kernel<MATH, XDT, RR>), grid, block, lds, stream, k); \
+  const size_t lds = ((size_t)nw * MT * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+#define BNN_LR(MATH, XDT, RR, MM)                                                                       \
+  do {                                                                                                  \
+    if (lds > 64 * 1024)                                                                                \
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fwd_kernel<MATH, XDT, RR, MM>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+    if (err == hipSuccess) hipLaunchKernelGGL((lr_fwd_kernel<MATH, XDT, RR, MM>), grid, block, lds, stream, k); \
+  } while (0)
+#define BNN_LR_M(MATH, XDT, RR)                  \
+  do {                                           \
+    if (MT == 2) BNN_LR(MATH, XDT, RR, 2);       \
+    else BNN_LR(MATH, XDT, RR, 8);               \
   } while (0)
 #define BNN_LR_R(MATH, XDT)                      \
   do {                                           \
-    if (R == 1) BNN_LR(MATH, XDT, 1);            \
-    else if (R == 2) BNN_LR(MATH, XDT, 2);       \
-    else BNN_LR(MATH, XDT, 4);                   \
+    if (R == 1) BNN_LR_M(MATH, XDT, 1);          \
+    else if (R == 2) BNN_LR_M(MATH, XDT, 2);     \
+    else BNN_LR_M(MATH, XDT, 4);                 \
   } while (0)
   if (a->math == BNN_MATH_BF16) {
     if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_BF16, BNN_F32); else BNN_LR_R(BNN_MATH_BF16, BNN_BF16);
@@ -848,6 +864,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_F32, BNN_F32); else BNN_LR_R(BNN_MATH_F32, BNN_BF16);
   }
 #undef BNN_LR
+#undef BNN_LR_M
 #undef BNN_LR_R
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
