@@ -449,9 +449,11 @@ def test_lr_throughput_path_against_oracle(dev, monkeypatch, force_gemm, S):
     close(got[0], ref[0].numpy(), rtol=1e-4)            # ELBO
 
 
+@pytest.mark.parametrize("eps_mode", ["philox", "memory"])
 @pytest.mark.parametrize("prior", [ops.PriorSpec(False, 0.8), ops.PriorSpec(True, 1.0, 0.5, 1.0, math.exp(-6.0))])
-@pytest.mark.parametrize("shape", [(3, 20, 72, 37, True), (2, 128, 1200, 1200, True), (1, 8, 50, 1, False), (2, 5, 33, 65, False)])
-def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape):
+@pytest.mark.parametrize("shape", [(3, 20, 72, 37, True), (2, 128, 1200, 1200, True), (1, 8, 50, 1, False), (2, 5, 33, 65, False),
+                                   (3, 20, 72, 36, True), (2, 100, 200, 40, False), (1, 130, 784, 1200, True)])
+def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape, eps_mode):
     """F1: bnn_bbb_linear_bwd (eps regenerated on chip, fp32 matrix core) against the closed-form
     gradients evaluated with tensor ops on the same Philox eps — and through them against
     autograd of the oracle (the tensor-op path is what golden G5 pins)."""
@@ -461,14 +463,17 @@ def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape):
     mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
     x = mk(S, B, K, lo=-1, hi=1)
     w_mu, w_rho, b_mu, b_rho = mk(N, K), mk(N, K, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
-    call = Fn.LayerCall(n_samples=S, prior=prior, math_mode=L.MATH_F32, relu=relu, eps_mode=L.EPS_PHILOX, seed=11,
-                        layer_id=2, sample_offset=40, want_stats=True)
+    mem = eps_mode == "memory"
+    eps_w = torch.from_numpy(rs.standard_normal((S, N, K)).astype(np.float32)).to(dev) if mem else None
+    eps_b = torch.from_numpy(rs.standard_normal((S, N)).astype(np.float32)).to(dev) if mem else None
+    call = Fn.LayerCall(n_samples=S, prior=prior, math_mode=L.MATH_F32, relu=relu,
+                        eps_mode=L.EPS_MEMORY if mem else L.EPS_PHILOX, seed=11, layer_id=2, sample_offset=40, want_stats=True)
     gy, glp, glq = mk(S, B, N, lo=-1, hi=1), mk(S, lo=-0.5, hi=0.5), mk(S, lo=-0.5, hi=0.5)
     grads = {}
     for hip in (True, False):
         Fn.HIP_BACKWARD = hip
         leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
-        y, lp, lq = Fn.BBBLinearFn.apply(*leaves, None, None, call)
+        y, lp, lq = Fn.BBBLinearFn.apply(*leaves, eps_w, eps_b, call)
         ((y * gy).sum() + (lp * glp).sum() + (lq * glq).sum()).backward()
         grads[hip] = [l.grad.clone() for l in leaves]
     Fn.HIP_BACKWARD = True
