@@ -152,11 +152,39 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
       }
     } else {
       const float* tgt = reinterpret_cast<const float*>(p.target);
-      for (int b = threadIdx.x; b < p.B; b += blockDim.x)
-        for (int cc = 0; cc < p.C; ++cc) {
-          const float d = tgt[(size_t)b * p.C + cc] - lg[(size_t)b * ldc + cc];
-          acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
+      if (p.C <= 8) {                            // a thread per row (the 1-output regression net)
+        for (int b = threadIdx.x; b < p.B; b += blockDim.x)
+          for (int cc = 0; cc < p.C; ++cc) {
+            const float d = tgt[(size_t)b * p.C + cc] - lg[(size_t)b * ldc + cc];
+            acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
+          }
+      } else {                                   // wide outputs: a wave per row, lanes stride over the outputs
+        // sum of squares in fp32 per lane (<= B*C/threads terms), the affine map applied once per lane
+        const int nwv = blockDim.x >> 6;
+        float d2 = 0.f;
+        int cnt = 0;
+        for (int b = wave; b < p.B; b += nwv) {
+          const float* row = lg + (size_t)b * ldc;
+          const float* trow = tgt + (size_t)b * p.C;
+          if (((p.C | ldc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(trow)) & 15) == 0) {
+#pragma unroll 4
+            for (int cc = lane * 4; cc < p.C; cc += 256) {                    // 16-byte loads, 4 of each stream in flight
+              const float4 t4 = *reinterpret_cast<const float4*>(trow + cc), r4 = *reinterpret_cast<const float4*>(row + cc);
+              const float dx = t4.x - r4.x, dy = t4.y - r4.y, dz = t4.z - r4.z, dw = t4.w - r4.w;
+              d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, __builtin_fmaf(dz, dz, __builtin_fmaf(dw, dw, d2))));
+              cnt += 4;
+            }
+          } else {
+#pragma unroll 8
+            for (int cc = lane; cc < p.C; cc += 64) {                         // 8 loads of each stream in flight
+              const float d = trow[cc] - row[cc];
+              d2 = __builtin_fmaf(d, d, d2);
+              ++cnt;
+            }
+          }
         }
+        acc = (float)((double)d2 * cst.reg_inv2var + (double)cnt * cst.reg_const);
+      }
     }
     v[NV - 1] = acc;
   }

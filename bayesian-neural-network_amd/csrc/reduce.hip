@@ -358,7 +358,9 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   const int rc = make_fin(a, k, cst);
   if (rc != BNN_OK) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const int single = a->n_samples <= 16;
+  // few samples with small logits: one block walks them all and also writes the sums (one launch);
+  // otherwise a block per sample
+  const int single = a->n_samples <= 16 && (long)a->n_samples * a->batch * a->classes <= 65536;
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single,
                      a->sums);
   hipError_t err = hipGetLastError();

@@ -680,3 +680,19 @@ def test_throughput_forms_over_odd_shapes(dev, monkeypatch, shape):
                                          w_sigma=ops.softplus(wr) if hoist else None)
                 err = float((out["y"] - ref).abs().max())
                 assert err <= 3e-3 * (float(ref.abs().max()) + 1e-6), (shape, "BBB", hoist, err)
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 4096), (2, 37, 37), (20, 16, 100), (1, 128, 1)])
+def test_regression_nll_wide_outputs(dev, shape):
+    """K4's Gaussian NLL (networks.py:185-187) for output widths the 1-output regression net never
+    reaches (the 4096-wide stack of BASELINE configs[4]): wave-per-row / 16-byte path and the
+    block-per-sample grid against torch.distributions."""
+    S, B, Cc = shape
+    gen = torch.Generator(device="cpu").manual_seed(S * 131 + Cc)
+    logits = torch.randn(S, B, Cc, generator=gen).to(dev)
+    target = torch.randn(B, Cc, generator=gen).to(dev)
+    sig = 0.7
+    out = ops.elbo_finalize(workspaces=[], layer_in=[], layer_out=[], local_reparam=False, prior=ops.PriorSpec(), n_samples=S,
+                            logits=logits, target=target, mode="regression", nll_sigma=sig)
+    ref = torch.stack([-torch.distributions.Normal(logits[s].double(), sig).log_prob(target.double()).sum() for s in range(S)])
+    close(out["nll"], ref.cpu().numpy(), rtol=2e-6)
