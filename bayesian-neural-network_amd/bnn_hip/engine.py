@@ -19,9 +19,15 @@ from .runtime import state, take_samples
 
 CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it saves
 # BBB: K-sliced GEMM form (deterministic split-K + reduce kernel) for this range of samples per launch.
-# Measured on MI355X it only ties the K-split kernel at 4..24 samples (29+5 us vs 32 us per layer at 8
-# samples), so it is off unless BNN_HIP_SPLITK=1.
-SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = (4, 24) if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else (0, 0)
+# Measured on MI355X it only ties the K-split kernel on the 1200-wide layers (29+5 us vs 32 us per layer
+# at 8 samples) but wins on big layers below the plain GEMM form's threshold (4096x4096, 4 samples:
+# 126 vs 175 us), so it is on for layers of >= SPLIT_MIN_WEIGHTS weights, everywhere with BNN_HIP_SPLITK=1.
+SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = 4, 24
+SPLIT_MIN_WEIGHTS = 0 if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else 4_000_000
+
+
+def use_split(fin: int, fout: int, n_samples: int) -> bool:
+    return fout > 16 and fin * fout >= SPLIT_MIN_WEIGHTS and SPLIT_MIN_SAMPLES <= n_samples < SPLIT_MAX_SAMPLES
 SIGMA_HOIST_MIN_SAMPLES = 24  # BBB: precompute sigma = softplus(rho) once per evaluation from here on
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
@@ -129,7 +135,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 if h.dtype == torch.bfloat16 and n_local >= SIGMA_HOIST_MIN_SAMPLES and eps_mode != L.EPS_ZERO and \
                         ((sp.in_out[1] + 63) // 64) * n_local >= 450:
                     kw["w_sigma"] = ops.softplus(pd[1])        # consumed by the throughput (GEMM) form only
-                if not last and h.dtype == torch.bfloat16 and SPLIT_MIN_SAMPLES <= n_local < SPLIT_MAX_SAMPLES:
+                if h.dtype == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], n_local):
                     kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
@@ -321,8 +327,8 @@ class GraphedElbo:
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]
         self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
-                      if (not self.lr and i < len(self.specs) - 1 and hid == torch.bfloat16 and
-                          SPLIT_MIN_SAMPLES <= S < SPLIT_MAX_SAMPLES) else None for i, sp in enumerate(self.specs)]
+                      if (not self.lr and hid == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], S)) else None
+                      for i, sp in enumerate(self.specs)]
         self.wsigma = [torch.empty_like(sp.m.weight_rho.detach())
                       if (not self.lr and hid == torch.bfloat16 and S >= SIGMA_HOIST_MIN_SAMPLES and
                           ((sp.in_out[1] + 63) // 64) * S >= 450) else None for sp in self.specs]
@@ -378,7 +384,10 @@ class GraphedElbo:
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]
             elif i == last:
-                ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
+                if self.wsigma[i] is not None:
+                    ops.softplus(p[1], out=self.wsigma[i])
+                ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
+                                                 w_sigma=self.wsigma[i], **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))
             else:
                 if self.wsigma[i] is not None:
