@@ -13,7 +13,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .functional import AllReduceSumFn, BBBLinearFn, LayerCall, LRLinearFn, NLLFn
+from .functional import AllReduceSumFn, BBBLinearFn, ElboFn, LayerCall, LRLinearFn, NetCall, NLLFn
 from .runtime import state, take_samples
 
 
@@ -24,6 +24,11 @@ CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it s
 # 126 vs 175 us), so it is on for layers of >= SPLIT_MIN_WEIGHTS weights, everywhere with BNN_HIP_SPLITK=1.
 SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = 4, 24
 SPLIT_MIN_WEIGHTS = 0 if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else 4_000_000
+
+
+# differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
+# chip; BNN_HIP_FUSED_ELBO=0 keeps one node per layer (the form the identical-eps parity path always uses)
+FUSED_ELBO_NODE = os.environ.get("BNN_HIP_FUSED_ELBO", "1") != "0"
 
 
 def use_split(fin: int, fout: int, n_samples: int) -> bool:
@@ -203,6 +208,18 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
                           mode=mode, nll_sigma=float(sigma),
                           ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None,
                           scratch=None if local_reparam else ops.final_scratch(n_local, dev))
+        fused_node = differentiable and injected is None and FUSED_ELBO_NODE and x.dtype == torch.float32 and \
+            all(bool(sp.lr) == bool(local_reparam) for sp in layers)
+        if fused_node:
+            # the whole network as one autograd node (functional.ElboFn): ~15 launches per step instead of ~60
+            call = NetCall(layers=tuple((bool(sp.lr), bool(sp.relu), sp.layer_id, sp.m._prior_spec, *sp.in_out) for sp in layers),
+                           n_samples=n_local, sample_offset=first_global + lo, mode=mode, sigma=float(sigma),
+                           math_mode=state.math, seed=state.seed, sample_counter=state.device_counter)
+            params = [t for sp in layers for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
+            sums = ElboFn.apply(x, target, call, *params)
+            if world > 1:
+                sums = AllReduceSumFn.apply(sums)
+            return sums[0], sums[1], sums[2], samples
         logits, stats = run_layers(layers, x, n_local, first_global + lo, want_stats=True, sample=True,
                                    injected=injected, differentiable=differentiable,
                                    fin_kw=fin_kw if not local_reparam else None)

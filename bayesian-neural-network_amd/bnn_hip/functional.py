@@ -216,6 +216,90 @@ class LRLinearFn(torch.autograd.Function):
         return gx, g_M, g_rho, g_bmu, g_brho, None, None, None
 
 
+@dataclass(frozen=True)
+class NetCall:
+    """Static description of one ELBO evaluation of a whole stack of layers (ElboFn)."""
+    layers: tuple                 # per layer: (local_reparam, relu, layer_id, PriorSpec, in_features, out_features)
+    n_samples: int                # local MC samples
+    sample_offset: int
+    mode: str
+    sigma: float
+    math_mode: int
+    seed: int
+    sample_counter: Optional[torch.Tensor] = None
+
+
+class ElboFn(torch.autograd.Function):
+    """(x, target, *[w_mu, w_rho, b_mu, b_rho per layer]) -> float32[3] = the local samples' sums
+    {sum_s log p | sum_s KL, sum_s log q | 0, sum_s nll}: the whole network of networks.py:166-190 as ONE
+    autograd node.  Forward = layer kernels + bnn_elbo_finalize; backward = bnn_nll_bwd + the layer
+    backward kernels chained by hand (what train.GraphedTrainStep captures), so an unchanged
+    `loss.backward()` loop pays ~15 launches per step instead of autograd's ~60.  On-chip eps only."""
+
+    @staticmethod
+    def forward(ctx, x, target, call: NetCall, *params):
+        S = call.n_samples
+        h = x
+        saved, wss = [], []
+        for i, (lr, relu, layer_id, prior, _fin, _fout) in enumerate(call.layers):
+            p = tuple(t.detach() for t in params[4 * i:4 * i + 4])
+            common = dict(n_samples=S, math_mode=call.math_mode, relu=relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
+                          seed=call.seed, layer_id=layer_id, sample_offset=call.sample_offset,
+                          sample_counter=call.sample_counter)
+            if lr:
+                out = ops.lr_linear_fwd(h, *p, sigma_p=prior.sigma_p, want_kl=True, want_v=True, **common)
+            else:
+                out = ops.bbb_linear_fwd(h, *p, prior=prior, want_stats=True, **common)
+            saved += [h, out["y"], out.get("v")]
+            wss.append(out["workspace"])
+            h = out["y"]
+        lr_net = bool(call.layers[0][0])
+        sums = torch.empty(4, dtype=torch.float32, device=h.device)
+        ops.elbo_finalize(workspaces=wss, layer_in=[l[4] for l in call.layers], layer_out=[l[5] for l in call.layers],
+                          local_reparam=lr_net, prior=call.layers[0][3], n_samples=S, logits=h, target=target, mode=call.mode,
+                          nll_sigma=call.sigma, sums=sums)
+        ctx.call = call
+        ctx.n_saved = len(saved)
+        ctx.save_for_backward(target, *params, *saved)
+        return sums[:3].clone()
+
+    @staticmethod
+    def backward(ctx, gsums):
+        call: NetCall = ctx.call
+        S = call.n_samples
+        nl = len(call.layers)
+        tensors = ctx.saved_tensors
+        target, params, saved = tensors[0], tensors[1:1 + 4 * nl], tensors[1 + 4 * nl:]
+        lr_net = bool(call.layers[0][0])
+        gsums = gsums.float()
+        g_a = gsums[0].expand(S).contiguous()
+        g_b = gsums[1].expand(S).contiguous()
+        g_nll = gsums[2].expand(S).contiguous()
+        # LR: the first sum is S times the layers' total KL, so each layer's KL sees S * g
+        g_kl3 = torch.stack([gsums[0] * S, torch.zeros_like(gsums[0]), torch.zeros_like(gsums[0])]) if lr_net else None
+        logits = saved[3 * (nl - 1) + 1]
+        g = ops.nll_bwd(logits, target, g_nll, call.mode, call.sigma)
+        grads = [None] * (4 * nl)
+        gx = None
+        for i in reversed(range(nl)):
+            lr, relu, layer_id, prior, _fin, _fout = call.layers[i]
+            xin, y, v = saved[3 * i:3 * i + 3]
+            p = params[4 * i:4 * i + 4]
+            kw = dict(n_samples=S, relu=relu, eps_mode=L.EPS_PHILOX, seed=call.seed, layer_id=layer_id,
+                      sample_offset=call.sample_offset, sample_counter=call.sample_counter,
+                      want_gx=(i > 0) or ctx.needs_input_grad[0])
+            if lr:
+                out = ops.lr_linear_bwd(xin, g, y if relu else None, v, *p, sigma_p=prior.sigma_p, g_kl=g_kl3, **kw)
+            else:
+                out = ops.bbb_linear_bwd(xin, g, y if relu else None, *p, prior=prior, math_mode=call.math_mode,
+                                         g_log_prior=g_a, g_log_q=g_b, **kw)
+            grads[4 * i:4 * i + 4] = out[:4]
+            g = out[4]
+        if ctx.needs_input_grad[0] and g is not None:
+            gx = g.sum(0) if g.dim() == 3 and tensors[1 + 4 * nl].dim() == 2 else g
+        return (gx, None, None, *grads)
+
+
 class NLLFn(torch.autograd.Function):
     """logits[S,B,C], target -> nll[S] via K4 (networks.py:183-190)."""
 

@@ -242,3 +242,45 @@ def test_data_parallel_train_step_two_ranks(tmp_path, variant):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+@pytest.mark.parametrize("config", [("bbb", False), ("bbb", True), ("lr", False)])
+def test_whole_network_autograd_node_equals_per_layer_nodes(config):
+    """functional.ElboFn (sample_elbo* as ONE autograd node: layer kernels + finalize forward, hand-chained
+    backward kernels) gives the loss tuple and the gradients of the per-layer autograd path on the same
+    Philox sample indices — classification and regression, Gaussian and mixture prior, LR."""
+    import networks
+    from bnn_hip import engine
+    variant, mixture = config
+    dev = torch.device("cuda:0")
+    bnn_hip.set_math("f32")
+    for mode, dims, B in (("classification", (784, 96, 10), 64), ("regression", (1, 50, 1), 37)):
+        mp = dict(input_shape=dims[0], classes=dims[2], batch_size=B, hidden_units=dims[1], mode=mode, mu_init=[-0.2, 0.2],
+                  rho_init=[-5, -4], prior_init=[0.5, 0.0, -6.0] if mixture else [1.0], mixture_prior=mixture,
+                  local_reparam=variant == "lr")
+        torch.manual_seed(3)
+        net = networks.BayesianNetwork(mp).to(dev).train()
+        rs = np.random.RandomState(4)
+        if mode == "classification":
+            x = torch.from_numpy(rs.uniform(0, 1, (B, 1, 28, 28)).astype(np.float32)).to(dev)
+            y = torch.from_numpy(rs.randint(0, 10, B)).to(dev)
+        else:
+            x = torch.from_numpy(rs.uniform(0, 0.5, (B, 1)).astype(np.float32)).to(dev)
+            y = torch.from_numpy(rs.uniform(-1, 1, (B, 1)).astype(np.float32)).to(dev)
+        elbo = net.sample_elbo_lr if variant == "lr" else net.sample_elbo
+        res = {}
+        try:
+            for fused in (True, False):
+                engine.FUSED_ELBO_NODE = fused
+                bnn_hip.manual_seed(21, counter=77)
+                net.zero_grad()
+                out = elbo(x, y, 0.37, 3, 0.4)
+                out[0].backward()
+                res[fused] = ([o.detach().clone() for o in out], [p.grad.clone() for p in net.parameters()])
+        finally:
+            engine.FUSED_ELBO_NODE = True
+        for a, b in zip(res[True][0], res[False][0]):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-6)
+        for (name, _), a, b in zip(net.named_parameters(), res[True][1], res[False][1]):
+            assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-9), (mode, name)
