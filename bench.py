@@ -323,6 +323,11 @@ def main():
         roof = layer2_roofline(evs[0], net, dims, args.batch, S_local, lr, args.math)
         print(json.dumps({"roofline": roof, "mc_samples_per_launch": S_local, "variant": args.variant}), flush=True)
         return
+    # clocks, caches and the allocator settle during the first few dozen replays after capture: always run
+    # some untimed ones before the W warm-up steps the caller asked for (they matter when W is tiny)
+    prewarm = 16 * per_replay * nstr
+    run_steps(evs, 0, prewarm if dist is None else (prewarm + ar_every * nstr - 1) // (ar_every * nstr) * (ar_every * nstr),
+              dist, slab, ar_every)
     dt = run_steps(evs, args.steps, args.warmup, dist, slab, ar_every)
     if dist is not None and run_steps.last_flushed_half is not None:
         # every all-reduced row carries the GLOBAL sample count in its 4th word
