@@ -696,3 +696,43 @@ def test_regression_nll_wide_outputs(dev, shape):
                             logits=logits, target=target, mode="regression", nll_sigma=sig)
     ref = torch.stack([-torch.distributions.Normal(logits[s].double(), sig).log_prob(target.double()).sum() for s in range(S)])
     close(out["nll"], ref.cpu().numpy(), rtol=2e-6)
+
+
+def test_misaligned_operands_are_rejected_or_handled(dev):
+    """A tensor view that starts 4 bytes into an allocation breaks the 16-byte accesses of the vector
+    paths: every entry point must either take its scalar path and be right, or answer with
+    BNN_ERR_ALIGN (a Python exception) — never read the wrong bytes or fault."""
+    from bnn_hip import BnnHipError
+    K, N, B = 64, 32, 16
+    x_bad = torch.randn(B * K + 1, device=dev)[1:].view(B, K)      # 4-byte offset
+    assert x_bad.data_ptr() % 16 != 0
+    wm, wr = torch.randn(N, K, device=dev) * 0.1, torch.full((N, K), -3.0, device=dev)
+    bm, br = torch.randn(N, device=dev), torch.full((N,), -3.0, device=dev)
+
+    def right_or_refused(fn, ref):
+        try:
+            out = fn()
+        except BnnHipError as e:
+            assert "align" in str(e).lower()
+            return "refused"
+        close(out, ref.cpu().numpy(), rtol=2e-5, atol=1e-5)
+        return "handled"
+
+    seen = set()
+    seen.add(right_or_refused(lambda: ops.bbb_linear_fwd(x_bad, wm, wr, bm, br, n_samples=1, prior=ops.PriorSpec(False, 1.0),
+                                                         math_mode=L.MATH_F32, relu=False, y_dtype=torch.float32,
+                                                         eps_mode=L.EPS_ZERO, want_stats=False)["y"][0], x_bad @ wm.t() + bm))
+    wml, wrl = wm.t().contiguous(), wr.t().contiguous()
+    seen.add(right_or_refused(lambda: ops.lr_linear_fwd(x_bad, wml, wrl, bm, br, n_samples=1, sigma_p=1.0, math_mode=L.MATH_F32,
+                                                        relu=False, y_dtype=torch.float32, eps_mode=L.EPS_ZERO,
+                                                        want_kl=False)["y"][0], x_bad @ wml + bm))
+    w_bad = (torch.randn(N * K + 1, device=dev) * 0.1)[1:].view(N, K)
+    seen.add(right_or_refused(lambda: ops.bbb_linear_fwd(x_bad.contiguous().clone(), w_bad, wr, bm, br, n_samples=1,
+                                                         prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_F32, relu=False,
+                                                         y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=False)["y"][0],
+                              x_bad @ w_bad.t() + bm))
+    x3, gy = torch.randn(1, B, K, device=dev), torch.randn(1, B, N, device=dev)
+    with pytest.raises(BnnHipError):                              # the backward kernels are vector-only on their parameters
+        ops.bbb_linear_bwd(x3, gy, None, w_bad, wr, bm, br, n_samples=1, prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_F32,
+                           relu=False, eps_mode=L.EPS_PHILOX, seed=1, layer_id=0, want_gx=False)
+    assert seen <= {"refused", "handled"} and seen
