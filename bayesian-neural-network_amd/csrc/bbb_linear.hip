@@ -970,6 +970,10 @@ Plan make_plan(int S, int B, int K, int N, bool aligned) {
   // them share a CU and cover each other's load and barrier stalls; a lone sample instead wants
   // the shortest per-wave chain (one or two k-steps per wave).
   if ((long)((N + F - 1) / F) * S * mbs >= 400 && ssteps >= 8) nw = 4;
+  // a CU has 4 SIMDs: 10 waves sit 3,3,2,2 and the block waits for the crowded pair (stamps: 3.9 k cycles
+  // of barrier wait); a multiple of 4 keeps the generator work per SIMD even (measured 11.2 -> 10.4 us per
+  // one-sample launch of the 1200x1200 layer, 16.2 -> 14.8 us per evaluation with four in flight)
+  else if (ssteps >= 4) nw = (ssteps >= 12 ? 12 : ssteps) & ~3;   // as many waves as there are k-steps, up to 12, in fours
   if (forceNw > 0) nw = forceNw > 12 ? 12 : forceNw;
   if (nw > ssteps) nw = ssteps;
   pl.R = R;

@@ -828,6 +828,9 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   while ((ssteps + spw - 1) / spw > max_nw) ++spw;
   int nw = (ssteps + spw - 1) / spw;
   nw = nw < 1 ? 1 : nw;
+  // a CU has 4 SIMDs: keep the waves of a block a multiple of 4 so no SIMD carries one more than the others
+  // (as many as there are k-steps, up to the limit) -- see make_plan in bbb_linear.hip
+  if (ssteps >= 4 && lr_env_int("BNN_HIP_LR_WAVES4", 1)) nw = (ssteps >= max_nw ? max_nw : ssteps) & ~3;
   {
     // the epilogue gives every thread at most 2 output items (batch row x 4 features): a short k range
     // must not leave the block with fewer threads than that needs (extra waves own no k-step and
