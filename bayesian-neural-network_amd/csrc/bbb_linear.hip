@@ -1188,6 +1188,13 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   // block), so the last layer's latency chain is one step long instead of ceil(ssteps/12).
   int KS = (ssteps + 11) / 12;
   KS = KS > kFinalMaxSlices ? kFinalMaxSlices : KS;
+  for (int ks = KS; ks <= kFinalMaxSlices; ++ks) {     // ... and a wave count in fours (even work per SIMD), if a
+    const int per = (ssteps + ks - 1) / ks;             // slightly finer slicing gives one: 38 steps -> 5 slices of 8
+    if (per <= 12 && ((per & 3) == 0 || per < 4)) {
+      KS = ks;
+      break;
+    }
+  }
   if ((long)a->n_samples * KS > 128) KS = 1;           // enough sample blocks already: skip the hand-off
   const int forceKs = env_int("BNN_HIP_FINAL_KS", 0);
   if (forceKs >= 1 && forceKs <= kFinalMaxSlices) KS = forceKs;
