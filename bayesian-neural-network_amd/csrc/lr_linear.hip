@@ -46,7 +46,24 @@ struct LrK {
   int eps_mode, want_kl, relu, y_bf16;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
+#ifdef BNN_STAMPS
+  unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
+#endif
 };
+
+#ifdef BNN_STAMPS
+#define LR_STAMP(i)                                                              \
+  do {                                                                           \
+    if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define LR_STAMP_RT(i)                                                           \
+  do {                                                                           \
+    if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define LR_STAMP(i)
+#define LR_STAMP_RT(i)
+#endif
 
 // MT = batch tiles (of 16 rows) per block: 8, or 2 for a narrow layer (the 10-class output layer is
 // 3 feature tiles: with 128 rows per block three blocks would each ingest all of x; 32-row blocks
@@ -95,6 +112,8 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
     if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
   }
 
+  LR_STAMP(0);
+  LR_STAMP_RT(8);
   f32x4 am[MT], av[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
       s2[j] = rho_n[j];
     }
     if (t + nw < ssteps) load_params(t + nw);
+    if (t == wave) { asm volatile("" :: "v"(mu[0]), "v"(s2[0])); LR_STAMP(1); }
 
     float ls = 0.f, a2 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -235,6 +255,7 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
     }
   }
 
+  LR_STAMP(3);
   // ---- bias + its KL terms
   if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
@@ -280,7 +301,9 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
 #pragma unroll
   for (int m = 0; m < MT; ++m)
     if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = am[m];
+  LR_STAMP(4);
   __syncthreads();
+  LR_STAMP(5);
   reduce_items(vm);
   if (do_kl && threadIdx.x == 0) {
     float a = 0.f, b = 0.f, cc = 0.f;
@@ -297,6 +320,7 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
     if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = av[m];
   __syncthreads();
   reduce_items(vv);
+  LR_STAMP(6);
 
   // ---- epilogue: y = m + sqrt(v) * eps + b  [-> ReLU]
   const bool vec_ok = (N & 3) == 0;
@@ -364,6 +388,8 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
       }
     }
   }
+  LR_STAMP(7);
+  LR_STAMP_RT(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -778,6 +804,12 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   k.eps_mode = a->eps_mode; k.want_kl = a->want_kl ? 1 : 0; k.relu = a->relu ? 1 : 0; k.y_bf16 = ybf;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
+#ifdef BNN_STAMPS
+  {
+    const char* v = getenv("BNN_HIP_DBG_PTR");
+    k.dbg = v ? reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0)) : nullptr;
+  }
+#endif
 
   // launch geometry: a function of the shape only
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
