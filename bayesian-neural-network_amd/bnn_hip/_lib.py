@@ -46,7 +46,7 @@ class BbbFwdArgs(C.Structure):
         ("want_stats", C.c_int32), ("relu", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
-        ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved", C.c_int32),
+        ("y", C.c_void_p), ("y_dtype", C.c_int32), ("concurrency", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
     ]
 
@@ -62,7 +62,7 @@ class LrFwdArgs(C.Structure):
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
         ("sample_counter", C.c_void_p),
         ("eps_act_dump", C.c_void_p), ("eps_b_dump", C.c_void_p),
-        ("sigma_p", C.c_float), ("want_kl", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32),
+        ("sigma_p", C.c_float), ("want_kl", C.c_int32), ("relu", C.c_int32), ("concurrency", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),

@@ -393,7 +393,8 @@ class GraphedElbo:
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
-                          sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i])
+                          sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i],
+                          concurrency=self.stride)      # evaluators that run side by side: size launches for a share of the chip
             if self.lr:
                 if self.wfrag[i] is not None:
                     ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])

@@ -108,7 +108,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
-               out=None, split_scratch=None, w_sigma=None):
+               out=None, split_scratch=None, w_sigma=None, concurrency: int = 0):
     """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -138,6 +138,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     a.eps_w, a.eps_b = _ptr(eps_w) if eps_mode == L.EPS_MEMORY else None, _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
     a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
     a.sample_counter = _ptr(sample_counter)
+    a.concurrency = int(concurrency)
     a.eps_w_dump, a.eps_b_dump = _ptr(dw), _ptr(db)
     a.prior = prior.c()
     a.want_stats, a.relu = int(want_stats), int(relu)
@@ -167,7 +168,7 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None, w_frag=None, want_v: bool = False):
+                  out_sq=None, w_frag=None, want_v: bool = False, concurrency: int = 0):
     """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
     lib = L.load()
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -198,6 +199,7 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
     a.eps_b = _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
     a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
     a.sample_counter = _ptr(sample_counter)
+    a.concurrency = int(concurrency)
     a.eps_act_dump, a.eps_b_dump = _ptr(da), _ptr(db)
     a.sigma_p, a.want_kl, a.relu = float(sigma_p), int(want_kl), int(relu)
     a.workspace = _ptr(workspace) if want_kl else None

@@ -845,7 +845,8 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     }
   }
   int R = 1;
-  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
+  const long want_blocks = 120 / (a->concurrency > 1 ? a->concurrency : 1);   // a 1/n share of the chip, see make_plan (bbb_linear.hip)
+  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < want_blocks) R *= 2;
   const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
   if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
   const int F = 16 / R;

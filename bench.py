@@ -179,11 +179,12 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
         if lr:
             ops.lr_linear_fwd(xin, *pd, n_samples=S_local, sigma_p=1.0, math_mode=mm, relu=True, y_dtype=out.dtype,
                               eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_kl=True, workspace=ws, out=out,
-                              x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1])
+                              x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1], concurrency=ev.stride)
         else:
             ops.bbb_linear_fwd(xin, *pd, n_samples=S_local, prior=l2._prior_spec, math_mode=mm, relu=True,
                                y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True,
-                               workspace=ws, out=out, w_sigma=ev.wsigma[1], split_scratch=ev.split[1])
+                               workspace=ws, out=out, w_sigma=ev.wsigma[1], split_scratch=ev.split[1],
+                               concurrency=ev.stride)
     us = kernel_alone_us(launch, torch.cuda.current_stream())
     abytes = S_local * algorithmic_bytes_layer(dims[1], dims[1], batch, hid_b, hid_b)
     note = "un-amortised 8 B/param/sample formula of SURVEY 8(d)"
@@ -196,8 +197,10 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "kernel": ("lr_linear_fwd_kernel" if lr else "K1 bbb_linear_fwd") + f" layer 2 ({dims[1]}x{dims[1]})",
             "algorithmic_bytes_per_launch": abytes, "mc_samples_per_launch": S_local, "avg_launch_us": us,
-            "note": "HIP events around back-to-back graph launches of this kernel on its stream (incl. the "
-                    "dependent-launch boundary); " + note}
+            "note": "HIP events around back-to-back graph launches of this kernel, ALONE on its stream (incl. the "
+                    "dependent-launch boundary), with the tile plan of the timed region"
+                    + (f" (sized for 1/{ev.stride} of the chip because {ev.stride} evaluations run side by side there: "
+                       "alone it leaves most CUs idle)" if ev.stride > 1 else "") + "; " + note}
 
 
 def cpu_baseline(dims, lr, batch, budget_s=15.0):

@@ -135,7 +135,9 @@ typedef struct bnn_bbb_fwd_args {
   float* log_q;             /* optional [n_samples] */
   void* y;
   int32_t y_dtype;          /* bnn_dtype */
-  int32_t reserved;
+  int32_t concurrency;      /* 0 / 1: the launch has the chip to itself.  n > 1: about n independent launches
+                               like this one run side by side (one stream each): the launch is then sized for
+                               a 1/n share of the chip (fewer, larger tiles) */
   void* split_scratch;      /* optional, 16-byte aligned, >= 8 * n_samples*batch*out_features*4 bytes:
                                lets a mid-sized launch split its K range over several blocks
                                (fp32 partial tiles summed in a fixed order by a tiny second kernel) */
@@ -182,7 +184,7 @@ typedef struct bnn_lr_fwd_args {
   float sigma_p;            /* prior_init[0]; prior mean is 0 (networks.py:103-104) */
   int32_t want_kl;
   int32_t relu;
-  int32_t reserved;
+  int32_t concurrency;      /* as in bnn_bbb_fwd_args */
   void* workspace;
   size_t workspace_bytes;
   float* kl_out;
