@@ -7,7 +7,7 @@ import csv, glob, json, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def mean_counter(d, counter, kern):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == counter and kern in r["Kernel_Name"]]
     return sum(vals) / len(vals), len(vals)
