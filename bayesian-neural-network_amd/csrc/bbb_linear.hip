@@ -533,7 +533,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   BNN_STAMP_RT(9);
   if (FINAL) {
     const FinK& fk = fp->k;
-    float* part = fin_lg + 128 * 16;
+    float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(fin_lg + 128 * 16) + 7) & ~(uintptr_t)7);   // holds doubles too
     int T[8];
 #pragma unroll
     for (int l = 0; l < 8; ++l)
@@ -560,6 +560,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
         *flag = last;
       }
       __syncthreads();
+      BNN_STAMP(7);
       if (*flag == 0u) return;                                    // block-uniform
       __syncthreads();
       const float* tiles = fp->ks_tiles + (size_t)s * KS * (128 * 16);
@@ -579,24 +580,26 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
             if (fg * 4 + i < N) yp[i] = v[i];
         }
       }
+      if (threadIdx.x < 64) {                                      // wave 0: one slice per lane, folded by shuffles
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x < KS) q4 = fp->ks_stats[(size_t)s * KS + threadIdx.x];
+        own0 = wave_sum(q4.x);
+        own1 = wave_sum(q4.y);
+        own2 = wave_sum(q4.z);
+      }
       if (threadIdx.x == 0) {
-        own0 = own1 = own2 = 0.f;
-        for (int j = 0; j < KS; ++j) {
-          const float4 q4 = fp->ks_stats[(size_t)s * KS + j];
-          own0 += q4.x;
-          own1 += q4.y;
-          own2 += q4.z;
-        }
         p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
         fp->ks_ticket[s] = 0u;                                    // ready for the next launch
       }
     }
     __syncthreads();                               // logits tile complete in LDS
+    BNN_STAMP(10);
     float a = 0.f, b = 0.f, nll = 0.f;
     // thread 0 supplies this layer's own partial sums directly (every FINAL block computes its
     // own sum log sigma, so nothing is read from another block of this launch)
     const int own_layer = fk.n_layers - 1;
     fin_sample(fk, fp->c, s, T, fin_lg, 16, own_layer, own0, own1, own2, part, a, b, nll);
+    BNN_STAMP(11);
     if (threadIdx.x == 0) {
       fin_store(fk, s, a, b, nll);
       if (fk.S == 1) {

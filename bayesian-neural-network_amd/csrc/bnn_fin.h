@@ -85,7 +85,7 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
 //   T[]      : tile counts of the layers' workspaces (ws[l][0].x), 0 for own_layer;
 //   own_layer: a layer whose three partial sums thread 0 supplies directly (own0..2) because
 //              this very block produced them (-1: none);
-//   part     : LDS scratch, >= (blockDim.x/64) * kFinNV floats.
+//   part     : LDS scratch, 8-byte aligned, >= max((blockDim.x/64) * kFinNV floats, kFinNV doubles).
 // Partial sums go through fp32 wave shuffles (each thread holds at most a few partials) and
 // fp64 only across waves; one barrier.
 __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s, const int T[8], const float* lg, int ldc,
@@ -197,13 +197,19 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  // cross-wave sums in parallel: thread i folds value i over the waves (one thread walking all of them was
+  // ~70 dependent LDS reads, 3 us by the stamps), then hands the doubles to thread 0 through the same scratch
+  double folded = 0;
+  {
     const int nwv = blockDim.x >> 6;
-    auto red = [&](int i) {
-      double t = 0;
-      for (int w = 0; w < nwv; ++w) t += (double)part[w * NV + i];
-      return t;
-    };
+    if ((int)threadIdx.x < NV && ((int)threadIdx.x < nv || (int)threadIdx.x == NV - 1))
+      for (int w = 0; w < nwv; ++w) folded += (double)part[w * NV + threadIdx.x];
+  }
+  __syncthreads();                                          // every read of the per-wave partials is done
+  if ((int)threadIdx.x < NV) reinterpret_cast<double*>(part)[threadIdx.x] = folded;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    auto red = [&](int i) { return reinterpret_cast<const double*>(part)[i]; };
     // per-layer fp32 rounding, then fp32 adds, as the reference sums l1 + l2 + l3
     // (networks.py:174-181)
     float a_tot = 0.f, b_tot = 0.f;

@@ -100,7 +100,7 @@ static inline int kl_blocks(long n) {
 // grid = n_samples blocks (one sample each), or ONE block looping over all samples when
 // `single` (small n_samples): then the block also writes the 4-vector of sums, in sample order.
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums) {
-  __shared__ float part[4 * kFinNV];
+  __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
   int T[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l)
