@@ -73,10 +73,24 @@ __device__ __forceinline__ float softplus(float rho) {
 }
 
 // ---------------------------------------------------------------------------- reductions
+// v + (v moved across lanes by a DPP control); lanes the control or the row mask leaves unwritten add 0.
+// __shfl_xor is a ds_bpermute: an LDS-crossbar round trip of ~120 cycles per step, six dependent steps per sum
+// (stamps: ten back-to-back sums were 7 k cycles of the finalize tail); DPP moves ride on the add itself.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+
+// Sum over the 64 lanes of a wave, the same value returned in every lane.  All lanes must be active.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]: every lane holds its quad's sum
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror: ... its 8-lane half's
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror: ... its 16-lane row's
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: row1 = r0 + r1, row3 = r2 + r3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3: row3 = r0 + r1 + r2 + r3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
