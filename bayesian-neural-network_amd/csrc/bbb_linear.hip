@@ -598,7 +598,11 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
     // thread 0 supplies this layer's own partial sums directly (every FINAL block computes its
     // own sum log sigma, so nothing is read from another block of this launch)
     const int own_layer = fk.n_layers - 1;
+#ifdef BNN_STAMPS
+    fin_sample(fk, fp->c, s, T, fin_lg, 16, own_layer, own0, own1, own2, part, a, b, nll, p.dbg ? p.dbg + (size_t)blockIdx.x * 16 : nullptr);
+#else
     fin_sample(fk, fp->c, s, T, fin_lg, 16, own_layer, own0, own1, own2, part, a, b, nll);
+#endif
     BNN_STAMP(11);
     if (threadIdx.x == 0) {
       fin_store(fk, s, a, b, nll);

@@ -90,7 +90,8 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
 // fp64 only across waves; one barrier.
 __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s, const int T[8], const float* lg, int ldc,
                                            int own_layer, float own0, float own1, float own2, float* part,
-                                           float& out_a, float& out_b, float& out_nll) {
+                                           float& out_a, float& out_b, float& out_nll, unsigned long long* dbg = nullptr) {
+#define FIN_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
   constexpr int NV = kFinNV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float v[NV];
@@ -115,6 +116,7 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
       }
     }
   }
+  FIN_STAMP(12);
   if (p.nll && lg) {
     float acc = 0.f;
     if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
@@ -122,13 +124,28 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
       if (p.C <= 32) {                           // a thread per row
         for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
           const float* row = lg + (size_t)b * ldc;
-          float mx = row[0];
-          for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
-          float se = 0.f;
-          for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
           const long long tc = tgt[b];
+          float mx, se = 0.f;
+          if (ldc == 16 && p.C <= 16) {
+            // a row of the LDS tile [rows][16] held in registers: lane b starts at column b so that a wave's 64
+            // reads spread over all 32 banks (walking the same column put them on two); hardware exp2 / log2
+            float vr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vr[i] = row[(i + b) & 15];
+            mx = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = (((i + b) & 15) < p.C) ? fmaxf(mx, vr[i]) : mx;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) se += (((i + b) & 15) < p.C) ? __expf(vr[i] - mx) : 0.f;
+            se = __logf(se);
+          } else {
+            mx = row[0];
+            for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
+            for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
+            se = logf(se);
+          }
           const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
-          acc += (mx + logf(se)) - picked;
+          acc += (mx + se) - picked;
         }
       } else {                                   // a wave per row, lanes stride over the classes
         const int nwv = blockDim.x >> 6;
@@ -188,14 +205,28 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     }
     v[NV - 1] = acc;
   }
+  FIN_STAMP(13);
   const int nv = 3 * p.n_layers;
+  if (nv <= 9) {                               // up to 3 layers (block-uniform): ten sums as straight-line code, so
+    float t[10];                                // their DPP chains interleave instead of running one per basic block
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    if (i < nv || i == NV - 1) {               // block-uniform
-      const float t = wave_sum(v[i]);
-      if (lane == 0) part[wave * NV + i] = t;
+    for (int i = 0; i < 9; ++i) t[i] = wave_sum(v[i]);
+    t[9] = wave_sum(v[NV - 1]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) part[wave * NV + i] = t[i];
+      part[wave * NV + NV - 1] = t[9];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < nv || i == NV - 1) {             // block-uniform
+        const float t = wave_sum(v[i]);
+        if (lane == 0) part[wave * NV + i] = t;
+      }
     }
   }
+  FIN_STAMP(14);
   __syncthreads();
   // cross-wave sums in parallel: thread i folds value i over the waves (one thread walking all of them was
   // ~70 dependent LDS reads, 3 us by the stamps), then hands the doubles to thread 0 through the same scratch
@@ -208,12 +239,15 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   __syncthreads();                                          // every read of the per-wave partials is done
   if ((int)threadIdx.x < NV) reinterpret_cast<double*>(part)[threadIdx.x] = folded;
   __syncthreads();
+  FIN_STAMP(15);
   if (threadIdx.x == 0) {
     auto red = [&](int i) { return reinterpret_cast<const double*>(part)[i]; };
     // per-layer fp32 rounding, then fp32 adds, as the reference sums l1 + l2 + l3
     // (networks.py:174-181)
     float a_tot = 0.f, b_tot = 0.f;
-    for (int l = 0; l < p.n_layers; ++l) {
+#pragma unroll                                   // static indices into the constants: their loads batch, the layers' fp64 chains overlap
+    for (int l = 0; l < 8; ++l) {
+      if (l >= p.n_layers) break;
       double r0, r1, r2;
       if (l == own_layer) {
         r0 = own0; r1 = own1; r2 = own2;

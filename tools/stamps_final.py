@@ -17,8 +17,8 @@ ev = engine.GraphedElbo(net, x, y, 1, capture=False)
 for _ in range(300): ev.replay()
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 16)[:8]
-names = {1: "params", 2: "w ready", 3: "mfma done", 4: "prebarrier", 5: "barrier", 6: "slab/epilogue", 7: "ticket taken", 10: "tiles summed (last block)", 11: "fin_sample done"}
+names = {1: "params", 2: "w ready", 3: "mfma done", 4: "prebarrier", 5: "barrier", 6: "slab/epilogue", 7: "ticket taken", 10: "tiles summed (last block)", 11: "fin_sample done", 12: "fin: partials in", 13: "fin: nll done", 14: "fin: wave sums done", 15: "fin: folded"}
 for b in range(8):
     if d[b, 0] == 0: continue
     t0 = d[b, 0]
-    print(f"block {b}: " + "  ".join(f"{names[i]} {int(d[b, i] - t0)}" for i in (1, 2, 3, 4, 5, 6, 7, 10, 11) if d[b, i] > t0))
+    print(f"block {b}: " + "  ".join(f"{names[i]} {int(d[b, i] - t0)}" for i in (1, 2, 3, 4, 5, 6, 7, 10, 12, 13, 14, 15, 11) if d[b, i] > t0))
