@@ -564,6 +564,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       if (*flag == 0u) return;                                    // block-uniform
       __syncthreads();
       const float* tiles = fp->ks_tiles + (size_t)s * KS * (128 * 16);
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);                 // the slices' statistics: requested together with
+      if ((int)threadIdx.x < KS) q4 = fp->ks_stats[(size_t)s * KS + threadIdx.x];   // the tiles (one round trip, not two)
       for (int it = threadIdx.x; it < 128 * 4; it += blockDim.x) {   // (batch row, 4 consecutive features)
         const int brow = it >> 2, fg = it & 3;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -580,9 +582,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
             if (fg * 4 + i < N) yp[i] = v[i];
         }
       }
-      if (threadIdx.x < 64) {                                      // wave 0: one slice per lane, folded by shuffles
-        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((int)threadIdx.x < KS) q4 = fp->ks_stats[(size_t)s * KS + threadIdx.x];
+      if (threadIdx.x < 64) {                                      // wave 0: one slice per lane, folded by DPP sums
         own0 = wave_sum(q4.x);
         own1 = wave_sum(q4.y);
         own2 = wave_sum(q4.z);
