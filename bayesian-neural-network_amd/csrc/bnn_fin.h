@@ -138,6 +138,17 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
 #pragma unroll
             for (int i = 0; i < 16; ++i) se += (((i + b) & 15) < p.C) ? __expf(vr[i] - mx) : 0.f;
             se = __logf(se);
+          } else if (p.C <= 16) {
+            // a row in global memory: all of its loads issued at once (a rolled loop waits for each in turn)
+            float vr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vr[i] = row[min(i, p.C - 1)];
+            mx = vr[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = i < p.C ? fmaxf(mx, vr[i]) : mx;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) se += i < p.C ? __expf(vr[i] - mx) : 0.f;
+            se = __logf(se);
           } else {
             mx = row[0];
             for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
