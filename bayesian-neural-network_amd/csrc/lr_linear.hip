@@ -234,10 +234,20 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
             }
             if (MATH == BNN_MATH_BF16) {
               bf16x8 xb, x2b;
+              if (XDT == BNN_BF16) {
+                xb = __builtin_bit_cast(bf16x8, xraw[mm * R + cc]);      // already the MFMA operand
+              } else {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                xb[j] = (__bf16)xv[j];
-                x2b[j] = (__bf16)(xv[j] * xv[j]);
+                for (int j = 0; j < 8; ++j) xb[j] = (__bf16)xv[j];
+              }
+              // squares two at a time (v_pk_mul_f32): the x handling is what the vector pipe spends this kernel on
+              typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+              for (int j = 0; j < 8; j += 2) {
+                f32x2 pr = {xv[j], xv[j + 1]};
+                pr = pr * pr;
+                x2b[j] = (__bf16)pr[0];
+                x2b[j + 1] = (__bf16)pr[1];
               }
               am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? ma : wz, xb, am[m], 0, 0, 0);
               av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? sa : wz, x2b, av[m], 0, 0, 0);
