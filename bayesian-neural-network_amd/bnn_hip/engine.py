@@ -17,7 +17,12 @@ from .functional import AllReduceSumFn, BBBLinearFn, ElboFn, LayerCall, LRLinear
 from .runtime import state, take_samples
 
 
-CAST_INPUT_MIN_SAMPLES = 8    # below this the extra launch costs more than it saves
+CAST_INPUT_MIN_SAMPLES = 8    # BBB: below this the extra launch costs more than it saves
+# LR: from one sample on.  Its first layer squares every x fragment it loads, and fp32 x doubles the bytes each block
+# pulls through its CU's L1 (21.5 us for that layer against 14.7 us for the wider second one): casting first wins
+# even with the extra launch in the chain (one-sample evaluation 59.4 -> 55.3 us alone, 15.7 -> 14.6 us pipelined)
+CAST_INPUT_MIN_SAMPLES_LR = 1
+LR_SQUARES_MIN_SAMPLES = 8    # LR: carry x^2 (bf16) between layers from here on (the block-GEMM form streams it)
 # BBB: K-sliced GEMM form (deterministic split-K + reduce kernel) for this range of samples per launch.
 # Measured on MI355X it only ties the K-split kernel on the 1200-wide layers (29+5 us vs 32 us per layer
 # at 8 samples) but wins on big layers below the plain GEMM form's threshold (4096x4096, 4 samples:
@@ -90,9 +95,10 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     math_mode = state.math
     hidden_dtype = torch.float32 if (differentiable or math_mode == L.MATH_F32) else torch.bfloat16
     h, h_sq = x, None
-    lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= CAST_INPUT_MIN_SAMPLES and \
-        any(sp.lr for sp in layers)
-    if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES:
+    any_lr = any(sp.lr for sp in layers)
+    lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= LR_SQUARES_MIN_SAMPLES and any_lr
+    if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and \
+            n_local >= (CAST_INPUT_MIN_SAMPLES_LR if any_lr else CAST_INPUT_MIN_SAMPLES):
         # once per evaluation: every layer then streams 2-byte x (LR: and its elementwise square)
         if lr_sq:
             h, h_sq = ops.cast_bf16(x, want_sq=True)
@@ -338,8 +344,9 @@ class GraphedElbo:
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
-                    if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and S >= CAST_INPUT_MIN_SAMPLES) else None)
-        self.lr_sq = self.lr and self.x16 is not None
+                    if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
+                        S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) else None)
+        self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]

@@ -10,6 +10,7 @@ from bnn_hip import ops, _lib as L
 dev = torch.device("cuda:0")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 K, N, B = 1200, int(sys.argv[2]) if len(sys.argv) > 2 else 1200, 128
+CONC = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # the ABI's concurrency hint (4: the bench's tile plan)
 torch.manual_seed(0)
 wmu = torch.empty(N, K, device=dev).uniform_(-0.2, 0.2); wrho = torch.empty(N, K, device=dev).uniform_(-5, -4)
 bmu = torch.empty(N, device=dev).uniform_(-0.2, 0.2); brho = torch.empty(N, device=dev).uniform_(-5, -4)
@@ -20,7 +21,7 @@ ws = ops.bbb_workspace(S, N, dev); out = torch.empty(S, B, N, dtype=torch.bfloat
 def go():
     ops.bbb_linear_fwd(x, wmu, wrho, bmu, brho, n_samples=S, prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_BF16,
                        relu=True, y_dtype=torch.bfloat16, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1, want_stats=True,
-                       workspace=ws, out=out)
+                       workspace=ws, out=out, concurrency=CONC)
 for _ in range(3000): go()
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 16)
