@@ -97,8 +97,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     h, h_sq = x, None
     any_lr = any(sp.lr for sp in layers)
     lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= LR_SQUARES_MIN_SAMPLES and any_lr
-    if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and \
-            n_local >= (CAST_INPUT_MIN_SAMPLES_LR if any_lr else CAST_INPUT_MIN_SAMPLES):
+    if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES:   # (eager calls
+        # are host-bound: the one-sample LR cast of GraphedElbo would only add a launch here)
         # once per evaluation: every layer then streams 2-byte x (LR: and its elementwise square)
         if lr_sq:
             h, h_sq = ops.cast_bf16(x, want_sq=True)
