@@ -91,6 +91,8 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
 __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s, const int T[8], const float* lg, int ldc,
                                            int own_layer, float own0, float own1, float own2, float* part,
                                            float& out_a, float& out_b, float& out_nll, unsigned long long* dbg = nullptr) {
+// diagnostic build (-DBNN_STAMPS, tools/stamps_final.py) passes a stamp buffer; production callers pass none and
+// the stamps fold away
 #define FIN_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
   constexpr int NV = kFinNV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
