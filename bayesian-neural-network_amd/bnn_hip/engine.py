@@ -396,6 +396,7 @@ class GraphedElbo:
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
                       sample_counter_inc=self.samples * self.stride, out=self.out, sums=self.sums,
                       ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring)
+        pending = None
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
@@ -408,12 +409,19 @@ class GraphedElbo:
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]
+            elif i == last and pending is not None:
+                # one sample: the last hidden layer, the output layer and the finalize in ONE launch
+                ops.bbb_tail2_fwd(pending[0], pending[1], (h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
+                                  dict(workspaces=self.ws[:last - 1], **fin_kw))
             elif i == last:
                 if self.wsigma[i] is not None:
                     ops.softplus(p[1], out=self.wsigma[i])
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
                                                  w_sigma=self.wsigma[i], **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))
+            elif i == last - 1 and self.n_local == 1 and self.bufs[i].dtype == torch.bfloat16 and \
+                    h.dtype == torch.bfloat16 and self.split[i] is None and self.wsigma[i] is None:
+                pending = ((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common))   # launched with the last layer
             else:
                 if self.wsigma[i] is not None:
                     ops.softplus(p[1], out=self.wsigma[i])

@@ -322,6 +322,21 @@ def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
     return res, out
 
 
+def bbb_tail2_fwd(hidden_args: tuple, hidden_kw: dict, last_args: tuple, last_kw: dict, fin_kw: dict):
+    """Last hidden BBB layer + output layer + finalize through bnn_bbb_tail2_fwd (one launch for a one-sample
+    evaluation).  `last_args[0]` (the output layer's x) must be the hidden layer's `out` tensor; `fin_kw` carries the
+    workspaces of the layers BEFORE these two.  Returns (hidden result, last result, finalize result)."""
+    lib = L.load()
+    a2, res2, keep2 = _bbb_build(*hidden_args, **hidden_kw)
+    a3, res3, keep3 = _bbb_build(*last_args, **last_kw)
+    fin_kw = dict(fin_kw)
+    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res2["workspace"], res3["workspace"]]
+    fin_kw["logits"] = res3["y"]
+    f, out, keepf = _fin_build(**fin_kw)
+    L.check(lib.bnn_bbb_tail2_fwd(C.byref(a2), C.byref(a3), C.byref(f), _stream()), "bnn_bbb_tail2_fwd")
+    return res2, res3, out
+
+
 def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int, rows: int, cols: int,
                   device) -> torch.Tensor:
     """The on-chip epsilon stream, materialised: float32[n_samples, rows, cols]."""

@@ -258,8 +258,11 @@ struct FinPack {
 // output features): kernel "feature" n = original input index, kernel reduction index k =
 // original output index, weight element (k, n) lives at w[k * ldw + n]; its eps is slot n & 3 of
 // Philox group (k, n >> 2).  No bias, no statistics.
+// Returns false for the padding blocks of the XCD-aware grid (no work done).  `forced_item` >= 0 runs that
+// work item whatever the block index is (the fused-tail kernel hands the last layer to whichever block
+// finished the layer before it last).
 template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false>
-__device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
+__device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, int forced_item = -1) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -269,7 +272,8 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
   int item;
   const int KS = FINAL ? fp->ks : 1;                          // K-range slices per sample (FINAL only)
-  if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return;   // block-uniform
+  if (forced_item >= 0) item = forced_item;
+  else if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return false;   // block-uniform
   const int ks = item % KS;
   item /= KS;
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
@@ -561,7 +565,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       }
       __syncthreads();
       BNN_STAMP(7);
-      if (*flag == 0u) return;                                    // block-uniform
+      if (*flag == 0u) return true;                               // block-uniform
       __syncthreads();
       const float* tiles = fp->ks_tiles + (size_t)s * KS * (128 * 16);
       float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);                 // the slices' statistics: requested together with
@@ -638,6 +642,7 @@ __device__ __forceinline__ void bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       }
     }
   }
+  return true;
 }
 
 template <int MATH, int XDT, int R, bool ALIGNED>
@@ -648,6 +653,40 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
 template <int MATH, int XDT>
 __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const FinPack fp) {
   bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
+}
+
+// K1d  one-sample tail of an evaluation in ONE launch: the last hidden layer (K1a, any tile plan) and, run by
+// whichever of its blocks finishes last, the output layer + finalize (K1c without K-slices).  Every block
+// drains its stores, one lane releases at agent scope and takes a ticket; the last arriver acquires and
+// carries on (no block ever waits for another: placement-independent, guide G16).  Saves a dependent launch
+// and the K-slice hand-off of the separate last-layer kernel on the latency chain of a one-sample evaluation.
+template <int MATH, int R2>
+__global__ __launch_bounds__(768) void bbb_fwd_tail2_kernel(const BbbK p2, const BbbK p3, const FinPack fp,
+                                                            uint32_t* ticket, uint32_t n_real_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // word 0 doubles as the "I am last" flag between the two
+  uint32_t& last_flag = *reinterpret_cast<uint32_t*>(lds);      // bodies (static LDS would eat into the 160 KiB the slabs need)
+  const bool real = bbb_fwd_body<MATH, BNN_BF16, R2, true, false>(p2, nullptr);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores of the layer's outputs and statistics
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t last = 0u;
+    if (real) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == n_real_blocks - 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *ticket = 0u;                                    // ready for the next launch
+        last = 1u;
+      }
+    }
+    last_flag = last;
+  }
+  __syncthreads();
+  if (last_flag == 0u) return;                           // block-uniform
+  __syncthreads();
+  bbb_fwd_body<MATH, BNN_BF16, 1, true, true>(p3, &fp, 0);
 }
 
 template <int MATH, int R, bool ALIGNED>
@@ -1246,6 +1285,68 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   if (err != hipSuccess) return (int)err;
   if (tail_kernel) return bnn_elbo_sums_(f, stream_);
   return BNN_OK;
+}
+
+// The last hidden layer + the output layer + finalize of a ONE-sample evaluation in one launch (K1d) when the
+// shapes allow it and BNN_HIP_FUSE_TAIL2=1; otherwise bnn_bbb_linear_fwd(hidden) followed by
+// bnn_bbb_final_fwd(last, fin).  OFF by default: measured on MI355X the single block that inherits the output
+// layer (38 k-steps over its 12 waves, all of the hidden activations through one CU's L1) takes longer than the
+// dependent launch of five K-slice blocks it replaces: 47.0 against 40.3 us per evaluation alone, 13.8 against
+// 11.7 us with four in flight.
+extern "C" int bnn_bbb_tail2_fwd(const bnn_bbb_fwd_args* hidden, const bnn_bbb_fwd_args* last, const bnn_finalize_args* f,
+                                 void* stream_) {
+  BbbK k2, k3;
+  bool al2 = false, al3 = false;
+  int rc = prepare(hidden, k2, al2);
+  if (rc != BNN_OK) return rc;
+  rc = prepare(last, k3, al3);
+  if (rc != BNN_OK) return rc;
+  FinPack fp;
+  rc = make_fin(f, fp.k, fp.c);
+  if (rc != BNN_OK) return rc;
+  const int nl = f->n_layers;
+  const long gemm_blocks = (long)((hidden->out_features + 63) / 64) * hidden->n_samples * ((hidden->batch + 127) / 128);
+  const bool fuse =
+      env_int("BNN_HIP_FUSE_TAIL2", 0) != 0 && f->ticket != nullptr && hidden->n_samples == 1 && last->n_samples == 1 &&
+      f->n_samples == 1 && nl >= 2 && al2 && al3 && hidden->math == BNN_MATH_BF16 && last->math == BNN_MATH_BF16 &&
+      hidden->x_dtype == BNN_BF16 && hidden->y_dtype == BNN_BF16 && last->x_dtype == BNN_BF16 && last->x == hidden->y &&
+      last->x_per_sample == 1 && last->in_features == hidden->out_features && last->batch == hidden->batch &&
+      hidden->batch <= 128 && last->out_features <= 16 && hidden->want_stats && last->want_stats && !f->local_reparam &&
+      f->layer_workspace[nl - 1] == last->workspace && f->layer_workspace[nl - 2] == hidden->workspace &&
+      f->classes == last->out_features && f->batch == last->batch && last->y_dtype == BNN_F32 &&
+      !(hidden->log_prior || hidden->log_q || last->log_prior || last->log_q) && !hidden->split_scratch &&
+      gemm_blocks < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1;
+  if (!fuse) {
+    rc = bnn_bbb_linear_fwd(hidden, stream_);
+    if (rc != BNN_OK) return rc;
+    return bnn_bbb_final_fwd(last, f, stream_);
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  fp.sums = f->sums;
+  fp.ticket = nullptr;                                  // one sample: the finalising block writes the sums itself
+  fp.ks = 1;
+  fp.ks_ticket = nullptr;
+  fp.ks_stats = nullptr;
+  fp.ks_tiles = nullptr;
+  const Plan pl = make_plan(1, hidden->batch, hidden->in_features, hidden->out_features, true, hidden->concurrency);
+  const long total = (long)pl.tiles;                    // one sample, one batch block
+  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
+  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw + 128 * 16 + kFinMaxWaves * kFinNV + 2) * sizeof(float);
+  hipError_t err = hipSuccess;
+#define BNN_T2(RR)                                                                                                   \
+  do {                                                                                                               \
+    err = allow_big_lds(bbb_fwd_tail2_kernel<BNN_MATH_BF16, RR>, lds);                                               \
+    if (err == hipSuccess)                                                                                           \
+      hipLaunchKernelGGL((bbb_fwd_tail2_kernel<BNN_MATH_BF16, RR>), grid, block, lds, stream, k2, k3, fp, f->ticket, \
+                         (uint32_t)total);                                                                           \
+  } while (0)
+  if (pl.R == 1) BNN_T2(1);
+  else if (pl.R == 2) BNN_T2(2);
+  else BNN_T2(4);
+#undef BNN_T2
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
 }
 
 // gx[S,B,K] = gz[S,B,N] . w_s with w regenerated (TRANS form of the K-split kernel).  Called by

@@ -290,6 +290,16 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
 size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 
+/* bnn_bbb_tail2_fwd — the last HIDDEN layer, the output layer and the finalize of a ONE-sample evaluation in one
+ * launch: the same results as bnn_bbb_linear_fwd(hidden) followed by bnn_bbb_final_fwd(last, fin) with
+ * last->x == hidden->y (bf16) and fin's two last workspaces those of the two layers, but whichever block of the
+ * hidden layer finishes last carries on with the output layer and the finalize (fin->ticket: one zero-initialised
+ * device word).  Falls back to the two calls when the shapes or modes do not allow it (more than one sample,
+ * fp32 math, an output layer wider than 16, ...) and, by default, always: the fused form measured slower on
+ * MI355X (see the source); BNN_HIP_FUSE_TAIL2=1 enables it. */
+int bnn_bbb_tail2_fwd(const bnn_bbb_fwd_args* hidden, const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------
  * bnn_bbb_linear_bwd — backward of BayesianLinear for n_samples MC samples (what autograd
  * derives from networks.py:73-88 under classification/class_task.py:78 `loss.backward()`;

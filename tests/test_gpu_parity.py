@@ -736,3 +736,36 @@ def test_misaligned_operands_are_rejected_or_handled(dev):
         ops.bbb_linear_bwd(x3, gy, None, w_bad, wr, bm, br, n_samples=1, prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_F32,
                            relu=False, eps_mode=L.EPS_PHILOX, seed=1, layer_id=0, want_gx=False)
     assert seen <= {"refused", "handled"} and seen
+
+
+@pytest.mark.parametrize("conc", [1, 4])
+def test_fused_tail_of_a_one_sample_evaluation_equals_separate_launches(dev, monkeypatch, conc):
+    """bnn_bbb_tail2_fwd (last hidden layer + output layer + finalize in one launch: the block that finishes
+    the hidden layer last carries on) gives the scalars, logits and hidden activations of the separate
+    launches, replay after replay (ticket reset, device sample counter), for both tile plans the engine
+    uses (one evaluation alone / four side by side)."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("BNN_HIP_FUSE_TAIL2", fuse)
+        bnn_hip.manual_seed(31, counter=400)
+        ev = engine.GraphedElbo(net, xd, yd, 1, counter_stride=conc)
+        rec = []
+        for _ in range(4):
+            sums = ev.replay().clone()
+            rec.append((sums, {k: v.clone() for k, v in ev.out.items()}, ev.logits.clone(), ev.bufs[1].float().clone()))
+        outs.append((rec, int(ev.counter.item()), int(ev.ticket.item())))
+    (ra, ca, ta), (rb, cb, tb) = outs
+    assert ca == cb and ta == 0 and tb == 0                     # same sample indices drawn; ticket back at zero
+    for (sa, pa, la, ha), (sb, pb, lb, hb) in zip(ra, rb):
+        assert torch.equal(ha, hb)                               # the hidden layer is the same kernel body: bitwise
+        scale = float(lb.abs().max())
+        assert float((la - lb).abs().max()) <= 2e-3 * scale      # output layer: one block instead of K-slices (fp32 sum order)
+        for k in pa:
+            close(pa[k], pb[k].cpu().numpy(), rtol=1e-3 if k == "nll" else 2e-6)
+        close(sa, sb.cpu().numpy(), rtol=1e-3)
+    assert not torch.equal(ra[0][0], ra[1][0])                   # fresh eps on every replay
