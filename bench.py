@@ -73,7 +73,8 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     nstr = len(evs)
     E = evs[0].per_replay
     assert steps % E == 0 and warmup % E == 0 and (dist is None or ar_every % E == 0)
-    main = torch.cuda.current_stream()
+    have_gpu = torch.cuda.is_available()                   # (the CPU test of this bookkeeping runs it over gloo)
+    main = torch.cuda.current_stream() if have_gpu else None
     per_flush = nstr * ar_every // E                    # replays between two all-reduces
     works = [None, None]
     flushed = []
@@ -114,7 +115,8 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
                 if w is not None:
                     w.wait()
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
     nw, ns = warmup // E, steps // E
     for i in range(nw):
@@ -126,7 +128,7 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     barrier(nw + ns)
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=slab.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=slab.device)   # NCCL reduces device tensors only
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     run_steps.last_flushed_half = flushed[-1] if flushed else None

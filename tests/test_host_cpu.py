@@ -190,3 +190,57 @@ def test_two_rank_gloo_sample_sharding(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+BENCH_WORKER = textwrap.dedent(r'''
+    import os, sys
+    sys.path.insert(0, r"{repo}"); sys.path.insert(0, os.path.join(r"{repo}", "bayesian-neural-network_amd"))
+    import torch, torch.distributed as dist
+    import bench
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeEvaluator:
+        """Stands in for engine.GraphedElbo: a replay runs `per_replay` evaluations, each depositing its
+        4-vector {{evaluation index, rank, 0, 1}} at the device-side ring cursor (here a Python int)."""
+        def __init__(self, slab, j, n, per_replay):
+            self.slab, self.j, self.n, self.per_replay, self.stream, self.pos, self.count = slab, j, n, per_replay, None, 0, 0
+        def replay(self):
+            for _ in range(self.per_replay):
+                self.slab[self.pos, self.j] = torch.tensor([float(self.count * self.n + self.j), float(rank), 0.0, 1.0])
+                self.pos = (self.pos + 1) % self.slab.shape[0]
+                self.count += 1
+
+    for (nstr, E, ar_every, warmup, steps) in ((3, 4, 16, 24, 120), (4, 2, 8, 10, 46), (1, 1, 4, 3, 9)):
+        slab = torch.zeros((2 * ar_every, nstr, 4))
+        evs = [FakeEvaluator(slab, j, nstr, E) for j in range(nstr)]
+        dt = bench.run_steps(evs, steps, warmup, dist, slab, ar_every)
+        assert dt > 0
+        h = bench.run_steps.last_flushed_half
+        if h is not None:                                   # every row of the last fully reduced half: summed over the ranks
+            rows = slab[h * ar_every:(h + 1) * ar_every]
+            assert bool((rows[:, :, 3] == float(world)).all()), rows[:, :, 3]
+            assert bool((rows[:, :, 1] == sum(range(world))).all())
+            idx = rows[:, :, 0] / world                     # the same evaluation index on every rank
+            assert bool((idx == idx.round()).all())
+        total = sum(e.count for e in evs)
+        assert total == warmup + steps, (total, warmup, steps)
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+''')
+
+
+def test_bench_ring_allreduce_bookkeeping_two_ranks(tmp_path):
+    """bench.run_steps' N>1 bookkeeping (ring halves, one all-reduce per half, partial flush at the barriers,
+    matching collective counts on every rank) on 2 ranks over gloo with stand-in evaluators: no hang, every
+    fully flushed row is the sum over the ranks, exactly warmup + steps evaluations ran."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER.format(repo=REPO))
+    port = str(30500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert f"rank {r} ok" in o
