@@ -257,7 +257,8 @@ class ElboFn(torch.autograd.Function):
         sums = torch.empty(4, dtype=torch.float32, device=h.device)
         ops.elbo_finalize(workspaces=wss, layer_in=[l[4] for l in call.layers], layer_out=[l[5] for l in call.layers],
                           local_reparam=lr_net, prior=call.layers[0][3], n_samples=S, logits=h, target=target, mode=call.mode,
-                          nll_sigma=call.sigma, sums=sums)
+                          nll_sigma=call.sigma, sums=sums,
+                          ticket=torch.zeros(1, dtype=torch.int32, device=h.device) if S > 1 else None)
         ctx.call = call
         ctx.n_saved = len(saved)
         ctx.save_for_backward(target, *params, *saved)

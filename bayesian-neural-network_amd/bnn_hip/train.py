@@ -57,6 +57,7 @@ class GraphedTrainStep:
         self.x, self.y = x.clone(), y.clone()
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
         self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
         offs, tot = [], 0
@@ -141,7 +142,8 @@ class GraphedTrainStep:
             h = out["y"]
         fin = ops.elbo_finalize(workspaces=wss, layer_in=[sp.in_out[0] for sp in specs],
                                 layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr, prior=specs[0].m._prior_spec,
-                                n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma)
+                                n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma,
+                                ticket=self.fin_ticket if S > 1 else None)
         out4, g_a, g_b, g_nll, g_kl3 = ops.elbo_loss(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
                                                      fin["nll"], self.beta, S, lr, grad_scale=1.0 / self.world)
         g = ops.nll_bwd(h, self.y, g_nll, net.mode, self.sigma)

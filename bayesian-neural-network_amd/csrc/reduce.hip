@@ -97,9 +97,12 @@ static inline int kl_blocks(long n) {
 }
 
 // ----------------------------------------------------------------------------- K4
-// grid = n_samples blocks (one sample each), or ONE block looping over all samples when
-// `single` (small n_samples): then the block also writes the 4-vector of sums, in sample order.
-__global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums) {
+// grid = n_samples blocks (one sample each), or ONE block looping over all samples when `single`: then the
+// block also writes the 4-vector of sums, in sample order.  With a `ticket` word the one-block-per-sample form
+// does that too: the last-arriving block folds the per-sample scalars (release / ticket / acquire, nobody
+// waits), so a handful of samples is finalized in parallel and still in one launch (8 samples: 31.7 us serially).
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums,
+                                                            uint32_t* ticket) {
   __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
   int T[8];
 #pragma unroll
@@ -119,14 +122,45 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
     }
     if (s + 1 < s_end) __syncthreads();
   }
-  if (single && sums && threadIdx.x == 0) {
-    sums = fin_sums_slot(p, sums);
-    sums[0] = (float)tot_a;
-    sums[1] = (float)tot_b;
-    sums[2] = (float)tot_n;
-    sums[3] = (float)p.S;
+  if (single) {
+    if (threadIdx.x == 0) {
+      if (sums) {
+        sums = fin_sums_slot(p, sums);
+        sums[0] = (float)tot_a;
+        sums[1] = (float)tot_b;
+        sums[2] = (float)tot_n;
+        sums[3] = (float)p.S;
+      }
+      if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
+    }
+    return;
   }
-  if (p.sample_counter && blockIdx.x == 0 && threadIdx.x == 0) *p.sample_counter += p.sample_counter_inc;
+  if (!ticket) {                                             // the sums (if any) come from a follow-up launch
+    if (p.sample_counter && blockIdx.x == 0 && threadIdx.x == 0) *p.sample_counter += p.sample_counter_inc;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == (uint32_t)p.S - 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (sums) {
+        double ta = 0, tb = 0, tn = 0;
+        const float* pa = p.local_reparam ? p.kl : p.log_prior;
+        for (int i = 0; i < p.S; ++i) {                      // sample order: the sums do not depend on who arrived when
+          if (pa) ta += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!p.local_reparam && p.log_q) tb += __hip_atomic_load(p.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p.nll) tn += __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float* so = fin_sums_slot(p, sums);
+        so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)p.S;
+      }
+      *ticket = 0u;
+      if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
+    }
+  }
 }
 
 // Sum of the per-sample scalars over the local samples, in index order per thread and a
@@ -358,14 +392,17 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   const int rc = make_fin(a, k, cst);
   if (rc != BNN_OK) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  // few samples with small logits: one block walks them all and also writes the sums (one launch);
-  // otherwise a block per sample
-  const int single = a->n_samples <= 16 && (long)a->n_samples * a->batch * a->classes <= 65536;
-  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single,
-                     a->sums);
+  // one sample, or a few with small logits and no ticket word to fold them in parallel: one block walks them all
+  // and writes the sums; otherwise a block per sample, the sums folded by the last arriver (ticket) or by a
+  // follow-up launch
+  const bool small = (long)a->n_samples * a->batch * a->classes <= 65536;
+  const bool ticketed = a->n_samples > 1 && a->n_samples <= 64 && a->ticket != nullptr;
+  const int single = a->n_samples == 1 || (a->n_samples <= 16 && small && !ticketed);
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single, a->sums,
+                     (single || !ticketed) ? (uint32_t*)nullptr : a->ticket);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  if (a->sums && !single) {
+  if (a->sums && !single && !ticketed) {
     const float* first = a->local_reparam ? a->kl : a->log_prior;
     const float* second = a->local_reparam ? nullptr : a->log_q;
     hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples, a->sums,

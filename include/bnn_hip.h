@@ -264,8 +264,9 @@ typedef struct bnn_finalize_args {
   float* sums;                      /* optional float[4]: sums over the n_samples local samples of
                                        {log p | KL, log q | 0, nll, n_samples}: the vector a sharded
                                        job all-reduces (fixed summation order) */
-  uint32_t* ticket;                 /* optional zero-initialised device word used by the fused
-                                       last-layer form (bnn_bbb_final_fwd) when n_samples > 1 */
+  uint32_t* ticket;                 /* optional zero-initialised device word (left at zero again): lets 2..64 samples be
+                                       finalized by one block each IN ONE launch, the last arriver folding `sums`
+                                       (bnn_elbo_finalize and the fused last-layer form bnn_bbb_final_fwd) */
   void* scratch;                    /* optional, bnn_bbb_final_scratch_bytes(n_samples) bytes, 16-byte
                                        aligned, ZEROED ONCE by the caller: lets the fused last layer
                                        split its K range over several blocks per sample */
