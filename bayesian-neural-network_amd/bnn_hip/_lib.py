@@ -20,6 +20,7 @@ EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
+    "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
@@ -80,7 +81,7 @@ class BbbBwdArgs(C.Structure):
         ("eps_mode", C.c_int32), ("math", C.c_int32),
         ("eps_w", C.c_void_p), ("eps_b", C.c_void_p),
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
-        ("prior", Prior), ("reserved", C.c_int32),
+        ("prior", Prior), ("gx_relu_mask", C.c_int32),
         ("g_log_prior", C.c_void_p), ("g_log_q", C.c_void_p),
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p),
@@ -99,7 +100,7 @@ class LrBwdArgs(C.Structure):
         ("eps_mode", C.c_int32), ("reserved", C.c_int32),
         ("eps_act", C.c_void_p), ("eps_b", C.c_void_p),
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
-        ("sigma_p", C.c_float), ("reserved2", C.c_int32),
+        ("sigma_p", C.c_float), ("gx_relu_mask", C.c_int32),
         ("g_kl", C.c_void_p),
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
@@ -117,8 +118,9 @@ class AdamArgs(C.Structure):
         ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
         ("numel", C.c_int64 * ADAM_MAX_TENSORS),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
-        ("step", C.c_uint32), ("reserved0", C.c_uint32),
+        ("step", C.c_uint32), ("bump_by", C.c_uint32),
         ("lr_device", C.c_void_p), ("step_device", C.c_void_p), ("step_advance", C.c_int32), ("reserved", C.c_int32),
+        ("ticket", C.c_void_p), ("bump_counter", C.c_void_p),
     ]
 
 
@@ -181,6 +183,13 @@ def load():
     lib.bnn_elbo_loss.restype = C.c_int
     lib.bnn_elbo_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bnn_elbo_loss_nll_bwd.restype = C.c_int
+    lib.bnn_elbo_loss_nll_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    lib.bnn_stage_inputs.restype = C.c_int
+    lib.bnn_stage_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_float, C.c_void_p]
     lib.bnn_nll_bwd.restype = C.c_int
     lib.bnn_nll_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_float, C.c_void_p]

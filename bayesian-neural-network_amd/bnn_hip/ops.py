@@ -395,7 +395,8 @@ def _grad_outputs(out, w_mu, w_rho, b_mu, b_rho):
 
 def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
                    eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
-                   g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None, out=None):
+                   g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None, out=None,
+                   gx_relu_mask: bool = False):
     """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
     (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
     lib = L.load()
@@ -430,6 +431,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
     a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
     a.g_x = _ptr(gx)
+    a.gx_relu_mask = int(bool(gx_relu_mask) and want_gx)
     ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     a.sample_counter = _ptr(sample_counter)
@@ -439,7 +441,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
 
 def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
                   eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
-                  want_gx: bool = True, sample_counter=None, out=None):
+                  want_gx: bool = True, sample_counter=None, out=None, gx_relu_mask: bool = False):
     """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
     saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
     Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
@@ -474,6 +476,7 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
     gx = torch.empty((n_samples, B, K), dtype=torch.float32, device=dev) if want_gx else None
     a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
     a.g_x = _ptr(gx)
+    a.gx_relu_mask = int(bool(gx_relu_mask) and want_gx)
     ws = torch.empty(lib.bnn_lr_linear_bwd_workspace_bytes(n_samples, B, K, N, int(want_gx)) // 4, dtype=torch.float32,
                      device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -512,15 +515,7 @@ def elbo_loss(a, b, nll, beta, total_samples: int, local_reparam: bool, grad_sca
     return out4, g_a, g_b, g_nll, g_kl3
 
 
-def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
-    """Gradient of the per-sample summed NLL w.r.t. logits[S,B,C] scaled by g_nll[S] (bnn_nll_bwd)."""
-    lib = L.load()
-    require_device(logits, target, g_nll)
-    lg = _f32c(logits, "logits")
-    S, B, Cc = lg.shape
-    gn = _f32c(g_nll.reshape(-1), "g_nll")
-    if gn.numel() != S:
-        raise BnnHipError("g_nll must have one element per MC sample")
+def _nll_target(target, mode: str, B: int, Cc: int):
     if mode == "classification":
         tg, m = target.to(torch.int64).contiguous(), L.NLL_CLASSIFICATION
         if tg.numel() != B:
@@ -531,6 +526,57 @@ def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
             raise BnnHipError("regression target must match the output shape")
     else:
         raise Exception("Training mode must be either 'regression' or 'classification'")
+    return tg, m
+
+
+def elbo_loss_nll_bwd(a, b, nll, beta, total_samples: int, local_reparam: bool, logits, target, mode: str,
+                      sigma: float = 1.0, grad_scale: float = 1.0):
+    """bnn_elbo_loss_nll_bwd: elbo_loss + nll_bwd in one launch.  Returns (out4, g_a, g_b, g_kl3, g_logits)."""
+    lib = L.load()
+    require_device(a, b, nll, beta, logits, target)
+    lg = _f32c(logits, "logits")
+    S, B, Cc = lg.shape
+    if nll.numel() != S:
+        raise BnnHipError("nll must have one element per MC sample")
+    tg, m = _nll_target(target, mode, B, Cc)
+    dev = nll.device
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    g_a = torch.empty(S, dtype=torch.float32, device=dev)
+    g_b = torch.empty(S, dtype=torch.float32, device=dev)
+    g_kl3 = torch.empty(3, dtype=torch.float32, device=dev)
+    g_logits = torch.empty_like(lg)
+    L.check(lib.bnn_elbo_loss_nll_bwd(a.data_ptr(), _ptr(b), nll.data_ptr(), beta.data_ptr(), S, float(total_samples),
+                                      float(grad_scale), int(local_reparam), out4.data_ptr(), g_a.data_ptr(), g_b.data_ptr(),
+                                      g_kl3.data_ptr(), lg.data_ptr(), tg.data_ptr(), g_logits.data_ptr(), B, Cc, m,
+                                      float(sigma), _stream()), "bnn_elbo_loss_nll_bwd")
+    return out4, g_a, g_b, g_kl3, g_logits
+
+
+def stage_inputs(src0, dst0, src1=None, dst1=None, word=None, value: float = 0.0):
+    """bnn_stage_inputs: dst0 <- src0, dst1 <- src1 (same dtype, shape; contiguous device tensors), *word = value,
+    one launch."""
+    lib = L.load()
+    require_device(src0, dst0, src1, dst1, word)
+    for s_, d_ in ((src0, dst0), (src1, dst1)):
+        if s_ is None:
+            continue
+        if s_.dtype != d_.dtype or s_.numel() != d_.numel() or not s_.is_contiguous() or not d_.is_contiguous():
+            raise BnnHipError("stage_inputs: source and destination must be contiguous, same dtype and size")
+    nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+    L.check(lib.bnn_stage_inputs(_ptr(src0), _ptr(dst0), nb(src0), _ptr(src1), _ptr(dst1), nb(src1), _ptr(word), float(value),
+                                 _stream()), "bnn_stage_inputs")
+
+
+def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
+    """Gradient of the per-sample summed NLL w.r.t. logits[S,B,C] scaled by g_nll[S] (bnn_nll_bwd)."""
+    lib = L.load()
+    require_device(logits, target, g_nll)
+    lg = _f32c(logits, "logits")
+    S, B, Cc = lg.shape
+    gn = _f32c(g_nll.reshape(-1), "g_nll")
+    if gn.numel() != S:
+        raise BnnHipError("g_nll must have one element per MC sample")
+    tg, m = _nll_target(target, mode, B, Cc)
     out = torch.empty_like(lg)
     L.check(lib.bnn_nll_bwd(lg.data_ptr(), tg.data_ptr(), gn.data_ptr(), out.data_ptr(), S, B, Cc, m, float(sigma), _stream()),
             "bnn_nll_bwd")
@@ -538,8 +584,9 @@ def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
 
 
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: float, weight_decay: float, step: int = 0,
-              lr_device=None, step_device=None):
-    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch)."""
+              lr_device=None, step_device=None, ticket=None, bump_counter=None, bump_by: int = 0):
+    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch).  With `ticket` (zeroed uint32 device
+    word) the device step advances inside the first launch, which also adds bump_by to *bump_counter."""
     lib = L.load()
     n = len(params)
     for lo in range(0, n, L.ADAM_MAX_TENSORS):
@@ -561,6 +608,12 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: fl
         a.lr_device = _ptr(lr_device)
         a.step_device = _ptr(step_device)
         a.step_advance = int(lo == 0)                   # the first launch of the step advances the device counter
+        if lo == 0 and ticket is not None and step_device is not None:
+            a.ticket = ticket.data_ptr()
+            if bump_counter is not None:
+                a.bump_counter, a.bump_by = bump_counter.data_ptr(), int(bump_by)
+        elif bump_counter is not None and lo == 0:
+            raise BnnHipError("adam_step: bump_counter needs a device step and a ticket word")
         L.check(lib.bnn_adam_step(C.byref(a), _stream()), "bnn_adam_step")
 
 

@@ -27,13 +27,20 @@ class FusedAdam(torch.optim.Optimizer):
         if not 0.0 <= weight_decay:
             raise ValueError(f"Invalid weight_decay value: {weight_decay}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable))
-        self._dev = {}            # group index -> (step int32[1], lr float32[1], last lr written)
+        self._dev = {}            # group index -> (step int32[1], lr float32[1], last lr written, ticket int32[1])
+        self._bump = None         # (uint32 device word, increment): advanced inside the step's launch
+
+    def bump_after_step(self, counter: torch.Tensor, inc: int):
+        """Capturable optimisers only: the (first group's) update launch also adds `inc` to the device word
+        `counter` -- train.GraphedTrainStep's MC-sample counter, advanced once the backward has read it."""
+        self._bump = (counter, int(inc))
 
     def _group_dev(self, gi, group, device):
         if gi not in self._dev:
             steps = [int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
             self._dev[gi] = [torch.tensor([max(steps) if steps else 0], dtype=torch.int32, device=device),
-                             torch.tensor([group["lr"]], dtype=torch.float32, device=device), group["lr"]]
+                             torch.tensor([group["lr"]], dtype=torch.float32, device=device), group["lr"],
+                             torch.zeros(1, dtype=torch.int32, device=device)]
         return self._dev[gi]
 
     def sync_lr(self):
@@ -73,10 +80,12 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             kw = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
             if group["capturable"]:
-                step_dev, lr_dev, _ = self._group_dev(gi, group, ps[0].device)
+                step_dev, lr_dev, _, ticket = self._group_dev(gi, group, ps[0].device)
                 if not torch.cuda.is_current_stream_capturing():
                     self.sync_lr()
-                ops.adam_step(ps, gs, ms, vs, lr_device=lr_dev, step_device=step_dev, **kw)
+                bump = self._bump if gi == 0 and self._bump is not None else (None, 0)
+                ops.adam_step(ps, gs, ms, vs, lr_device=lr_dev, step_device=step_dev, ticket=ticket,
+                              bump_counter=bump[0], bump_by=bump[1], **kw)
             else:
                 step = int(self.state[ps[0]]["step"]) + 1
                 for p in ps:

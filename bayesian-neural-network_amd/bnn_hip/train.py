@@ -11,8 +11,8 @@ capturable mode; StepLR keeps working through FusedAdam.sync_lr()).
 
 Two forms of the captured step: `autograd=True` records exactly what the eager loop runs
 (torch.autograd over the HIP-kernel Functions); the default chains the same kernels by hand —
-layer forwards, bnn_elbo_finalize, bnn_elbo_loss (loss + backward seeds), bnn_nll_bwd, the layer
-backwards, bnn_adam_step — without autograd's bookkeeping kernels (zero fills, gradient
+layer forwards, bnn_elbo_finalize, bnn_elbo_loss_nll_bwd (loss, backward seeds, d nll / d logits), the
+layer backwards (each layer's ReLU mask applied by the input-gradient kernel above it), bnn_adam_step — without autograd's bookkeeping kernels (zero fills, gradient
 accumulation, per-layer scalar launches): about a third fewer microseconds per step.
 """
 from __future__ import annotations
@@ -68,6 +68,8 @@ class GraphedTrainStep:
         self.grad_views = [self.bucket[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self._elbo = net.sample_elbo_lr if net.local_reparam else net.sample_elbo
         self.first = take_samples(0)
+        # the step's MC-sample counter advances inside Adam's launch (after the backward re-read it)
+        optimizer.bump_after_step(self.counter, self.samples * self.world)
 
         # ---- warm-up on a side stream (allocator pools, lazy inits), then undo its effects
         params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -144,19 +146,25 @@ class GraphedTrainStep:
                                 layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr, prior=specs[0].m._prior_spec,
                                 n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma,
                                 ticket=self.fin_ticket if S > 1 else None)
-        out4, g_a, g_b, g_nll, g_kl3 = ops.elbo_loss(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
-                                                     fin["nll"], self.beta, S, lr, grad_scale=1.0 / self.world)
-        g = ops.nll_bwd(h, self.y, g_nll, net.mode, self.sigma)
+        # loss, backward seeds and d nll / d logits in one launch (the NLL seed is the constant 1 / (S ranks))
+        out4, g_a, g_b, g_kl3, g = ops.elbo_loss_nll_bwd(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
+                                                         fin["nll"], self.beta, S, lr, h, self.y, net.mode, self.sigma,
+                                                         grad_scale=1.0 / self.world)
+        top = len(specs) - 1
         for i in reversed(range(len(specs))):
             sp = specs[i]
             xin, y, v, p = saved[i]
-            kw = dict(n_samples=S, relu=sp.relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
-                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4])
+            # layer i's ReLU mask is applied by layer i+1's input-gradient kernel (its x IS layer i's output),
+            # so only a top layer with a ReLU masks its own gy
+            own_relu = sp.relu and i == top
+            kw = dict(n_samples=S, relu=own_relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
+                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4],
+                      gx_relu_mask=i > 0 and specs[i - 1].relu)
             if sp.lr:
-                grads = ops.lr_linear_bwd(xin, g, y if sp.relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
+                grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
                                           **kw)
             else:
-                grads = ops.bbb_linear_bwd(xin, g, y if sp.relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
+                grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
                                            g_log_prior=g_a, g_log_q=g_b, **kw)
             sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
             g = grads[4]
@@ -166,8 +174,7 @@ class GraphedTrainStep:
 
     def _update(self):
         with torch.no_grad():
-            self.opt.step()
-            self.counter.add_(self.samples * self.world)
+            self.opt.step()                          # also advances self.counter (bump_after_step)
 
     def _allreduce(self):
         import torch.distributed as dist
@@ -186,8 +193,7 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)
             out = self._elbo(self.x, self.y, self.beta, self.samples, self.sigma)
             out[0].backward()
-            self.opt.step()
-            self.counter.add_(self.samples)          # the next step's MC samples: fresh Philox subsequences
+            self.opt.step()                          # also advances self.counter: the next step draws fresh eps
         finally:
             state.device_counter = None
         return tuple(o.detach() for o in out)
@@ -195,9 +201,13 @@ class GraphedTrainStep:
     def step(self, x: torch.Tensor, y: torch.Tensor, beta: float):
         """One optimiser step on minibatch (x, y) with KL weight beta.  Returns the tuple
         sample_elbo* returns (static tensors: read them before the next call)."""
-        self.x.copy_(x, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
-        self.beta.fill_(float(beta))
+        if (x.is_cuda and y.is_cuda and x.dtype == self.x.dtype and y.dtype == self.y.dtype and x.is_contiguous()
+                and y.is_contiguous() and x.numel() == self.x.numel() and y.numel() == self.y.numel()):
+            ops.stage_inputs(x, self.x, y, self.y, self.beta, float(beta))       # one launch instead of three
+        else:
+            self.x.copy_(x, non_blocking=True)
+            self.y.copy_(y, non_blocking=True)
+            self.beta.fill_(float(beta))
         self.opt.sync_lr()
         self.graph.replay()
         if self.dp:

@@ -48,7 +48,24 @@ struct BwdK {
   const uint32_t* sample_counter;
   float inv_var_p;                                   // Gaussian prior: 1 / sigma_p^2
   float a1, a2, inv2var1, inv2var2, invvar1, invvar2; // mixture: a_i = pi_i / sigma_i
+#ifdef BNN_STAMPS
+  unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
+#endif
 };
+
+#ifdef BNN_STAMPS
+#define BWD_STAMP(i)                                                             \
+  do {                                                                           \
+    if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define BWD_STAMP_RT(i)                                                          \
+  do {                                                                           \
+    if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define BWD_STAMP(i)
+#define BWD_STAMP_RT(i)
+#endif
 
 // d log p(w) / dw
 __device__ __forceinline__ float dlogp(const BwdK& p, float w) {
@@ -65,10 +82,12 @@ __device__ __forceinline__ float sigmoidf(float r) { return __builtin_amdgcn_rcp
 // divergent branch gets its own basic block and the waits between blocks serialise the batch):
 // indices are clamped and the result selected afterwards.
 template <bool VEC>
-__global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
+__global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
+  BWD_STAMP(0);
+  BWD_STAMP_RT(8);
   // XCD-aware order: an XCD walks a few feature blocks (its slice of gz) across all k strips, so
   // x and that slice stay in its own L2 instead of every L2 holding everything
   const int nkb = (K + 63) >> 6;
@@ -123,48 +142,54 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
   const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   const int ka = k0 + 4 * r;                               // first k of this lane's A-operand quad
 
-  for (int s = 0; s < p.S; ++s) {
+  // The (sample, 32-row group) pairs form one pipeline over two register buffers: the 16 loads of the next group --
+  // of the next SAMPLE at a sample's end -- are in flight while this group's 32 MFMAs issue and while the sample's
+  // epilogue regenerates eps (single-buffered, every group waited a full memory round trip: ~2 us of a ~2.4 us group).
+  constexpr int U = 8;                                     // batch-row quads per group (32 rows)
+  const int G_ = (B + 4 * U - 1) / (4 * U);                // groups per sample
+  const int total_groups = p.S * G_;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float colsum = 0.f;
+  float4 avA[U], avB[U];
+  float bvA[U], bvB[U];
+  auto load_group = [&](int gi, float4 (&av)[U], float (&bv)[U]) {
+    const int s = gi / G_, b0 = (gi - s * G_) * (4 * U);
+    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+    const float* gzs = p.gz + (size_t)s * B * N;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int brow = b0 + 4 * u + q;
+      const float* xr = xs + (size_t)min(brow, B - 1) * K;
+      if (VEC) {
+        av[u] = *reinterpret_cast<const float4*>(xr + min(ka, K - 4));   // k >= K: rows of D that are never stored
+      } else {
+        av[u].x = xr[min(ka + 0, K - 1)];
+        av[u].y = xr[min(ka + 1, K - 1)];
+        av[u].z = xr[min(ka + 2, K - 1)];
+        av[u].w = xr[min(ka + 3, K - 1)];
+      }
+      const float gzv = gzs[(size_t)min(brow, B - 1) * N + min(n, N - 1)];
+      bv[u] = brow < B ? gzv : 0.f;                                       // rows >= B contribute nothing
+    }
+  };
+  auto mfma_group = [&](const float4 (&av)[U], const float (&bv)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      colsum += bv[u];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u], acc[3], 0, 0, 0);
+    }
+  };
+  // epilogue of sample s: regenerate eps of the lane's weights, fold the sample's gW tile into (G, H)
+  auto finish_sample = [&](int s) {
+    if (s == 0) { asm volatile("" ::"v"(acc[3][3])); BWD_STAMP(3); }
     const float glp = p.glp ? p.glp[s] : 0.f;
     cq += p.glq ? p.glq[s] : 0.f;
     const uint32_t gs = sample_base + (uint32_t)s;
-    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
-    const float* gzs = p.gz + (size_t)s * B * N;
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.f;
-    constexpr int U = 8;                                   // batch rows in flight per lane quad
-    for (int b0 = 0; b0 < B; b0 += 4 * U) {
-      float4 av[U];
-      float bv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int brow = b0 + 4 * u + q;
-        const float* xr = xs + (size_t)min(brow, B - 1) * K;
-        if (VEC) {
-          av[u] = *reinterpret_cast<const float4*>(xr + min(ka, K - 4));   // k >= K: rows of D that are never stored
-        } else {
-          av[u].x = xr[min(ka + 0, K - 1)];
-          av[u].y = xr[min(ka + 1, K - 1)];
-          av[u].z = xr[min(ka + 2, K - 1)];
-          av[u].w = xr[min(ka + 3, K - 1)];
-        }
-        const float gzv = gzs[(size_t)min(brow, B - 1) * N + min(n, N - 1)];
-        bv[u] = brow < B ? gzv : 0.f;                                       // rows >= B contribute nothing
-      }
-      // keep the batch a batch: without this the scheduler sinks every load next to its MFMAs to
-      // shorten live ranges, and the group costs U round trips instead of one
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        colsum += bv[u];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u], acc[3], 0, 0, 0);
-      }
-    }
-    // ---- epilogue of sample s: regenerate eps of the lane's weights, fold into (G, H)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int kb = k0 + q * 16 + reg * 4;
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
         }
       }
     }
-    // ---- bias: gb_s[n] = sum_b gz_s[b][n]; the 4 lane quads hold b = q (mod 4)
+    // bias: gb_s[n] = sum_b gz_s[b][n]; the 4 lane quads hold b = q (mod 4)
     colsum += __shfl_xor(colsum, 16, kWave);
     colsum += __shfl_xor(colsum, 32, kWave);
     if (do_bias) {
@@ -202,6 +227,28 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
       const float t = colsum + glp * dlogp(p, bw);
       Gb += t;
       Hb = __builtin_fmaf(t, e, Hb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    colsum = 0.f;
+    if (s == 0) { asm volatile("" ::"v"(G[0][0]), "v"(H[3][3])); BWD_STAMP(4); }
+  };
+  // Loads are issued unconditionally (the last ones re-read the final group): a load under a branch would make the
+  // join point wait for vmcnt(0), i.e. for the group just issued, which is the round trip this pipeline hides.
+  const int last_group = total_groups - 1;
+  load_group(0, avA, bvA);
+  for (int gi = 0; gi < total_groups; gi += 2) {
+    load_group(min(gi + 1, last_group), avB, bvB);
+    __builtin_amdgcn_sched_barrier(0);                     // the loads stay a batch, issued ahead of the MFMAs
+    if (gi == 0) { asm volatile("" ::"v"(sg[0][0]), "v"(avA[0].x)); BWD_STAMP(1); }
+    mfma_group(avA, bvA);
+    if (gi == 0) { asm volatile("" ::"v"(acc[0][0])); BWD_STAMP(2); }
+    if ((gi + 1) % G_ == 0) finish_sample(gi / G_);
+    load_group(min(gi + 2, last_group), avA, bvA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (gi + 1 < total_groups) {
+      mfma_group(avB, bvB);
+      if ((gi + 2) % G_ == 0) finish_sample((gi + 1) / G_);
     }
   }
 
@@ -230,6 +277,8 @@ __global__ __launch_bounds__(256) void bbb_bwd_weights_kernel(const BwdK p) {
     p.g_bmu[n] = Gb;
     p.g_brho[n] = (Hb - cq * __builtin_amdgcn_rcpf(bsg)) * sigmoidf(brh);
   }
+  BWD_STAMP(7);
+  BWD_STAMP_RT(9);
 }
 
 // gz = gy * (y > 0)  (or a plain copy when there was no ReLU)
@@ -294,6 +343,12 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
+#ifdef BNN_STAMPS
+  {
+    const char* v = getenv("BNN_HIP_DBG_PTR");
+    k.dbg = v ? reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0)) : nullptr;
+  }
+#endif
   k.inv_var_p = 0.f; k.a1 = k.a2 = k.inv2var1 = k.inv2var2 = k.invvar1 = k.invvar2 = 0.f;
   if (a->prior.kind == BNN_PRIOR_MIXTURE) {
     if (!(a->prior.sigma1 > 0.f) || !(a->prior.sigma2 > 0.f)) return BNN_ERR_SHAPE;

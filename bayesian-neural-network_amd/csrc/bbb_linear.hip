@@ -55,6 +55,8 @@ struct BbbK {
   int ksl;          // GEMM form: K-range slices per (tile group, sample); 1 = none
   float* ks_part;   // GEMM form, ksl > 1: fp32 partial outputs [ksl][S][B][N] (bias in slice 0)
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
+  const float* mask;  // TRANS only, optional: [S|1, B, N] the layer's input; the stored gx is multiplied by (mask > 0)
+  long mask_sstride;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
   float inv2var1, c1, inv2var2, c2, pi;   // mixture: log N(w;0,s_i) = c_i - w^2 * inv2var_i
@@ -210,6 +212,12 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
       v[i] = o;
     }
     if (lds_out) *reinterpret_cast<f32x4*>(lds_out + (m * 16 + b) * 16 + fg * 4) = v;
+    if (p.mask) {                                  // input gradient through the ReLU of the layer below
+      const float* mp = p.mask + (size_t)s * (size_t)p.mask_sstride + (size_t)brow * N + nb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N && !(mp[i] > 0.f)) v[i] = 0.f;
+    }
     const size_t yoff = ((size_t)s * B + brow) * N + nb;
     if (p.y_bf16) {
       __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
@@ -1043,6 +1051,7 @@ hipError_t allow_big_lds(KernelT kernel, size_t lds) {
 // Validate the arguments and fill the kernel parameter block.  `al` = the 16-byte vector path
 // applies (K % 8 == 0, aligned bases).
 static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
+  k.mask = nullptr; k.mask_sstride = 0;      // input-gradient form only
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
@@ -1365,6 +1374,8 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   k.K = a->out_features;            // reduction length
   k.N = a->in_features;             // produced features
   k.ldw = a->in_features;
+  k.mask = a->gx_relu_mask ? a->x : nullptr;
+  k.mask_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = 0; k.relu = 0; k.y_bf16 = 0; k.spb = 1;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;

@@ -34,7 +34,6 @@ struct LrBwdK {
   const float* h;        // [S, B, N]
   const float* w_mu;     // [K, N]
   const float* w_rho;
-  const float* w_sigma;  // [K, N] softplus(rho) (input-gradient kernel)
   const float* b_mu;
   const float* b_rho;
   const float* eps_b;    // BNN_EPS_MEMORY: [S, N]
@@ -46,6 +45,7 @@ struct LrBwdK {
   float* g_x;            // [S, B, K]
   int S, B, K, N;
   int eps_mode;
+  int gx_mask;           // g_x *= (x > 0): the ReLU of the layer below
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
   float inv_var_p;
@@ -353,12 +353,14 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
     f.ha1 = load_quad<VEC>(hs + (size_t)ra1 * N, n, N);
     f.m0 = load_quad<VEC>(p.w_mu + (size_t)kc0 * N, n, N);
     f.m1 = load_quad<VEC>(p.w_mu + (size_t)kc1 * N, n, N);
-    f.s0 = load_quad<VEC>(p.w_sigma + (size_t)kc0 * N, n, N);
-    f.s1 = load_quad<VEC>(p.w_sigma + (size_t)kc1 * N, n, N);
+    f.s0 = load_quad<VEC>(p.w_rho + (size_t)kc0 * N, n, N);
+    f.s1 = load_quad<VEC>(p.w_rho + (size_t)kc1 * N, n, N);
   };
+  auto sq_softplus = [](float r) { const float sg = softplus(r); return sg * sg; };
   auto mfma_slice = [&](Frag& f) {
-    f.s0.x *= f.s0.x; f.s0.y *= f.s0.y; f.s0.z *= f.s0.z; f.s0.w *= f.s0.w;
-    f.s1.x *= f.s1.x; f.s1.y *= f.s1.y; f.s1.z *= f.s1.z; f.s1.w *= f.s1.w;
+    // sigma^2 from rho in place (a separate softplus pass over [K, N] was one more launch per layer)
+    f.s0.x = sq_softplus(f.s0.x); f.s0.y = sq_softplus(f.s0.y); f.s0.z = sq_softplus(f.s0.z); f.s0.w = sq_softplus(f.s0.w);
+    f.s1.x = sq_softplus(f.s1.x); f.s1.y = sq_softplus(f.s1.y); f.s1.z = sq_softplus(f.s1.z); f.s1.w = sq_softplus(f.s1.w);
 #define LR_STEP(F)                                                                     \
     P[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ga0.F, f.m0.F, P[0][0], 0, 0, 0); \
     P[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ga0.F, f.m1.F, P[0][1], 0, 0, 0); \
@@ -430,7 +432,8 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int b = b0 + 16 * ti + 4 * q + reg;
-        if (b < B) p.g_x[((size_t)s * B + b) * K + k] = __builtin_fmaf(2.f * xv[reg], qs[reg], ps[reg]);
+        const float gx = __builtin_fmaf(2.f * xv[reg], qs[reg], ps[reg]);
+        if (b < B) p.g_x[((size_t)s * B + b) * K + k] = (p.gx_mask && !(xv[reg] > 0.f)) ? 0.f : gx;
       }
     }
   }
@@ -440,16 +443,14 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
 
 using namespace bnn;
 
-extern "C" int bnn_softplus(const float* rho, float* sigma, int64_t n, void* stream);
-
 static size_t lr_bwd_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t bnn_lr_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t in_features,
                                                     int32_t out_features, int32_t want_gx) {
   if (n_samples <= 0 || batch <= 0 || in_features <= 0 || out_features <= 0) return 0;
   const size_t act = lr_bwd_align((size_t)n_samples * batch * out_features * sizeof(float));
-  const size_t sig = want_gx ? lr_bwd_align((size_t)in_features * out_features * sizeof(float)) : 0;
-  return 2 * act + sig;
+  (void)in_features; (void)want_gx;          // gz and h; sigma is recomputed from rho where it is used
+  return 2 * act;
 }
 
 extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
@@ -479,7 +480,6 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   char* base = reinterpret_cast<char*>(a->workspace);
   float* gz = reinterpret_cast<float*>(base);
   float* h = reinterpret_cast<float*>(base + act);
-  float* sig = a->g_x ? reinterpret_cast<float*>(base + 2 * act) : nullptr;
 
   const uint32_t k0 = (uint32_t)a->seed, k1 = (uint32_t)(a->seed >> 32);
   const long groups = (long)S * B * ((N + 3) / 4);
@@ -494,12 +494,13 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)B * K : 0;
   k.gz = gz; k.h = h;
-  k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.w_sigma = sig; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
+  k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_b = a->eps_b; k.gkl = a->g_kl;
   k.g_wmu = a->g_w_mu; k.g_wrho = a->g_w_rho; k.g_bmu = a->g_b_mu; k.g_brho = a->g_b_rho; k.g_x = a->g_x;
   k.S = S; k.B = B; k.K = K; k.N = N;
   k.eps_mode = a->eps_mode; k.k0 = k0; k.k1 = k1; k.layer_id = a->layer_id; k.sample_offset = a->sample_offset;
   k.sample_counter = a->sample_counter;
+  k.gx_mask = a->gx_relu_mask ? 1 : 0;
   k.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
   const int wblocks = ((K + 63) / 64) * ((N + 63) / 64);
   const dim3 wgrid((unsigned)(((wblocks + 7) / 8) * 8));
@@ -508,8 +509,6 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) {
-    const int rc = bnn_softplus(a->w_rho, sig, (int64_t)K * N, stream_);
-    if (rc != BNN_OK) return rc;
     const dim3 igrid((K + 31) / 32, (B + 31) / 32, S);
     if ((N & 3) == 0) hipLaunchKernelGGL(lr_bwd_input_kernel<true>, igrid, dim3(512), 0, stream, k);
     else hipLaunchKernelGGL(lr_bwd_input_kernel<false>, igrid, dim3(512), 0, stream, k);

@@ -25,7 +25,10 @@ struct AdamK {
   float beta2f, omb1, omb2, eps, wd;
   uint32_t step;
   const float* lr_dev;
-  const uint32_t* step_dev;   // already advanced by adam_tick_kernel when set
+  uint32_t* step_dev;         // already advanced by adam_tick_kernel when set and ticket == nullptr
+  uint32_t* ticket;           // set: this launch advances *step_dev itself (last arriver), no tick launch
+  uint32_t* bump;             // optional word the last arriver adds bump_by to (the step's MC-sample counter)
+  uint32_t bump_by;
 };
 
 __global__ void adam_tick_kernel(uint32_t* step) { *step += 1u; }
@@ -41,7 +44,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
   float* __restrict__ m = k.m[t];
   float* __restrict__ v = k.v[t];
   const double lr = k.lr_dev ? (double)*k.lr_dev : k.lr;
-  const uint32_t step = k.step_dev ? *k.step_dev : k.step;
+  // with a ticket word every block reads the old step and uses step + 1; the block that arrives last (all have
+  // read it by then) stores it: the optimiser step is ONE launch, nobody waits
+  const uint32_t step = k.step_dev ? *k.step_dev + (k.ticket ? 1u : 0u) : k.step;
   // bias corrections in double, as torch computes them on the host (1 - beta ** step)
   const double bc1 = 1.0 - pow(k.beta1, (double)step);
   const double bc2 = 1.0 - pow(k.beta2, (double)step);
@@ -84,6 +89,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (i + j < n) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; }
+    }
+  }
+  if (k.ticket && threadIdx.x == 0) {
+    const uint32_t tk = __hip_atomic_fetch_add(k.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gridDim.x - 1u) {
+      *k.step_dev = step;
+      if (k.bump) *k.bump += k.bump_by;
+      *k.ticket = 0u;                                   // ready for the next launch
     }
   }
 }
@@ -145,8 +158,13 @@ extern "C" int bnn_adam_step(const bnn_adam_args* a, void* stream_) {
   k.lr = a->lr; k.beta1 = a->beta1; k.beta2 = a->beta2; k.eps = (float)a->eps; k.wd = (float)a->weight_decay;
   k.beta2f = (float)a->beta2; k.omb1 = (float)(1.0 - a->beta1); k.omb2 = (float)(1.0 - a->beta2);
   k.step = a->step; k.lr_dev = a->lr_device; k.step_dev = a->step_device;
+  const bool ticketed = a->step_device && a->step_advance && a->ticket;
+  if (a->bump_counter && !ticketed) return BNN_ERR_NULL;   // the counter rides on the ticketed hand-off only
+  k.ticket = ticketed ? a->ticket : nullptr;
+  k.bump = a->bump_counter; k.bump_by = a->bump_by;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (a->step_device && a->step_advance) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, a->step_device);
+  if (a->step_device && a->step_advance && !ticketed)
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, a->step_device);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks), dim3(256), 0, stream, k);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;

@@ -263,10 +263,11 @@ __global__ void philox_normal_kernel(float* __restrict__ eps, uint32_t k0, uint3
 // ELBO assembly of one training step (reference networks.py:205-208 / :222-224) from the per-sample
 // scalars, and the seeds of the backward chain: d loss / d log p[s] = -beta/S, d loss / d log q[s] =
 // beta/S, d loss / d nll[s] = 1/S; LR: d loss / d (a layer's KL) = beta.  One block.
-__global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nll,
-                                 const float* __restrict__ beta_p, int S, float total, float grad_scale, int local_reparam,
-                                 float* __restrict__ out4, float* __restrict__ g_a, float* __restrict__ g_b,
-                                 float* __restrict__ g_nll, float* __restrict__ g_kl3) {
+__device__ __forceinline__ void elbo_loss_block(const float* __restrict__ a, const float* __restrict__ b,
+                                                const float* __restrict__ nll, const float* __restrict__ beta_p, int S,
+                                                float total, float grad_scale, int local_reparam, float* __restrict__ out4,
+                                                float* __restrict__ g_a, float* __restrict__ g_b, float* __restrict__ g_nll,
+                                                float* __restrict__ g_kl3) {
   __shared__ double scratch[16];
   double x = 0, y = 0, z = 0;
   for (int i = threadIdx.x; i < S; i += blockDim.x) {
@@ -292,6 +293,61 @@ __global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __res
     out4[2] = bm;
     out4[3] = nm;
     if (g_kl3) { g_kl3[0] = beta * grad_scale; g_kl3[1] = 0.f; g_kl3[2] = 0.f; }
+  }
+}
+
+__global__ void elbo_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nll,
+                                 const float* __restrict__ beta_p, int S, float total, float grad_scale, int local_reparam,
+                                 float* __restrict__ out4, float* __restrict__ g_a, float* __restrict__ g_b,
+                                 float* __restrict__ g_nll, float* __restrict__ g_kl3) {
+  elbo_loss_block(a, b, nll, beta_p, S, total, grad_scale, local_reparam, out4, g_a, g_b, g_nll, g_kl3);
+}
+
+// The same, and in the same launch the gradient of the summed NLL w.r.t. the logits (bnn_nll_bwd with the constant
+// seed grad_scale / total): block 0 assembles the loss and the seeds, blocks 1.. take one (sample, batch row) per thread.
+__global__ __launch_bounds__(256) void elbo_loss_nll_bwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ nll, const float* __restrict__ beta_p,
+    int S, float total, float grad_scale, int local_reparam, float* __restrict__ out4, float* __restrict__ g_a,
+    float* __restrict__ g_b, float* __restrict__ g_kl3, const float* __restrict__ logits, const void* __restrict__ target,
+    float* __restrict__ g_logits, int B, int C, int mode, float inv_var) {
+  if (blockIdx.x == 0) {
+    elbo_loss_block(a, b, nll, beta_p, S, total, grad_scale, local_reparam, out4, g_a, g_b, nullptr, g_kl3);
+    return;
+  }
+  const float gs = grad_scale / total;
+  const long rows = (long)S * B;
+  for (long idx = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x; idx < rows; idx += (long)(gridDim.x - 1) * blockDim.x) {
+    const int brow = (int)(idx % B);
+    const float* row = logits + idx * C;
+    float* out = g_logits + idx * C;
+    if (mode == BNN_NLL_CLASSIFICATION) {
+      const long long tc = reinterpret_cast<const long long*>(target)[brow];
+      float mx = row[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+      const float inv = 1.0f / se;
+      for (int c = 0; c < C; ++c) out[c] = (expf(row[c] - mx) * inv - (c == tc ? 1.f : 0.f)) * gs;
+    } else {
+      const float* tg = reinterpret_cast<const float*>(target) + (size_t)brow * C;
+      for (int c = 0; c < C; ++c) out[c] = (row[c] - tg[c]) * inv_var * gs;
+    }
+  }
+}
+
+// Inputs of a captured training step staged into its static buffers in one launch: up to two device-to-device
+// copies (16-byte words when everything is aligned) and one float word (the step's KL weight).
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const char* __restrict__ s0, char* __restrict__ d0, size_t n0,
+                                                           const char* __restrict__ s1, char* __restrict__ d1, size_t n1,
+                                                           int vec, float* __restrict__ word, float value) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  if (tid == 0 && word) *word = value;
+  if (vec) {
+    for (size_t i = tid; i < (n0 >> 4); i += nt) reinterpret_cast<float4*>(d0)[i] = reinterpret_cast<const float4*>(s0)[i];
+    for (size_t i = tid; i < (n1 >> 4); i += nt) reinterpret_cast<float4*>(d1)[i] = reinterpret_cast<const float4*>(s1)[i];
+  } else {
+    for (size_t i = tid; i < n0; i += nt) d0[i] = s0[i];
+    for (size_t i = tid; i < n1; i += nt) d1[i] = s1[i];
   }
 }
 
@@ -372,6 +428,43 @@ extern "C" int bnn_elbo_loss(const float* a, const float* b, const float* nll, c
   if (n_samples <= 0 || !(total_samples > 0.f)) return BNN_ERR_SHAPE;
   hipLaunchKernelGGL(elbo_loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a, b, nll, beta,
                      n_samples, total_samples, grad_scale, local_reparam, out4, g_a, g_b, g_nll, g_kl3);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+extern "C" int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float* nll, const float* beta, int32_t n_samples,
+                                     float total_samples, float grad_scale, int32_t local_reparam, float* out4, float* g_a,
+                                     float* g_b, float* g_kl3, const float* logits, const void* target, float* g_logits,
+                                     int32_t batch, int32_t classes, int32_t nll_mode, float nll_sigma, void* stream_) {
+  if (!a || !nll || !beta || !out4 || !logits || !target || !g_logits) return BNN_ERR_NULL;
+  if (!local_reparam && !b) return BNN_ERR_NULL;
+  if (n_samples <= 0 || batch <= 0 || classes <= 0 || !(total_samples > 0.f)) return BNN_ERR_SHAPE;
+  if ((unsigned)nll_mode > 1u) return BNN_ERR_ENUM;
+  if (nll_mode == BNN_NLL_REGRESSION && !(nll_sigma > 0.f)) return BNN_ERR_SHAPE;
+  const long rows = (long)n_samples * batch;
+  long nb = (rows + 255) / 256;
+  nb = nb > 2048 ? 2048 : nb;
+  const float inv_var = nll_mode == BNN_NLL_REGRESSION ? (float)(1.0 / ((double)nll_sigma * nll_sigma)) : 0.f;
+  hipLaunchKernelGGL(elbo_loss_nll_bwd_kernel, dim3((unsigned)nb + 1u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     a, b, nll, beta, n_samples, total_samples, grad_scale, local_reparam, out4, g_a, g_b, g_kl3, logits,
+                     target, g_logits, batch, classes, nll_mode, inv_var);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+extern "C" int bnn_stage_inputs(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
+                                float* word, float value, void* stream_) {
+  if ((bytes0 && (!src0 || !dst0)) || (bytes1 && (!src1 || !dst1))) return BNN_ERR_NULL;
+  if (!bytes0 && !bytes1 && !word) return BNN_OK;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(dst0) | (uintptr_t)bytes0 |
+                       reinterpret_cast<uintptr_t>(src1) | reinterpret_cast<uintptr_t>(dst1) | (uintptr_t)bytes1;
+  const int vec = (al & 15) == 0;
+  const size_t words = vec ? ((bytes0 > bytes1 ? bytes0 : bytes1) >> 4) : (bytes0 > bytes1 ? bytes0 : bytes1);
+  size_t nb = (words + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     reinterpret_cast<const char*>(src0), reinterpret_cast<char*>(dst0), bytes0,
+                     reinterpret_cast<const char*>(src1), reinterpret_cast<char*>(dst1), bytes1, vec, word, value);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

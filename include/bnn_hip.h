@@ -333,7 +333,8 @@ typedef struct bnn_bbb_bwd_args {
   uint32_t layer_id;
   uint32_t sample_offset;
   bnn_prior prior;
-  int32_t reserved;
+  int32_t gx_relu_mask;       /* != 0: g_x is multiplied by (x > 0).  x is then the output of the ReLU layer below,
+                                 whose own backward takes this g_x as gy with relu = 0 (no separate mask pass) */
   const float* g_log_prior;   /* [n_samples] or NULL (zeros) */
   const float* g_log_q;       /* [n_samples] or NULL (zeros) */
   float* g_w_mu;
@@ -385,7 +386,7 @@ typedef struct bnn_lr_bwd_args {
   uint32_t layer_id;
   uint32_t sample_offset;
   float sigma_p;
-  int32_t reserved2;
+  int32_t gx_relu_mask;       /* as in bnn_bbb_bwd_args */
   const float* g_kl;          /* device float[3] or NULL */
   float* g_w_mu;
   float* g_w_rho;
@@ -424,12 +425,17 @@ typedef struct bnn_adam_args {
   double lr, beta1, beta2, eps, weight_decay;   /* doubles, as torch holds them: 1 - beta2 must not be
                                                    formed from a float-rounded beta2 */
   uint32_t step;                 /* 1-based step number when step_device == NULL */
-  uint32_t reserved0;
+  uint32_t bump_by;              /* see bump_counter */
   const float* lr_device;
   uint32_t* step_device;
   int32_t step_advance;          /* with step_device: 1 = ++(*step_device) before the update, 0 = use it
                                     as it is (second and later launches of one optimiser step) */
   int32_t reserved;
+  uint32_t* ticket;              /* optional zero-initialised device word.  With step_advance: the update uses
+                                    *step_device + 1 and the block that finishes last stores it (and re-zeroes the
+                                    ticket) -- the step counts inside the one launch, no separate tick launch */
+  uint32_t* bump_counter;        /* optional (needs ticket): *bump_counter += bump_by by that same last block, e.g. the
+                                    MC-sample counter of a captured training step, advanced after the backward read it */
 } bnn_adam_args;
 
 int bnn_adam_step(const bnn_adam_args* args, void* stream);
@@ -451,6 +457,21 @@ int bnn_elbo_loss(const float* a, const float* b, const float* nll, const float*
  * logits, g_logits fp32 [n_samples,batch,classes]; target as for bnn_elbo_finalize. */
 int bnn_nll_bwd(const float* logits, const void* target, const float* g_nll, float* g_logits, int32_t n_samples,
                 int32_t batch, int32_t classes, int32_t nll_mode, float nll_sigma, void* stream);
+
+/* bnn_elbo_loss_nll_bwd — bnn_elbo_loss and bnn_nll_bwd of one training step in ONE launch: the NLL seed is the
+ * constant grad_scale / total_samples, so the logits' gradient does not wait for the loss arithmetic.
+ * Arguments as for the two functions (no g_nll: it is not materialised). */
+int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float* nll, const float* beta, int32_t n_samples,
+                          float total_samples, float grad_scale, int32_t local_reparam, float* out4, float* g_a, float* g_b,
+                          float* g_kl3, const float* logits, const void* target, float* g_logits, int32_t batch,
+                          int32_t classes, int32_t nll_mode, float nll_sigma, void* stream);
+
+/* bnn_stage_inputs — the per-step inputs of a captured training step (the minibatch the reference's loop hands
+ * to sample_elbo, class_task.py:72-77, and its KL weight beta) copied into the graph's static device buffers
+ * in one launch: dst0 <- src0 (bytes0), dst1 <- src1 (bytes1), *word = value.  Device pointers; any part may be
+ * empty (bytes = 0 / word = NULL). */
+int bnn_stage_inputs(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
+                     float* word, float value, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * F3  bnn_mc_softmax_mean — the MC-averaged prediction of classification/class_task.py:81-87:

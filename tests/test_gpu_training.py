@@ -115,6 +115,92 @@ def test_nll_backward_kernel_matches_autograd(mode):
     assert float((got - logits.grad).abs().max()) <= 2e-6 * float(logits.grad.abs().max())
 
 
+@pytest.mark.parametrize("mode", ["classification", "regression"])
+@pytest.mark.parametrize("local_reparam", [False, True])
+def test_fused_loss_and_nll_backward_equal_the_two_launches(mode, local_reparam):
+    """bnn_elbo_loss_nll_bwd = bnn_elbo_loss followed by bnn_nll_bwd, bit for bit (same arithmetic, one launch)."""
+    from bnn_hip import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(8)
+    for S, B in ((1, 128), (3, 37), (8, 300)):
+        C = 10 if mode == "classification" else 4
+        logits = torch.from_numpy(rs.standard_normal((S, B, C)).astype(np.float32) * 3).to(dev)
+        tgt = (torch.from_numpy(rs.randint(0, C, B)) if mode == "classification"
+               else torch.from_numpy(rs.standard_normal((B, C)).astype(np.float32))).to(dev)
+        a, b, nll = (torch.from_numpy(rs.standard_normal(S).astype(np.float32) * 100).to(dev) for _ in range(3))
+        beta = torch.tensor(0.37, device=dev)
+        out4, g_a, g_b, g_nll, g_kl3 = ops.elbo_loss(a, None if local_reparam else b, nll, beta, 2 * S, local_reparam,
+                                                     grad_scale=0.5)
+        g_ref = ops.nll_bwd(logits, tgt, g_nll, mode, 0.7)
+        o4, ga, gb, gk, g = ops.elbo_loss_nll_bwd(a, None if local_reparam else b, nll, beta, 2 * S, local_reparam, logits,
+                                                  tgt, mode, 0.7, grad_scale=0.5)
+        assert torch.equal(o4[:2], out4[:2]) and torch.equal(o4[3], out4[3]) and torch.equal(gk, g_kl3)
+        assert torch.equal(ga, g_a) and torch.equal(gb, g_b) and torch.equal(g, g_ref)
+
+
+def test_stage_inputs_copies_and_sets_the_word():
+    from bnn_hip import ops
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(9)
+    for nx, ny in ((128 * 784, 128), (7, 3), (1, 0)):
+        x = torch.from_numpy(rs.standard_normal(nx).astype(np.float32)).to(dev)
+        y = torch.from_numpy(rs.randint(0, 10, ny)).to(dev) if ny else None
+        dx, dy, w = torch.zeros_like(x), (torch.zeros_like(y) if ny else None), torch.zeros((), device=dev)
+        ops.stage_inputs(x, dx, y, dy, w, 0.625)
+        assert torch.equal(dx, x) and (dy is None or torch.equal(dy, y)) and float(w) == 0.625
+    xo = torch.arange(41, dtype=torch.float32, device=dev)[1:]           # 4-byte aligned only: byte path
+    d = torch.zeros(40, device=dev)
+    ops.stage_inputs(xo, d)
+    assert torch.equal(d, xo)
+    with pytest.raises(ops.BnnHipError):
+        ops.stage_inputs(x, torch.zeros(3, device=dev))
+
+
+def test_adam_launch_advances_step_and_sample_counter():
+    """Capturable FusedAdam: the device step and the attached counter advance inside the update launch (last
+    block's hand-off), once per step, also when the tensors need more than one launch."""
+    from bnn_hip.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    ps = [torch.nn.Parameter(torch.randn(5000 if i == 0 else 9, device=dev)) for i in range(20)]
+    opt = FusedAdam(ps, lr=1e-3, capturable=True)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    opt.bump_after_step(counter, 6)
+    for it in range(1, 5):
+        for p_ in ps:
+            p_.grad = torch.randn_like(p_)
+        opt.step()
+        assert opt.device_step() == it and int(counter) == 6 * it
+        assert int(opt._dev[0][3]) == 0                                  # ticket word back at zero
+
+
+@pytest.mark.parametrize("variant", ["bbb", "lr"])
+def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
+    """gx_relu_mask: g_x * (x > 0) from the input-gradient kernel equals the separate mask pass the layer below
+    would run on it (its output IS this layer's x)."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(10)
+    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 38), (1, 7, 33, 10)):
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1))
+        gy = mk(S, B, N, lo=-1, hi=1)
+        b_mu, b_rho = mk(N), mk(N, lo=-5, hi=-2)
+        kw = dict(n_samples=S, relu=False, eps_mode=L.EPS_PHILOX, seed=3, layer_id=1, sample_offset=5)
+        if variant == "bbb":
+            w_mu, w_rho = mk(N, K), mk(N, K, lo=-5, hi=-2)
+            run = lambda m: ops.bbb_linear_bwd(x, gy, None, w_mu, w_rho, b_mu, b_rho, prior=ops.PriorSpec(False, 1.0),
+                                               math_mode=L.MATH_F32, gx_relu_mask=m, **kw)
+        else:
+            w_mu, w_rho = mk(K, N), mk(K, N, lo=-5, hi=-2)
+            v = mk(S, B, N, lo=0.1, hi=1.0)
+            run = lambda m: ops.lr_linear_bwd(x, gy, None, v, w_mu, w_rho, b_mu, b_rho, sigma_p=1.0, gx_relu_mask=m, **kw)
+        plain, masked = run(False), run(True)
+        for a, b in zip(plain[:4], masked[:4]):
+            assert torch.equal(a, b)
+        assert torch.equal(masked[4], plain[4] * (x > 0))
+        assert float(masked[4].abs().max()) > 0
+
+
 @pytest.mark.parametrize("autograd", [False, True])
 @pytest.mark.parametrize("local_reparam", [False, True])
 def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
