@@ -20,7 +20,7 @@ EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
-    "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs",
+    "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
@@ -49,6 +49,27 @@ class BbbFwdArgs(C.Structure):
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("concurrency", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
+        ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p),
+    ]
+
+
+SAMPLE_MAX_LAYERS = 8
+
+
+class SampleLayer(C.Structure):
+    _fields_ = [
+        ("in_features", C.c_int32), ("out_features", C.c_int32), ("layer_id", C.c_uint32), ("reserved", C.c_int32),
+        ("w_mu", C.c_void_p), ("w_rho", C.c_void_p), ("b_mu", C.c_void_p), ("b_rho", C.c_void_p),
+        ("w_out", C.c_void_p), ("b_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("prior", Prior), ("reserved2", C.c_int32),
+    ]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("n_layers", C.c_int32), ("n_samples", C.c_int32), ("sample_offset", C.c_uint32),
+        ("seed", C.c_uint64), ("sample_counter", C.c_void_p),
+        ("layer", SampleLayer * SAMPLE_MAX_LAYERS),
     ]
 
 
@@ -187,6 +208,10 @@ def load():
     lib.bnn_elbo_loss_nll_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    lib.bnn_bbb_sample_workspace_bytes.restype = C.c_size_t
+    lib.bnn_bbb_sample_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.bnn_bbb_sample_weights.restype = C.c_int
+    lib.bnn_bbb_sample_weights.argtypes = [C.POINTER(SampleArgs), C.c_void_p]
     lib.bnn_stage_inputs.restype = C.c_int
     lib.bnn_stage_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_float, C.c_void_p]

@@ -164,6 +164,83 @@ def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
     return res
 
 
+def sample_workspace(n_samples: int, fin: int, fout: int, device) -> torch.Tensor:
+    """Statistics workspace of one layer that serves both K1 (fused) and K1s (split) forms."""
+    nbytes = L.load().bnn_bbb_sample_workspace_bytes(n_samples, fin, fout) or \
+        L.load().bnn_bbb_linear_fwd_workspace_bytes(n_samples, fout)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: int = 0, sample_counter=None):
+    """K1s (bnn_bbb_sample_weights): `layers` = list of dicts(w_mu [out,in], w_rho, b_mu, b_rho, prior, layer_id,
+    workspace=None, w_out=None, b_out=None).  One launch samples them all; returns a list of dicts(w [S,out,in] bf16,
+    b [S,out] fp32, workspace)."""
+    lib = L.load()
+    if not 1 <= len(layers) <= L.SAMPLE_MAX_LAYERS:
+        raise BnnHipError(f"bbb_sample_weights: 1..{L.SAMPLE_MAX_LAYERS} layers per launch")
+    a = L.SampleArgs()
+    a.struct_bytes = C.sizeof(L.SampleArgs)
+    a.n_layers, a.n_samples = len(layers), int(n_samples)
+    a.seed, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, sample_offset & 0xFFFFFFFF
+    a.sample_counter = _ptr(sample_counter)
+    res, keep = [], []
+    for i, ly in enumerate(layers):
+        w_mu, w_rho = _f32c(ly["w_mu"], "weight_mu"), _f32c(ly["w_rho"], "weight_rho")
+        b_mu, b_rho = _f32c(ly["b_mu"], "bias_mu"), _f32c(ly["b_rho"], "bias_rho")
+        require_device(w_mu, w_rho, b_mu, b_rho)
+        N, K = w_mu.shape
+        if K % 8:
+            raise BnnHipError("bbb_sample_weights: in_features must be a multiple of 8")
+        if tuple(w_rho.shape) != (N, K) or tuple(b_mu.shape) != (N,) or tuple(b_rho.shape) != (N,):
+            raise BnnHipError("bbb_sample_weights: parameter shapes disagree")
+        dev = w_mu.device
+        ws = ly.get("workspace")
+        if ws is None:
+            ws = sample_workspace(n_samples, K, N, dev)
+        w = ly.get("w_out")
+        if w is None:
+            w = torch.empty((n_samples, N, K), dtype=torch.bfloat16, device=dev)
+        b = ly.get("b_out")
+        if b is None:
+            b = torch.empty((n_samples, N), dtype=torch.float32, device=dev)
+        if w.dtype != torch.bfloat16 or w.numel() != n_samples * N * K or b.dtype != torch.float32 or b.numel() != n_samples * N:
+            raise BnnHipError("bbb_sample_weights: w_out must be bf16 [S,out,in], b_out fp32 [S,out]")
+        e = a.layer[i]
+        e.in_features, e.out_features, e.layer_id = K, N, int(ly.get("layer_id", i))
+        e.w_mu, e.w_rho, e.b_mu, e.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+        e.w_out, e.b_out = w.data_ptr(), b.data_ptr()
+        e.workspace, e.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        e.prior = ly["prior"].c()
+        res.append(dict(w=w, b=b, workspace=ws))
+        keep.append((w_mu, w_rho, b_mu, b_rho))
+    L.check(lib.bnn_bbb_sample_weights(C.byref(a), _stream()), "bnn_bbb_sample_weights")
+    return res
+
+
+def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, concurrency: int = 0):
+    """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s])."""
+    lib = L.load()
+    require_device(x, w, b)
+    if w.dtype != torch.bfloat16 or b.dtype != torch.float32 or not w.is_contiguous() or not b.is_contiguous():
+        raise BnnHipError("bbb_sampled_matmul: w must be contiguous bf16, b contiguous fp32")
+    S, N, K = w.shape
+    xs, B, Kx, per_sample = _x3(x, n_samples)
+    if S != n_samples or Kx != K or b.numel() != S * N:
+        raise BnnHipError("bbb_sampled_matmul: shape mismatch")
+    y = out if out is not None else torch.empty((n_samples, B, N), dtype=y_dtype, device=xs.device)
+    a = L.BbbFwdArgs()
+    a.struct_bytes = C.sizeof(L.BbbFwdArgs)
+    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+    a.x, a.x_dtype, a.x_per_sample = xs.data_ptr(), _dt(xs), per_sample
+    a.eps_mode, a.math = L.EPS_ZERO, L.MATH_BF16
+    a.want_stats, a.relu = 0, int(relu)
+    a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    a.concurrency = int(concurrency)
+    a.w_sampled, a.b_sampled = w.data_ptr(), b.data_ptr()
+    L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
+    return y
+
+
 def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,

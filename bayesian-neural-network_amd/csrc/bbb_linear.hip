@@ -55,6 +55,8 @@ struct BbbK {
   int ksl;          // GEMM form: K-range slices per (tile group, sample); 1 = none
   float* ks_part;   // GEMM form, ksl > 1: fp32 partial outputs [ksl][S][B][N] (bias in slice 0)
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
+  const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
+  const float* b_pre;   // PRE only: sampled biases [S, N]
   const float* mask;  // TRANS only, optional: [S|1, B, N] the layer's input; the stored gx is multiplied by (mask > 0)
   long mask_sstride;
   uint32_t k0, k1, layer_id, sample_offset;
@@ -269,7 +271,7 @@ struct FinPack {
 // Returns false for the padding blocks of the XCD-aware grid (no work done).  `forced_item` >= 0 runs that
 // work item whatever the block index is (the fused-tail kernel hands the last layer to whichever block
 // finished the layer before it last).
-template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false>
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false>
 __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, int forced_item = -1) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -316,9 +318,12 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
 
   // (mu, rho) of this lane for super-step t: prefetched one step ahead.
   float mu_n[8], rho_n[8];
+  float4 wraw_n = make_float4(0.f, 0.f, 0.f, 0.f);    // PRE: the lane's 8 sampled bf16 weights of the step
   auto load_params = [&](int t) {
     const int k = (t * R + c) * 32 + q * 8;
-    if (TRANS) {
+    if (PRE) {
+      wraw_n = *reinterpret_cast<const float4*>(p.w_pre + ((size_t)s * N + nc) * K + min(k, K - 8));
+    } else if (TRANS) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const size_t woff = (size_t)min(k + j, K - 1) * p.ldw + nc;
@@ -339,7 +344,9 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   if (t_lo + wave < t_hi) load_params(t_lo + wave);
   // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
+  if (PRE) {
+    if (wave == nw - 1 && lane < F && n_ok && ks == 0) bmu_pre = p.b_pre[(size_t)s * N + n];
+  } else if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
     beps_pre = bias_eps(p, n, s, gs, do_dump);
@@ -397,11 +404,15 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
       mu[j] = mu_n[j];
       sg[j] = rho_n[j];
     }
+    const float4 wraw = wraw_n;
     if (t + nw < t_hi) load_params(t + nw);
     if (t == t_lo + wave) { asm volatile("" :: "v"(mu[0]), "v"(sg[0])); BNN_STAMP(1); }
 
     float e[8], w[8];
-    if (TRANS) {
+    if (PRE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = w[j] = 0.f;
+    } else if (TRANS) {
       const uint32_t gprw = (uint32_t)((p.ldw + 3) >> 2);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -429,14 +440,16 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
     // ALIGNED: a lane's 8 weights are all real or all padding (valid is 8 or <= 0), so one mask
     // per step suffices: padded lanes compute on clamped (finite) data and are zeroed at the end.
     float e2 = 0.f, a = 0.f, ls = 0.f;
+    if (!PRE) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = ALIGNED ? true : (j < valid);
-      sg[j] = softplus(sg[j]);
-      w[j] = ok ? __builtin_fmaf(sg[j], e[j], mu[j]) : 0.f;
-      e2 += ok ? e[j] * e[j] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = ALIGNED ? true : (j < valid);
+        sg[j] = softplus(sg[j]);
+        w[j] = ok ? __builtin_fmaf(sg[j], e[j], mu[j]) : 0.f;
+        e2 += ok ? e[j] * e[j] : 0.f;
+      }
     }
-    if (do_stats) {
+    if (do_stats && !PRE) {
       if (p.prior_kind == BNN_PRIOR_GAUSS) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
@@ -465,6 +478,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
         wa[j] = (__bf16)w[j];
         wz[j] = (__bf16)0.f;
       }
+      if (PRE && valid > 0) wa = __builtin_bit_cast(bf16x8, wraw);     // padding lanes (k >= K, n >= N) stay zero
     }
 #pragma unroll
     for (int ch = 0; ch < 8 / MC; ++ch) {
@@ -511,7 +525,8 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   // ---- bias of the tile's F features: wave 0, lanes 0..F-1
   if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
-    if (!TRANS && lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    if (PRE) b = (lane < F && n_ok && ks == 0) ? bmu_pre : 0.f;
+    else if (!TRANS && lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
     lds_bias[lane] = b;
   }
 #pragma unroll
@@ -695,6 +710,12 @@ __global__ __launch_bounds__(768) void bbb_fwd_tail2_kernel(const BbbK p2, const
   if (last_flag == 0u) return;                           // block-uniform
   __syncthreads();
   bbb_fwd_body<MATH, BNN_BF16, 1, true, true>(p3, &fp, 0);
+}
+
+// matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
+template <int XDT, int R>
+__global__ __launch_bounds__(768) void bbb_fwd_pre_kernel(const BbbK p) {
+  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false, false, true>(p, nullptr);
 }
 
 template <int MATH, int R, bool ALIGNED>
@@ -1052,15 +1073,25 @@ hipError_t allow_big_lds(KernelT kernel, size_t lds) {
 // applies (K % 8 == 0, aligned bases).
 static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.mask = nullptr; k.mask_sstride = 0;      // input-gradient form only
+  k.w_pre = nullptr; k.b_pre = nullptr;      // set below for the matmul-only form
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
   if ((double)a->n_samples * ((a->batch + 127) / 128) * ((a->out_features + 3) / 4) > 2.0e9) return BNN_ERR_SHAPE;
-  if (!a->x || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->y) return BNN_ERR_NULL;
+  const bool pre = a->w_sampled != nullptr;
+  if (!a->x || !a->y) return BNN_ERR_NULL;
+  if (!pre && (!a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho)) return BNN_ERR_NULL;
+  if (pre) {                                       // matmul half over bnn_bbb_sample_weights' output
+    if (!a->b_sampled) return BNN_ERR_NULL;
+    if (a->math != BNN_MATH_BF16 || a->want_stats || a->log_prior || a->log_q || a->eps_w_dump || a->eps_b_dump ||
+        (a->in_features & 7))
+      return BNN_ERR_SHAPE;
+    if (!aligned16(a->x) || !aligned16(a->w_sampled)) return BNN_ERR_ALIGN;
+  }
   if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u ||
       (unsigned)a->prior.kind > 1u)
     return BNN_ERR_ENUM;
-  if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
+  if (!pre && a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
   if (a->want_stats) {
     if (!a->workspace || a->workspace_bytes < bnn_bbb_linear_fwd_workspace_bytes(a->n_samples, a->out_features))
       return BNN_ERR_WORKSPACE;
@@ -1100,7 +1131,12 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   }
   const int K = a->in_features;
   al = (K % 8 == 0) && aligned16(a->x) && aligned16(a->w_mu) && aligned16(a->w_rho);
-  if (a->eps_mode == BNN_EPS_MEMORY) al = al && aligned16(a->eps_w);
+  if (pre) {
+    k.w_pre = reinterpret_cast<const __bf16*>(a->w_sampled);
+    k.b_pre = a->b_sampled;
+    k.eps_mode = BNN_EPS_ZERO;
+    al = true;
+  } else if (a->eps_mode == BNN_EPS_MEMORY) al = al && aligned16(a->eps_w);
   if (a->eps_w_dump) al = al && aligned16(a->eps_w_dump);
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
@@ -1138,6 +1174,39 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (fk >= 1 && fk <= max_ks) ksl = fk;
     if (ksl < 1) ksl = 1;
     if (a->split_scratch_bytes < (size_t)ksl * part_bytes || (reinterpret_cast<uintptr_t>(a->split_scratch) & 15)) ksl = 1;
+  }
+  if (a->w_sampled) {
+    // ---- matmul half only: same tile machinery, no generator work.  (A variant that issued every load of a wave
+    // in one round -- 10 waves x 2 steps of 64 k, 136 landing registers -- measured slower: 11.8 against 8.7 us at
+    // 128 x 1200 x 1200; the launch is bound by its ~300 KB of x per block through L1, not by dependent rounds.)
+    Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, true, a->concurrency);
+    const int fr = env_int("BNN_HIP_PRE_R", 0), fw = env_int("BNN_HIP_PRE_WAVES", 0);
+    if (fr == 1 || fr == 2 || fr == 4) {
+      pl.R = fr;
+      pl.tiles = (a->out_features + 16 / fr - 1) / (16 / fr);
+    }
+    if (fw >= 1 && fw <= 12) pl.nw = fw;
+    const long total = (long)pl.tiles * a->n_samples * mbs;
+    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
+    const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+#define BNN_PRE(XDT, RR)                                                                     \
+  do {                                                                                       \
+    err = allow_big_lds(bbb_fwd_pre_kernel<XDT, RR>, lds);                                   \
+    if (err == hipSuccess)                                                                   \
+      hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, RR>), grid, block, lds, stream, k);        \
+  } while (0)
+#define BNN_PRE_R(XDT)                      \
+  do {                                      \
+    if (pl.R == 1) BNN_PRE(XDT, 1);         \
+    else if (pl.R == 2) BNN_PRE(XDT, 2);    \
+    else BNN_PRE(XDT, 4);                   \
+  } while (0)
+    if (xdt == BNN_F32) BNN_PRE_R(BNN_F32); else BNN_PRE_R(BNN_BF16);
+#undef BNN_PRE
+#undef BNN_PRE_R
+    if (err != hipSuccess) return (int)err;
+    err = hipGetLastError();
+    return err == hipSuccess ? BNN_OK : (int)err;
   }
   const bool gemm_ok = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8;
   const bool use_gemm = gemm_ok && (force == 1 || (force != 0 && (gemm_blocks >= 450 || (ksl > 1 && gemm_blocks * ksl >= 300))));

@@ -144,10 +144,58 @@ typedef struct bnn_bbb_fwd_args {
   size_t split_scratch_bytes;
   const float* w_sigma;     /* optional [out,in]: softplus(w_rho) from bnn_softplus, computed once per
                                evaluation; the throughput kernel then skips the per-sample softplus */
+  const void* w_sampled;    /* optional bf16 [n_samples,out,in] from bnn_bbb_sample_weights: the launch is then the
+                               matmul half only, y = act(x . w_sampled^T + b_sampled) -- no sampling, no statistics
+                               (want_stats must be 0; w_mu .. eps_* are ignored and may be NULL).  bf16 math,
+                               in_features % 8 == 0, 16-byte aligned x and w_sampled */
+  const float* b_sampled;   /* with w_sampled: fp32 [n_samples,out] */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
 int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1s  bnn_bbb_sample_weights — the sampling half of BayesianLinear.forward (networks.py:73-86) for up to
+ * BNN_SAMPLE_MAX_LAYERS layers and n_samples MC samples in ONE launch:
+ *     w_out[s] = bf16(mu + softplus(rho) * eps_s)  [n_samples,out,in],   b_out[s] likewise, fp32 [n_samples,out]
+ * with eps from the Philox map at the top (the same elements K1 would draw for these layer_ids / sample
+ * indices), and the per-sample statistics {sum eps^2, sum w^2 | sum log p_mix, sum log sigma} (taken from the
+ * fp32 w, as K1 does) in each layer's workspace in K1's format, so bnn_elbo_finalize / bnn_bbb_final_fwd consume
+ * them unchanged.  The matmuls then run as bnn_bbb_linear_fwd(w_sampled, b_sampled).  Sampling depends on no
+ * activation: out of the layer-after-layer chain of a few-sample evaluation it is one streaming pass over the
+ * parameters (8 B read + 2 B written per weight).  in_features % 8 == 0; 16-byte aligned pointers.
+ * ---------------------------------------------------------------------------------- */
+#define BNN_SAMPLE_MAX_LAYERS 8
+typedef struct bnn_bbb_sample_layer {
+  int32_t in_features, out_features;
+  uint32_t layer_id;
+  int32_t reserved;
+  const float* w_mu;        /* [out,in] */
+  const float* w_rho;
+  const float* b_mu;        /* [out] */
+  const float* b_rho;
+  void* w_out;              /* bf16 [n_samples,out,in] */
+  float* b_out;             /* [n_samples,out] */
+  void* workspace;          /* >= bnn_bbb_sample_workspace_bytes(n_samples, in, out) */
+  size_t workspace_bytes;
+  bnn_prior prior;
+  int32_t reserved2;
+} bnn_bbb_sample_layer;
+
+typedef struct bnn_bbb_sample_args {
+  uint32_t struct_bytes;
+  int32_t n_layers;
+  int32_t n_samples;
+  uint32_t sample_offset;
+  uint64_t seed;
+  const uint32_t* sample_counter;   /* optional device word, as in bnn_bbb_fwd_args */
+  bnn_bbb_sample_layer layer[BNN_SAMPLE_MAX_LAYERS];
+} bnn_bbb_sample_args;
+
+/* >= bnn_bbb_linear_fwd_workspace_bytes(n_samples, out_features): one workspace serves either form; 0 when
+ * in_features % 8 != 0 (the split form does not apply) */
+size_t bnn_bbb_sample_workspace_bytes(int32_t n_samples, int32_t in_features, int32_t out_features);
+int bnn_bbb_sample_weights(const bnn_bbb_sample_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K3  bnn_lr_linear_fwd — BayesianLinearLR.forward (networks.py:116-138) for n_samples

@@ -769,3 +769,39 @@ def test_fused_tail_of_a_one_sample_evaluation_equals_separate_launches(dev, mon
             close(pa[k], pb[k].cpu().numpy(), rtol=1e-3 if k == "nll" else 2e-6)
         close(sa, sb.cpu().numpy(), rtol=1e-3)
     assert not torch.equal(ra[0][0], ra[1][0])                   # fresh eps on every replay
+
+
+@pytest.mark.parametrize("prior", [ops.PriorSpec(False, 0.9), ops.PriorSpec(True, 1.0, 0.4, 1.1, 0.05)])
+@pytest.mark.parametrize("shape", [(1, 128, 784, 1200), (1, 128, 1200, 1200), (3, 20, 72, 38), (2, 7, 8, 5), (1, 130, 64, 17)])
+def test_split_sampling_then_matmul_equals_the_fused_layer(dev, prior, shape):
+    """K1s + matmul-only K1 against fused K1a on the same Philox elements: the sampled bf16 weights are the ones
+    K1a feeds its matrix core (recomputed here from K1a's eps dump), the outputs agree to fp32 summation order,
+    the statistics to fp32 summation order, the sampled biases exactly."""
+    S, B, K, N = shape
+    rs = np.random.RandomState(21)
+    mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+    x = mk(B, K, lo=-1, hi=1).to(torch.bfloat16)
+    w_mu, w_rho, b_mu, b_rho = mk(N, K), mk(N, K, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
+    fused = ops.bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, n_samples=S, prior=prior, math_mode=L.MATH_BF16, relu=True,
+                               y_dtype=torch.float32, eps_mode=L.EPS_PHILOX, seed=77, layer_id=3, sample_offset=9,
+                               want_stats=True, dump_eps=True)
+    sm = ops.bbb_sample_weights([dict(w_mu=w_mu, w_rho=w_rho, b_mu=b_mu, b_rho=b_rho, prior=prior, layer_id=3)],
+                                n_samples=S, seed=77, sample_offset=9)[0]
+    y = ops.bbb_sampled_matmul(x, sm["w"], sm["b"], n_samples=S, relu=True, y_dtype=torch.float32)
+    # sampled parameters: same eps elements, same arithmetic up to the last ulp of softplus
+    sig = torch.log1p(torch.exp(w_rho.double()))
+    w_ref = (w_mu.double() + sig * fused["eps_w"].double())
+    err = (sm["w"].double() - w_ref).abs()
+    assert float((err / (w_ref.abs() + 1e-3)).max()) <= 2.0 ** -8              # bf16 rounding of the fp32 value
+    b_ref = b_mu.double() + torch.log1p(torch.exp(b_rho.double())) * fused["eps_b"].double()
+    close(sm["b"], b_ref.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    # outputs: both feed bf16(w) and bf16 x to the matrix core, fp32 accumulate
+    scale = float(fused["y"].abs().max()) + 1e-6
+    assert float((y - fused["y"]).abs().max()) <= 2e-5 * scale
+    # statistics per sample
+    def sums(ws):
+        T = int(ws[:1].view(torch.int32)[0])
+        return ws[4:4 + 4 * S * T].view(S, T, 4).double().sum(1), ws[4:4 + 4 * T].view(T, 4).double().sum(0)[2]
+    (fa, fls), (sa, sls) = sums(fused["workspace"]), sums(sm["workspace"])
+    close(sa[:, :2], fa[:, :2].cpu().numpy(), rtol=2e-5, atol=1e-3)
+    close(sls, float(fls), rtol=2e-5)
