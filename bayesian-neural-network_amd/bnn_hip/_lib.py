@@ -70,6 +70,7 @@ class SampleArgs(C.Structure):
         ("struct_bytes", C.c_uint32), ("n_layers", C.c_int32), ("n_samples", C.c_int32), ("sample_offset", C.c_uint32),
         ("seed", C.c_uint64), ("sample_counter", C.c_void_p),
         ("layer", SampleLayer * SAMPLE_MAX_LAYERS),
+        ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_n", C.c_int64),
     ]
 
 

@@ -31,6 +31,12 @@ SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = 4, 24
 SPLIT_MIN_WEIGHTS = 0 if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else 4_000_000
 
 
+# BBB, bf16 math: evaluations of at most this many MC samples take the split form -- ONE streaming launch samples the
+# hidden layers' weights (bnn_bbb_sample_weights, the input cast riding on it), the hidden layers are then matmul-only
+# launches over the sampled bf16 weights, the output layer + finalize stay fused.  0 = never.
+PRESAMPLE_MAX_SAMPLES = int(os.environ.get("BNN_HIP_PRESAMPLE", "0"))
+
+
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
 # chip; BNN_HIP_FUSED_ELBO=0 keeps one node per layer (the form the identical-eps parity path always uses)
 FUSED_ELBO_NODE = os.environ.get("BNN_HIP_FUSED_ELBO", "1") != "0"
@@ -343,9 +349,18 @@ class GraphedElbo:
             self.ring = (torch.zeros(1, dtype=torch.int32, device=dev), int(sums_ring[1]), int(sums_ring[2]))
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
+        nl = len(self.specs)
+        self.presample = (not self.lr and hid == torch.bfloat16 and 0 < S <= PRESAMPLE_MAX_SAMPLES and nl >= 2 and
+                          all(sp.in_out[0] % 8 == 0 for sp in self.specs[:-1]))
+        self.wsamp = self.bsamp = None
+        if self.presample:
+            self.wsamp = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) for sp in self.specs[:-1]]
+            self.bsamp = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) for sp in self.specs[:-1]]
+            for i, sp in enumerate(self.specs[:-1]):
+                self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
-                        S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) else None)
+                        (self.presample or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES))) else None)
         self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
@@ -384,7 +399,16 @@ class GraphedElbo:
     def _enqueue(self):
         math_mode = state.math
         h_sq = None
-        if self.x16 is None:
+        if self.presample:
+            hidden = self.specs[:-1]
+            ops.bbb_sample_weights(
+                [dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
+                      b_rho=sp.m.bias_rho.detach(), prior=sp.m._prior_spec, layer_id=sp.layer_id, workspace=self.ws[i],
+                      w_out=self.wsamp[i], b_out=self.bsamp[i]) for i, sp in enumerate(hidden)],
+                n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter,
+                cast=(self.x, self.x16) if self.x16 is not None else None)
+            h = self.x16 if self.x16 is not None else self.x
+        elif self.x16 is None:
             h = self.x
         elif self.lr_sq:
             h, h_sq = ops.cast_bf16(self.x, out=self.x16, out_sq=self.x16_sq)
@@ -403,7 +427,10 @@ class GraphedElbo:
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i],
                           concurrency=self.stride)      # evaluators that run side by side: size launches for a share of the chip
-            if self.lr:
+            if self.presample and i < last:
+                ops.bbb_sampled_matmul(h, self.wsamp[i], self.bsamp[i], n_samples=self.n_local, relu=sp.relu,
+                                       y_dtype=self.bufs[i].dtype, out=self.bufs[i], concurrency=self.stride)
+            elif self.lr:
                 if self.wfrag[i] is not None:
                     ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
@@ -419,7 +446,7 @@ class GraphedElbo:
                 ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
                                                  w_sigma=self.wsigma[i], **common),
                                   dict(workspaces=self.ws[:last], **fin_kw))
-            elif i == last - 1 and self.n_local == 1 and self.bufs[i].dtype == torch.bfloat16 and \
+            elif i == last - 1 and not self.presample and self.n_local == 1 and self.bufs[i].dtype == torch.bfloat16 and \
                     h.dtype == torch.bfloat16 and self.split[i] is None and self.wsigma[i] is None:
                 pending = ((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common))   # launched with the last layer
             else:

@@ -171,10 +171,10 @@ def sample_workspace(n_samples: int, fin: int, fout: int, device) -> torch.Tenso
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: int = 0, sample_counter=None):
+def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: int = 0, sample_counter=None, cast=None):
     """K1s (bnn_bbb_sample_weights): `layers` = list of dicts(w_mu [out,in], w_rho, b_mu, b_rho, prior, layer_id,
     workspace=None, w_out=None, b_out=None).  One launch samples them all; returns a list of dicts(w [S,out,in] bf16,
-    b [S,out] fp32, workspace)."""
+    b [S,out] fp32, workspace).  `cast` = (fp32 tensor, bf16 tensor): also converts the input batch in that launch."""
     lib = L.load()
     if not 1 <= len(layers) <= L.SAMPLE_MAX_LAYERS:
         raise BnnHipError(f"bbb_sample_weights: 1..{L.SAMPLE_MAX_LAYERS} layers per launch")
@@ -213,6 +213,13 @@ def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: 
         e.prior = ly["prior"].c()
         res.append(dict(w=w, b=b, workspace=ws))
         keep.append((w_mu, w_rho, b_mu, b_rho))
+    if cast is not None:                      # (fp32 src, bf16 dst): the input batch cast rides on the launch
+        src, dst = cast
+        require_device(src, dst)
+        if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.numel() != dst.numel() or \
+                not src.is_contiguous() or not dst.is_contiguous():
+            raise BnnHipError("bbb_sample_weights: cast = (contiguous fp32 source, contiguous bf16 destination) of one size")
+        a.cast_src, a.cast_dst, a.cast_n = src.data_ptr(), dst.data_ptr(), src.numel()
     L.check(lib.bnn_bbb_sample_weights(C.byref(a), _stream()), "bnn_bbb_sample_weights")
     return res
 

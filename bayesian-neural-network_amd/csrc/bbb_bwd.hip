@@ -81,7 +81,9 @@ __device__ __forceinline__ float sigmoidf(float r) { return __builtin_amdgcn_rcp
 // VEC: K % 4 == 0 and 16-byte aligned rows.  No load sits under per-lane control flow (a load in a
 // divergent branch gets its own basic block and the waits between blocks serialise the batch):
 // indices are clamped and the result selected afterwards.
-template <bool VEC>
+// MEM: eps comes from memory (BNN_EPS_MEMORY).  The Philox instantiation has no load in its per-sample epilogue,
+// so no wait there holds it back while the next sample's first group is in flight.
+template <bool VEC, bool MEM>
 __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -112,32 +114,26 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
     G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     H[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // raw parameter loads now; they are unpacked (softplus) after the first x / gz group has been requested too,
+  // so the launch starts with ONE memory round trip instead of two
+  float4 m4r[4], r4r[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int kq = k0 + q * 16 + reg * 4;                 // 4 consecutive k of feature n: one 16-byte access
     const size_t rowoff = (size_t)min(n, N - 1) * K;
     if (VEC) {
-      const float4 m4 = *reinterpret_cast<const float4*>(p.w_mu + rowoff + min(kq, K - 4));
-      const float4 r4 = *reinterpret_cast<const float4*>(p.w_rho + rowoff + min(kq, K - 4));
-      mu[reg][0] = m4.x; mu[reg][1] = m4.y; mu[reg][2] = m4.z; mu[reg][3] = m4.w;
-      rh[reg][0] = r4.x; rh[reg][1] = r4.y; rh[reg][2] = r4.z; rh[reg][3] = r4.w;
+      m4r[reg] = *reinterpret_cast<const float4*>(p.w_mu + rowoff + min(kq, K - 4));
+      r4r[reg] = *reinterpret_cast<const float4*>(p.w_rho + rowoff + min(kq, K - 4));
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        mu[reg][i] = p.w_mu[rowoff + min(kq + i, K - 1)];
-        rh[reg][i] = p.w_rho[rowoff + min(kq + i, K - 1)];
-      }
+      m4r[reg] = make_float4(p.w_mu[rowoff + min(kq + 0, K - 1)], p.w_mu[rowoff + min(kq + 1, K - 1)],
+                             p.w_mu[rowoff + min(kq + 2, K - 1)], p.w_mu[rowoff + min(kq + 3, K - 1)]);
+      r4r[reg] = make_float4(p.w_rho[rowoff + min(kq + 0, K - 1)], p.w_rho[rowoff + min(kq + 1, K - 1)],
+                             p.w_rho[rowoff + min(kq + 2, K - 1)], p.w_rho[rowoff + min(kq + 3, K - 1)]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sg[reg][i] = softplus(rh[reg][i]);
   }
   const bool do_bias = kblk == 0 && q == 0 && n_ok;         // one lane per feature
-  float bmu = 0.f, brh = 0.f, bsg = 1.f, Gb = 0.f, Hb = 0.f;
-  if (do_bias) {
-    bmu = p.b_mu[n];
-    brh = p.b_rho[n];
-    bsg = softplus(brh);
-  }
+  const float bmu_raw = p.b_mu[min(n, N - 1)], brh_raw = p.b_rho[min(n, N - 1)];
+  float Gb = 0.f, Hb = 0.f, bmu = 0.f, brh = 0.f, bsg = 1.f;   // bias parameters: unpacked with the weights' below
   float cq = 0.f;
   const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   const int ka = k0 + 4 * r;                               // first k of this lane's A-operand quad
@@ -154,8 +150,15 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   float colsum = 0.f;
   float4 avA[U], avB[U];
   float bvA[U], bvB[U];
-  auto load_group = [&](int gi, float4 (&av)[U], float (&bv)[U]) {
+  // the sample's upstream scalars ride with its groups (a load inside the epilogue would make it wait for
+  // everything in flight): always loaded from a valid address, selected afterwards
+  const float* glp_src = p.glp ? p.glp : p.b_mu;
+  const float* glq_src = p.glq ? p.glq : p.b_mu;
+  float gsA[2], gsB[2];
+  auto load_group = [&](int gi, float4 (&av)[U], float (&bv)[U], float (&gsc)[2]) {
     const int s = gi / G_, b0 = (gi - s * G_) * (4 * U);
+    gsc[0] = glp_src[p.glp ? s : 0];
+    gsc[1] = glq_src[p.glq ? s : 0];
     const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
     const float* gzs = p.gz + (size_t)s * B * N;
 #pragma unroll
@@ -185,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
     }
   };
   // epilogue of sample s: regenerate eps of the lane's weights, fold the sample's gW tile into (G, H)
-  auto finish_sample = [&](int s) {
+  auto finish_sample = [&](int s, const float (&gsc)[2]) {
     if (s == 0) { asm volatile("" ::"v"(acc[3][3])); BWD_STAMP(3); }
-    const float glp = p.glp ? p.glp[s] : 0.f;
-    cq += p.glq ? p.glq[s] : 0.f;
+    const float glp = p.glp ? gsc[0] : 0.f;
+    cq += p.glq ? gsc[1] : 0.f;
     const uint32_t gs = sample_base + (uint32_t)s;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.eps_mode == BNN_EPS_PHILOX) {
           philox_normal4((uint32_t)n * (uint32_t)gpr + (uint32_t)(kb >> 2), gs, p.layer_id * 4u, p.k0, p.k1, e);
-        } else if (p.eps_mode == BNN_EPS_MEMORY) {
+        } else if (MEM && p.eps_mode == BNN_EPS_MEMORY) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (kb + i < K) e[i] = p.eps_w[((size_t)s * N + n) * K + kb + i];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
         float e4[4];
         philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
         e = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
-      } else if (p.eps_mode == BNN_EPS_MEMORY) {
+      } else if (MEM && p.eps_mode == BNN_EPS_MEMORY) {
         e = p.eps_b[(size_t)s * N + n];
       }
       const float bw = __builtin_fmaf(bsg, e, bmu);
@@ -236,19 +239,32 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   // Loads are issued unconditionally (the last ones re-read the final group): a load under a branch would make the
   // join point wait for vmcnt(0), i.e. for the group just issued, which is the round trip this pipeline hides.
   const int last_group = total_groups - 1;
-  load_group(0, avA, bvA);
+  load_group(0, avA, bvA, gsA);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    mu[reg][0] = m4r[reg].x; mu[reg][1] = m4r[reg].y; mu[reg][2] = m4r[reg].z; mu[reg][3] = m4r[reg].w;
+    rh[reg][0] = r4r[reg].x; rh[reg][1] = r4r[reg].y; rh[reg][2] = r4r[reg].z; rh[reg][3] = r4r[reg].w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[reg][i] = softplus(rh[reg][i]);
+  }
+  if (do_bias) {
+    bmu = bmu_raw;
+    brh = brh_raw;
+    bsg = softplus(brh);
+  }
   for (int gi = 0; gi < total_groups; gi += 2) {
-    load_group(min(gi + 1, last_group), avB, bvB);
+    load_group(min(gi + 1, last_group), avB, bvB, gsB);
     __builtin_amdgcn_sched_barrier(0);                     // the loads stay a batch, issued ahead of the MFMAs
     if (gi == 0) { asm volatile("" ::"v"(sg[0][0]), "v"(avA[0].x)); BWD_STAMP(1); }
     mfma_group(avA, bvA);
     if (gi == 0) { asm volatile("" ::"v"(acc[0][0])); BWD_STAMP(2); }
-    if ((gi + 1) % G_ == 0) finish_sample(gi / G_);
-    load_group(min(gi + 2, last_group), avA, bvA);
+    if ((gi + 1) % G_ == 0) finish_sample(gi / G_, gsA);
+    load_group(min(gi + 2, last_group), avA, bvA, gsA);
     __builtin_amdgcn_sched_barrier(0);
     if (gi + 1 < total_groups) {
       mfma_group(avB, bvB);
-      if ((gi + 2) % G_ == 0) finish_sample((gi + 1) / G_);
+      if ((gi + 2) % G_ == 0) finish_sample((gi + 1) / G_, gsB);
     }
   }
 
@@ -365,8 +381,14 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   }
   const int nblocks = ((a->in_features + 63) / 64) * ((a->out_features + 63) / 64);
   const dim3 grid((unsigned)(((nblocks + 7) / 8) * 8)), block(256);
-  if ((a->in_features & 3) == 0) hipLaunchKernelGGL(bbb_bwd_weights_kernel<true>, grid, block, 0, stream, k);
-  else hipLaunchKernelGGL(bbb_bwd_weights_kernel<false>, grid, block, 0, stream, k);
+  const bool mem = a->eps_mode == BNN_EPS_MEMORY;
+  if ((a->in_features & 3) == 0) {
+    if (mem) hipLaunchKernelGGL((bbb_bwd_weights_kernel<true, true>), grid, block, 0, stream, k);
+    else hipLaunchKernelGGL((bbb_bwd_weights_kernel<true, false>), grid, block, 0, stream, k);
+  } else {
+    if (mem) hipLaunchKernelGGL((bbb_bwd_weights_kernel<false, true>), grid, block, 0, stream, k);
+    else hipLaunchKernelGGL((bbb_bwd_weights_kernel<false, false>), grid, block, 0, stream, k);
+  }
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) return bnn_bbb_input_grad_(a, gz, stream_);

@@ -49,6 +49,10 @@ struct SampleK {
   int n_layers, S;
   uint32_t k0, k1, sample_offset;
   const uint32_t* sample_counter;
+  const float* cast_src;   // optional rider: cast_dst[i] = bf16(cast_src[i]), the evaluation's input batch
+  __bf16* cast_dst;
+  long cast_n;
+  int cast_first;          // first block of the cast job (after every layer's blocks)
 };
 
 __device__ __forceinline__ float sample_mix_logp(const SampleL& L, float w) {
@@ -60,6 +64,19 @@ __device__ __forceinline__ float sample_mix_logp(const SampleL& L, float w) {
 
 __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const SampleK p) {
   __shared__ float red[kSampleThreads / 64][3];
+  if ((int)blockIdx.x >= p.cast_first) {                   // rider: fp32 -> bf16 of the input batch, 8 per thread
+    const long i = ((long)((int)blockIdx.x - p.cast_first) * kSampleThreads + threadIdx.x) * 8;
+    if (i + 7 < p.cast_n && (p.cast_n & 7) == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(p.cast_src + i), b = *reinterpret_cast<const float4*>(p.cast_src + i + 4);
+      bf16x8 o;
+      o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+      o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+      *reinterpret_cast<bf16x8*>(p.cast_dst + i) = o;
+    } else {
+      for (long j = i; j < i + 8 && j < p.cast_n; ++j) p.cast_dst[j] = (__bf16)p.cast_src[j];
+    }
+    return;
+  }
   int l = 0;
 #pragma unroll 1
   while (l + 1 < p.n_layers && (int)blockIdx.x >= p.L[l + 1].first_block) ++l;
@@ -226,6 +243,16 @@ extern "C" int bnn_bbb_sample_weights(const bnn_bbb_sample_args* a, void* stream
   k.n_layers = a->n_layers; k.S = a->n_samples;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
+  k.cast_src = a->cast_src; k.cast_dst = reinterpret_cast<__bf16*>(a->cast_dst); k.cast_n = (long)a->cast_n;
+  k.cast_first = (int)blocks;
+  if (a->cast_n > 0) {
+    if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst)) & 15) return BNN_ERR_ALIGN;
+    blocks += (a->cast_n + kSampleThreads * 8 - 1) / (kSampleThreads * 8);
+    if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
+  } else if (a->cast_n < 0) {
+    return BNN_ERR_SHAPE;
+  }
   hipLaunchKernelGGL(bbb_sample_kernel, dim3((unsigned)blocks), dim3(kSampleThreads), 0, reinterpret_cast<hipStream_t>(stream_),
                      k);
   const hipError_t err = hipGetLastError();

@@ -190,6 +190,9 @@ typedef struct bnn_bbb_sample_args {
   uint64_t seed;
   const uint32_t* sample_counter;   /* optional device word, as in bnn_bbb_fwd_args */
   bnn_bbb_sample_layer layer[BNN_SAMPLE_MAX_LAYERS];
+  const float* cast_src;            /* optional rider on the same launch: cast_dst[i] = bf16(cast_src[i]), */
+  void* cast_dst;                   /* i < cast_n -- the evaluation's input batch for the bf16 matmuls      */
+  int64_t cast_n;                   /* (16-byte aligned pointers); 0 = none                                  */
 } bnn_bbb_sample_args;
 
 /* >= bnn_bbb_linear_fwd_workspace_bytes(n_samples, out_features): one workspace serves either form; 0 when

@@ -805,3 +805,35 @@ def test_split_sampling_then_matmul_equals_the_fused_layer(dev, prior, shape):
     (fa, fls), (sa, sls) = sums(fused["workspace"]), sums(sm["workspace"])
     close(sa[:, :2], fa[:, :2].cpu().numpy(), rtol=2e-5, atol=1e-3)
     close(sls, float(fls), rtol=2e-5)
+
+
+@pytest.mark.parametrize("samples", [1, 2])
+def test_presampled_evaluation_equals_the_fused_evaluation(dev, monkeypatch, samples):
+    """GraphedElbo in its split form (one sampling launch for the hidden layers with the input cast riding on it,
+    matmul-only hidden layers, fused output layer + finalize) against the default fused form: same Philox elements,
+    so the scalars agree to summation order and the bf16 rounding of the hidden activations, replay after replay."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    outs = []
+    for pre in (2, 0):
+        monkeypatch.setattr(engine, "PRESAMPLE_MAX_SAMPLES", pre)
+        bnn_hip.manual_seed(37, counter=500)
+        ev = engine.GraphedElbo(net, xd, yd, samples, counter_stride=4)
+        assert ev.presample == bool(pre)
+        rec = []
+        for _ in range(3):
+            sums = ev.replay().clone()
+            rec.append((sums, {k: v.clone() for k, v in ev.out.items()}, ev.logits.clone()))
+        outs.append((rec, int(ev.counter.item())))
+    (ra, ca), (rb, cb) = outs
+    assert ca == cb
+    for (sa, pa, la), (sb, pb, lb) in zip(ra, rb):
+        scale = float(lb.abs().max())
+        assert float((la - lb).abs().max()) <= 2e-2 * scale      # fp32 x vs bf16 x into layer 1, bf16 hidden activations
+        for k in pa:
+            close(pa[k], pb[k].cpu().numpy(), rtol=2e-2 if k == "nll" else 2e-6)
+        close(sa[:2], sb[:2].cpu().numpy(), rtol=2e-6)
+    assert not torch.equal(ra[0][0], ra[1][0])
