@@ -83,9 +83,19 @@ __device__ __forceinline__ float sigmoidf(float r) { return __builtin_amdgcn_rcp
 // indices are clamped and the result selected afterwards.
 // MEM: eps comes from memory (BNN_EPS_MEMORY).  The Philox instantiation has no load in its per-sample epilogue,
 // so no wait there holds it back while the next sample's first group is in flight.
+//
+// Block = 32 features x 64 k, four waves: wave = (sub, half).  `sub` picks 16 of the features, `half` the parity of
+// the 16-row batch groups the wave reduces over; per sample the two halves swap partial accumulators through LDS and
+// each finishes HALF of the tile's weights (D registers 2 half, 2 half + 1: two Philox groups per lane).  The kernel
+// is bound by the fp32 matrix core and the generator, so what matters is how evenly the work lands on the SIMDs:
+// 64 x 64 blocks of four full waves were 1444 equal units on 1024 SIMDs (makespan 2 units); these are 2888 half
+// units (makespan 3 halves) at the 1200 x 1200 layer.
 template <bool VEC, bool MEM>
-__global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
+__global__ __launch_bounds__(256, 3) void bbb_bwd_weights_kernel(const BwdK p) {
+  __shared__ float xch[2][2][2][8][64];                   // [sample parity][sub][destination half][jr * 4 + tile][lane]
+  __shared__ float xcs[2][2][64];                         // [sample parity][sub][lane]: half 1's column sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = wave & 1, half = wave >> 1;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
   BWD_STAMP(0);
@@ -94,56 +104,53 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   // x and that slice stay in its own L2 instead of every L2 holding everything
   const int nkb = (K + 63) >> 6;
   int item;
-  if (!xcd_work_item(nkb * ((N + 63) >> 6), item)) return;
+  if (!xcd_work_item(nkb * ((N + 31) >> 5), item)) return;   // block-uniform: before any barrier
   const int kblk = item % nkb, nblk = item / nkb;
   const int k0 = kblk * 64;
-  const int n0 = nblk * 64 + wave * 16;
-  if (n0 >= N) return;                                   // wave-uniform; no barriers below
-  const int n = n0 + r;                                   // this lane's feature (D column / B-operand column)
-  const bool n_ok = n < N;
+  const int n = nblk * 32 + sub * 16 + r;                  // this lane's feature (D column / B-operand column)
+  const bool n_ok = n < N;                                 // a sub-tile past N runs on clamped data and stores nothing
   const int gpr = (K + 3) >> 2;
 
   // Tile i (i = 0..3) of the 64-wide k strip holds the k's congruent to i mod 4: A row r of tile i is
   // k = k0 + 4 r + i, so ONE 16-byte load x[b][k0 + 4r .. +3] feeds all four tiles, and D register
   // `reg` of lane quad q, taken across the four tiles, is the 4 consecutive k's
-  // k0 + 16 q + 4 reg + {0,1,2,3} of feature n: one Philox group.
-  float mu[4][4], sg[4][4], rh[4][4];                     // [reg][i]
-  f32x4 G[4], H[4];                                       // [i][reg]
+  // k0 + 16 q + 4 reg + {0,1,2,3} of feature n: one Philox group.  This wave finishes reg = 2 half + jr.
+  float mu[2][4], sg[2][4], rh[2][4];                      // [jr][i]
+  float G[4][2], H[4][2];                                  // [i][jr]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    H[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jr = 0; jr < 2; ++jr) G[i][jr] = H[i][jr] = 0.f;
   // raw parameter loads now; they are unpacked (softplus) after the first x / gz group has been requested too,
   // so the launch starts with ONE memory round trip instead of two
-  float4 m4r[4], r4r[4];
+  float4 m4r[2], r4r[2];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int kq = k0 + q * 16 + reg * 4;                 // 4 consecutive k of feature n: one 16-byte access
+  for (int jr = 0; jr < 2; ++jr) {
+    const int kq = k0 + q * 16 + (2 * half + jr) * 4;      // 4 consecutive k of feature n: one 16-byte access
     const size_t rowoff = (size_t)min(n, N - 1) * K;
     if (VEC) {
-      m4r[reg] = *reinterpret_cast<const float4*>(p.w_mu + rowoff + min(kq, K - 4));
-      r4r[reg] = *reinterpret_cast<const float4*>(p.w_rho + rowoff + min(kq, K - 4));
+      m4r[jr] = *reinterpret_cast<const float4*>(p.w_mu + rowoff + min(kq, K - 4));
+      r4r[jr] = *reinterpret_cast<const float4*>(p.w_rho + rowoff + min(kq, K - 4));
     } else {
-      m4r[reg] = make_float4(p.w_mu[rowoff + min(kq + 0, K - 1)], p.w_mu[rowoff + min(kq + 1, K - 1)],
-                             p.w_mu[rowoff + min(kq + 2, K - 1)], p.w_mu[rowoff + min(kq + 3, K - 1)]);
-      r4r[reg] = make_float4(p.w_rho[rowoff + min(kq + 0, K - 1)], p.w_rho[rowoff + min(kq + 1, K - 1)],
-                             p.w_rho[rowoff + min(kq + 2, K - 1)], p.w_rho[rowoff + min(kq + 3, K - 1)]);
+      m4r[jr] = make_float4(p.w_mu[rowoff + min(kq + 0, K - 1)], p.w_mu[rowoff + min(kq + 1, K - 1)],
+                            p.w_mu[rowoff + min(kq + 2, K - 1)], p.w_mu[rowoff + min(kq + 3, K - 1)]);
+      r4r[jr] = make_float4(p.w_rho[rowoff + min(kq + 0, K - 1)], p.w_rho[rowoff + min(kq + 1, K - 1)],
+                            p.w_rho[rowoff + min(kq + 2, K - 1)], p.w_rho[rowoff + min(kq + 3, K - 1)]);
     }
   }
-  const bool do_bias = kblk == 0 && q == 0 && n_ok;         // one lane per feature
+  const bool do_bias = kblk == 0 && half == 0 && q == 0 && n_ok;   // one lane per feature
   const float bmu_raw = p.b_mu[min(n, N - 1)], brh_raw = p.b_rho[min(n, N - 1)];
   float Gb = 0.f, Hb = 0.f, bmu = 0.f, brh = 0.f, bsg = 1.f;   // bias parameters: unpacked with the weights' below
   float cq = 0.f;
   const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   const int ka = k0 + 4 * r;                               // first k of this lane's A-operand quad
 
-  // The (sample, 32-row group) pairs form one pipeline over two register buffers: the 16 loads of the next group --
-  // of the next SAMPLE at a sample's end -- are in flight while this group's 32 MFMAs issue and while the sample's
-  // epilogue regenerates eps (single-buffered, every group waited a full memory round trip: ~2 us of a ~2.4 us group).
-  constexpr int U = 8;                                     // batch-row quads per group (32 rows)
-  const int G_ = (B + 4 * U - 1) / (4 * U);                // groups per sample
-  const int total_groups = p.S * G_;
+  // The wave's (sample, 16-row group) pairs form one pipeline over two register buffers: the 8 loads of the next
+  // group -- of the next SAMPLE at a sample's end -- are in flight while this group's 16 MFMAs issue and while the
+  // sample's epilogue regenerates eps.
+  constexpr int U = 4;                                     // batch-row quads per group (16 rows): two buffers of 8 loads fit 3 blocks per CU
+  const int Gh = (((B + 4 * U - 1) / (4 * U)) + 1) >> 1;   // groups per sample and half (a group past B is all masked)
+  const int total_groups = p.S * Gh;
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   const float* glq_src = p.glq ? p.glq : p.b_mu;
   float gsA[2], gsB[2];
   auto load_group = [&](int gi, float4 (&av)[U], float (&bv)[U], float (&gsc)[2]) {
-    const int s = gi / G_, b0 = (gi - s * G_) * (4 * U);
+    const int s = gi / Gh, b0 = (2 * (gi - s * Gh) + half) * (4 * U);
     gsc[0] = glp_src[p.glp ? s : 0];
     gsc[1] = glq_src[p.glq ? s : 0];
     const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
@@ -187,15 +194,31 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
       acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u], acc[3], 0, 0, 0);
     }
   };
-  // epilogue of sample s: regenerate eps of the lane's weights, fold the sample's gW tile into (G, H)
+  // end of sample s for this wave: swap partials with the other half, then regenerate eps of the lane's two weight
+  // groups and fold the sample's gW into (G, H)
   auto finish_sample = [&](int s, const float (&gsc)[2]) {
     if (s == 0) { asm volatile("" ::"v"(acc[3][3])); BWD_STAMP(3); }
+    const int par = s & 1, other = half ^ 1;
+    // a wave is never more than one sample (one barrier) ahead of its block, so two parities of the buffer suffice
+#pragma unroll
+    for (int jr = 0; jr < 2; ++jr)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xch[par][sub][other][jr * 4 + i][lane] = half ? acc[i][jr] : acc[i][2 + jr];   // the OTHER half's registers
+    // bias: gb_s[n] = sum_b gz_s[b][n]; the 4 lane quads hold b = q (mod 4)
+    colsum += __shfl_xor(colsum, 16, kWave);
+    colsum += __shfl_xor(colsum, 32, kWave);
+    if (half == 1) xcs[par][sub][lane] = colsum;
+    __syncthreads();
     const float glp = p.glp ? gsc[0] : 0.f;
     cq += p.glq ? gsc[1] : 0.f;
     const uint32_t gs = sample_base + (uint32_t)s;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
+    for (int jr = 0; jr < 2; ++jr) {
+      const int reg = 2 * half + jr;
       const int kb = k0 + q * 16 + reg * 4;
+      float tot[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tot[i] = (half ? acc[i][2 + jr] : acc[i][jr]) + xch[par][sub][half][jr * 4 + i][lane];
       if (n_ok && kb < K) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.eps_mode == BNN_EPS_PHILOX) {
@@ -207,16 +230,13 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float w = __builtin_fmaf(sg[reg][i], e[i], mu[reg][i]);
-          const float t = acc[i][reg] + glp * dlogp(p, w);
-          G[i][reg] += t;
-          H[i][reg] = __builtin_fmaf(t, e[i], H[i][reg]);
+          const float w = __builtin_fmaf(sg[jr][i], e[i], mu[jr][i]);
+          const float t = tot[i] + glp * dlogp(p, w);
+          G[i][jr] += t;
+          H[i][jr] = __builtin_fmaf(t, e[i], H[i][jr]);
         }
       }
     }
-    // bias: gb_s[n] = sum_b gz_s[b][n]; the 4 lane quads hold b = q (mod 4)
-    colsum += __shfl_xor(colsum, 16, kWave);
-    colsum += __shfl_xor(colsum, 32, kWave);
     if (do_bias) {
       float e = 0.f;
       if (p.eps_mode == BNN_EPS_PHILOX) {
@@ -227,14 +247,14 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
         e = p.eps_b[(size_t)s * N + n];
       }
       const float bw = __builtin_fmaf(bsg, e, bmu);
-      const float t = colsum + glp * dlogp(p, bw);
+      const float t = colsum + xcs[par][sub][lane] + glp * dlogp(p, bw);
       Gb += t;
       Hb = __builtin_fmaf(t, e, Hb);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     colsum = 0.f;
-    if (s == 0) { asm volatile("" ::"v"(G[0][0]), "v"(H[3][3])); BWD_STAMP(4); }
+    if (s == 0) { asm volatile("" ::"v"(G[0][0]), "v"(H[3][1])); BWD_STAMP(4); }
   };
   // Loads are issued unconditionally (the last ones re-read the final group): a load under a branch would make the
   // join point wait for vmcnt(0), i.e. for the group just issued, which is the round trip this pipeline hides.
@@ -242,11 +262,11 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
   load_group(0, avA, bvA, gsA);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    mu[reg][0] = m4r[reg].x; mu[reg][1] = m4r[reg].y; mu[reg][2] = m4r[reg].z; mu[reg][3] = m4r[reg].w;
-    rh[reg][0] = r4r[reg].x; rh[reg][1] = r4r[reg].y; rh[reg][2] = r4r[reg].z; rh[reg][3] = r4r[reg].w;
+  for (int jr = 0; jr < 2; ++jr) {
+    mu[jr][0] = m4r[jr].x; mu[jr][1] = m4r[jr].y; mu[jr][2] = m4r[jr].z; mu[jr][3] = m4r[jr].w;
+    rh[jr][0] = r4r[jr].x; rh[jr][1] = r4r[jr].y; rh[jr][2] = r4r[jr].z; rh[jr][3] = r4r[jr].w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sg[reg][i] = softplus(rh[reg][i]);
+    for (int i = 0; i < 4; ++i) sg[jr][i] = softplus(rh[jr][i]);
   }
   if (do_bias) {
     bmu = bmu_raw;
@@ -259,32 +279,32 @@ __global__ __launch_bounds__(256, 2) void bbb_bwd_weights_kernel(const BwdK p) {
     if (gi == 0) { asm volatile("" ::"v"(sg[0][0]), "v"(avA[0].x)); BWD_STAMP(1); }
     mfma_group(avA, bvA);
     if (gi == 0) { asm volatile("" ::"v"(acc[0][0])); BWD_STAMP(2); }
-    if ((gi + 1) % G_ == 0) finish_sample(gi / G_, gsA);
+    if ((gi + 1) % Gh == 0) finish_sample(gi / Gh, gsA);
     load_group(min(gi + 2, last_group), avA, bvA, gsA);
     __builtin_amdgcn_sched_barrier(0);
     if (gi + 1 < total_groups) {
       mfma_group(avB, bvB);
-      if ((gi + 2) % G_ == 0) finish_sample((gi + 1) / G_, gsB);
+      if ((gi + 2) % Gh == 0) finish_sample((gi + 1) / Gh, gsB);
     }
   }
 
   // ---- g_mu = G;  g_rho = (H - cq / sigma) * sigmoid(rho)
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int kq = k0 + q * 16 + reg * 4;
+  for (int jr = 0; jr < 2; ++jr) {
+    const int kq = k0 + q * 16 + (2 * half + jr) * 4;
     if (!n_ok || kq >= K) continue;
     float gr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gr[i] = (H[i][reg] - cq * __builtin_amdgcn_rcpf(sg[reg][i])) * sigmoidf(rh[reg][i]);
+    for (int i = 0; i < 4; ++i) gr[i] = (H[i][jr] - cq * __builtin_amdgcn_rcpf(sg[jr][i])) * sigmoidf(rh[jr][i]);
     const size_t off = (size_t)n * K + kq;
     if (VEC) {
-      *reinterpret_cast<float4*>(p.g_wmu + off) = make_float4(G[0][reg], G[1][reg], G[2][reg], G[3][reg]);
+      *reinterpret_cast<float4*>(p.g_wmu + off) = make_float4(G[0][jr], G[1][jr], G[2][jr], G[3][jr]);
       *reinterpret_cast<float4*>(p.g_wrho + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (kq + i < K) {
-          p.g_wmu[off + i] = G[i][reg];
+          p.g_wmu[off + i] = G[i][jr];
           p.g_wrho[off + i] = gr[i];
         }
     }
@@ -379,7 +399,7 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
     if (!(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
     k.inv_var_p = (float)(1.0 / ((double)a->prior.sigma_p * a->prior.sigma_p));
   }
-  const int nblocks = ((a->in_features + 63) / 64) * ((a->out_features + 63) / 64);
+  const int nblocks = ((a->in_features + 63) / 64) * ((a->out_features + 31) / 32);
   const dim3 grid((unsigned)(((nblocks + 7) / 8) * 8)), block(256);
   const bool mem = a->eps_mode == BNN_EPS_MEMORY;
   if ((a->in_features & 3) == 0) {
