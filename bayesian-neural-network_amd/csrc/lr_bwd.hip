@@ -131,27 +131,28 @@ __device__ __forceinline__ float2 load_pair(const float* row, int i, int len) {
   return r;
 }
 
-// Block = 64 x 64 output tile, 8 waves: 4 sub-tiles of 32 x 32 (2 x 2 interleaved MFMA tiles) times
-// 2 halves of every sample's batch rows.  Both halves accumulate both GEMMs over their rows; then
-// they swap one of them through LDS so that half 0 finalises g_w_mu (needs only M) and half 1
-// g_w_rho (needs only rho): twice the waves to hide the load latency of this short-reduction,
-// wide-output GEMM, and a balanced epilogue.
+// Each wave owns a 32 x 32 sub-tile (2 x 2 interleaved MFMA tiles) for HALF of the batch rows and accumulates both
+// GEMMs over them; the two halves of a sub-tile then swap one accumulator set through LDS so that half 0 finalises
+// g_w_mu (needs only M) and half 1 g_w_rho (needs only rho): twice the waves to hide the load latency of this
+// short-reduction, wide-output GEMM, and a balanced epilogue.
+// Block = 64 k x 32 n: (k half, batch-row half) waves.  (64 x 64 blocks of eight waves were 361 equal blocks on
+// 256 CUs at the 1200 x 1200 layer -- some CUs two, most one; 722 half-size blocks land 3 : 2.)
 template <bool VEC>
-__global__ __launch_bounds__(512) void lr_bwd_weights_kernel(const LrBwdK p) {
-  __shared__ f32x4 xch[8][4][64];                        // 32 KiB: the accumulators a wave hands to its partner
-  __shared__ float4 bxch[4][64];                         // bias partial sums of half 1
+__global__ __launch_bounds__(256, 3) void lr_bwd_weights_kernel(const LrBwdK p) {
+  __shared__ f32x4 xch[4][4][64];                        // 16 KiB: the accumulators a wave hands to its partner
+  __shared__ float4 bxch[2][64];                         // bias partial sums of half 1
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int sub = wave & 3, half = wave >> 2;
+  const int sub = wave & 1, half = wave >> 1;
   const int K = p.K, N = p.N, B = p.B;
   // XCD-aware order: an XCD walks a few out-feature blocks (its slice of gz, h) across all k
   // blocks, so x and that slice stay in its own L2
   const int nkb = (K + 63) >> 6;
   int item;
-  const bool in_range = xcd_work_item(nkb * ((N + 63) >> 6), item);     // block-uniform
+  const bool in_range = xcd_work_item(nkb * ((N + 31) >> 5), item);     // block-uniform
   const int kblk = in_range ? item % nkb : 0, nblk = in_range ? item / nkb : 0;
-  const int kb = kblk * 64 + (sub & 1) * 32;
-  const int nb = nblk * 64 + (sub >> 1) * 32;
+  const int kb = kblk * 64 + sub * 32;
+  const int nb = nblk * 32;
   const bool active = in_range && kb < K && nb < N;      // wave-uniform; inactive waves only keep the barriers
   const int ka = kb + 2 * c;                             // A operand: k pair of this lane (tile i <-> ka + i)
   const int na = nb + 2 * c;                             // B operand: n pair of this lane (tile j <-> na + j)
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void lr_bwd_weights_kernel(const LrBwdK p) {
       gM[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       gS[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  const bool do_bias = active && kblk == 0 && (sub & 1) == 0;
+  const bool do_bias = active && kblk == 0 && sub == 0;
   const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   float Gb[2] = {0.f, 0.f}, Hb[2] = {0.f, 0.f};
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512) void lr_bwd_weights_kernel(const LrBwdK p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (half ? gS[i][j] : gM[i][j]) + xch[wave ^ 4][i * 2 + j][lane];
+    for (int j = 0; j < 2; ++j) acc[i][j] = (half ? gS[i][j] : gM[i][j]) + xch[wave ^ 2][i * 2 + j][lane];
 
   // ---- epilogue: D row 4q + reg of tile i is k = kb + 2 (4q + reg) + i; D col c of tile j is n = na + j
   const float cw = p.gkl ? p.gkl[0] + p.gkl[1] : 0.f;
@@ -502,10 +503,10 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   k.sample_counter = a->sample_counter;
   k.gx_mask = a->gx_relu_mask ? 1 : 0;
   k.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
-  const int wblocks = ((K + 63) / 64) * ((N + 63) / 64);
+  const int wblocks = ((K + 63) / 64) * ((N + 31) / 32);
   const dim3 wgrid((unsigned)(((wblocks + 7) / 8) * 8));
-  if (((K | N) & 1) == 0) hipLaunchKernelGGL(lr_bwd_weights_kernel<true>, wgrid, dim3(512), 0, stream, k);
-  else hipLaunchKernelGGL(lr_bwd_weights_kernel<false>, wgrid, dim3(512), 0, stream, k);
+  if (((K | N) & 1) == 0) hipLaunchKernelGGL(lr_bwd_weights_kernel<true>, wgrid, dim3(256), 0, stream, k);
+  else hipLaunchKernelGGL(lr_bwd_weights_kernel<false>, wgrid, dim3(256), 0, stream, k);
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) {
