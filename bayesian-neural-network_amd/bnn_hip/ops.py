@@ -669,8 +669,8 @@ def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
 
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: float, weight_decay: float, step: int = 0,
               lr_device=None, step_device=None, ticket=None, bump_counter=None, bump_by: int = 0):
-    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch).  With `ticket` (zeroed uint32 device
-    word) the device step advances inside the first launch, which also adds bump_by to *bump_counter."""
+    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch).  With `ticket` (zeroed device array
+    of 16 uint32) the device step advances inside the first launch, which also adds bump_by to *bump_counter."""
     lib = L.load()
     n = len(params)
     for lo in range(0, n, L.ADAM_MAX_TENSORS):
@@ -693,6 +693,8 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: fl
         a.step_device = _ptr(step_device)
         a.step_advance = int(lo == 0)                   # the first launch of the step advances the device counter
         if lo == 0 and ticket is not None and step_device is not None:
+            if ticket.numel() < 16 or ticket.element_size() != 4:
+                raise BnnHipError("adam_step: ticket must be a zeroed array of 16 32-bit words")
             a.ticket = ticket.data_ptr()
             if bump_counter is not None:
                 a.bump_counter, a.bump_by = bump_counter.data_ptr(), int(bump_by)

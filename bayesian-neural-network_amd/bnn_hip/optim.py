@@ -40,7 +40,7 @@ class FusedAdam(torch.optim.Optimizer):
             steps = [int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
             self._dev[gi] = [torch.tensor([max(steps) if steps else 0], dtype=torch.int32, device=device),
                              torch.tensor([group["lr"]], dtype=torch.float32, device=device), group["lr"],
-                             torch.zeros(1, dtype=torch.int32, device=device)]
+                             torch.zeros(16, dtype=torch.int32, device=device)]
         return self._dev[gi]
 
     def sync_lr(self):

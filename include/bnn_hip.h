@@ -482,7 +482,7 @@ typedef struct bnn_adam_args {
   int32_t step_advance;          /* with step_device: 1 = ++(*step_device) before the update, 0 = use it
                                     as it is (second and later launches of one optimiser step) */
   int32_t reserved;
-  uint32_t* ticket;              /* optional zero-initialised device word.  With step_advance: the update uses
+  uint32_t* ticket;              /* optional zero-initialised device array of 16 words.  With step_advance: the update uses
                                     *step_device + 1 and the block that finishes last stores it (and re-zeroes the
                                     ticket) -- the step counts inside the one launch, no separate tick launch */
   uint32_t* bump_counter;        /* optional (needs ticket): *bump_counter += bump_by by that same last block, e.g. the
