@@ -108,7 +108,7 @@ class BbbBwdArgs(C.Structure):
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("sample_counter", C.c_void_p),
+        ("sample_counter", C.c_void_p), ("w_sampled", C.c_void_p),
     ]
 
 

@@ -480,7 +480,7 @@ def _grad_outputs(out, w_mu, w_rho, b_mu, b_rho):
 def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
                    eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
                    g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None, out=None,
-                   gx_relu_mask: bool = False):
+                   gx_relu_mask: bool = False, w_sampled=None):
     """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
     (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
     lib = L.load()
@@ -516,6 +516,11 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
     a.g_w_mu, a.g_w_rho, a.g_b_mu, a.g_b_rho = g_wmu.data_ptr(), g_wrho.data_ptr(), g_bmu.data_ptr(), g_brho.data_ptr()
     a.g_x = _ptr(gx)
     a.gx_relu_mask = int(bool(gx_relu_mask) and want_gx)
+    if w_sampled is not None and want_gx:
+        require_device(w_sampled)
+        if w_sampled.dtype != torch.bfloat16 or not w_sampled.is_contiguous() or w_sampled.numel() != n_samples * N * K:
+            raise BnnHipError("bbb_linear_bwd: w_sampled must be contiguous bf16 [samples,out,in]")
+        a.w_sampled = w_sampled.data_ptr()
     ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     a.sample_counter = _ptr(sample_counter)

@@ -17,12 +17,21 @@ accumulation, per-layer scalar launches): about a third fewer microseconds per s
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import ops
 from .optim import FusedAdam
 from .runtime import state, take_samples
+
+
+# BBB, bf16 math, hand-chained step: sample every layer's weights ONCE per step in one streaming launch
+# (bnn_bbb_sample_weights), run the forward as matmul-only launches over them and reuse them in the input-gradient
+# launches, which then need no generator either (the transposed generator draws a whole Philox group per weight).
+# The weight-gradient kernels still regenerate eps.  BNN_HIP_TRAIN_PRESAMPLE=0: sampling fused into every launch.
+TRAIN_PRESAMPLE = os.environ.get("BNN_HIP_TRAIN_PRESAMPLE", "1") != "0"
 
 
 class GraphedTrainStep:
@@ -67,6 +76,14 @@ class GraphedTrainStep:
         self.bucket = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.grad_views = [self.bucket[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
         self._elbo = net.sample_elbo_lr if net.local_reparam else net.sample_elbo
+        specs = net._specs()
+        self.presample = (TRAIN_PRESAMPLE and not self.autograd and not net.local_reparam and state.math == L.MATH_BF16 and
+                          all(sp.in_out[0] % 8 == 0 for sp in specs) and len(specs) <= L.SAMPLE_MAX_LAYERS)
+        if self.presample:
+            S = self.samples
+            self.wsamp = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) for sp in specs]
+            self.bsamp = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) for sp in specs]
+            self.wstat = [ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev) for sp in specs]
         self.first = take_samples(0)
         # the step's MC-sample counter advances inside Adam's launch (after the backward re-read it)
         optimizer.bump_after_step(self.counter, self.samples * self.world)
@@ -131,8 +148,20 @@ class GraphedTrainStep:
         h = net._flat(self.x)
         first = take_samples(S * self.world) + self.rank * S
         saved, wss = [], []
-        for sp in specs:
+        if self.presample:
+            ops.bbb_sample_weights(
+                [dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
+                      b_rho=sp.m.bias_rho.detach(), prior=sp.m._prior_spec, layer_id=sp.layer_id, workspace=self.wstat[i],
+                      w_out=self.wsamp[i], b_out=self.bsamp[i]) for i, sp in enumerate(specs)],
+                n_samples=S, seed=state.seed, sample_offset=first, sample_counter=self.counter)
+        for i, sp in enumerate(specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            if self.presample:
+                y = ops.bbb_sampled_matmul(h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu, y_dtype=torch.float32)
+                saved.append((h, y, None, p))
+                wss.append(self.wstat[i])
+                h = y
+                continue
             common = dict(n_samples=S, math_mode=state.math, relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                           seed=state.seed, layer_id=sp.layer_id, sample_offset=first, sample_counter=self.counter)
             if sp.lr:
@@ -165,7 +194,8 @@ class GraphedTrainStep:
                                           **kw)
             else:
                 grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
-                                           g_log_prior=g_a, g_log_q=g_b, **kw)
+                                           g_log_prior=g_a, g_log_q=g_b,
+                                           w_sampled=self.wsamp[i] if (self.presample and i > 0) else None, **kw)
             sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
             g = grads[4]
         if lr:

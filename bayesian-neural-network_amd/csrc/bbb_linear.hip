@@ -180,7 +180,7 @@ __device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brh
 
 // Epilogue: sum the NW slabs (and the R k-range classes of a feature), + bias, ReLU,
 // convert, store 4 consecutive features per item.
-template <int R>
+template <int R, int MT = 8>
 __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __restrict__ slab,
                                                const float* __restrict__ lds_bias, int nw, int mtiles, int nt, int s,
                                                int m0, float* __restrict__ lds_out = nullptr,
@@ -196,7 +196,7 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
 #pragma unroll 4
     for (int wv = 0; wv < nw; ++wv) {          // fixed order: wave-major, class-minor
 #pragma unroll
-      for (int c = 0; c < R; ++c) v += slab[(wv * 8 + m) * 64 + (c * FG + fg) * 16 + b];
+      for (int c = 0; c < R; ++c) v += slab[(wv * MT + m) * 64 + (c * FG + fg) * 16 + b];
     }
     const int brow = m0 + m * 16 + b;
     const int nb = nt * F + fg * 4;
@@ -271,7 +271,10 @@ struct FinPack {
 // Returns false for the padding blocks of the XCD-aware grid (no work done).  `forced_item` >= 0 runs that
 // work item whatever the block index is (the fused-tail kernel hands the last layer to whichever block
 // finished the layer before it last).
-template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false>
+// MT: 16-row batch tiles per block (8 = 128 rows).  The matmul-only forms use 2: without generator work a block's
+// cost is the x it pulls through its CU's L1 (all of K for its rows), so four times the blocks each ingest a quarter;
+// with sampling fused every batch block would redo the tile's sampling, hence 8 there.
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8>
 __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, int forced_item = -1) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -279,7 +282,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   const int r = lane & 15, q = lane >> 4;
   const int c = r / F, f = r % F;
   const int K = p.K, N = p.N, B = p.B;
-  const int ntiles = (N + F - 1) / F, mbs = (B + 127) >> 7;
+  const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
   int item;
   const int KS = FINAL ? fp->ks : 1;                          // K-range slices per sample (FINAL only)
   if (forced_item >= 0) item = forced_item;
@@ -290,8 +293,8 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   const int n = nt * F + f;
   const bool n_ok = n < N;
   const int nc = min(n, N - 1);                     // clamped feature for unconditional loads
-  const int m0 = mb * 128;
-  const int mtiles = min(8, (B - m0 + 15) >> 4);
+  const int m0 = mb * (16 * MT);
+  const int mtiles = min(MT, (B - m0 + 15) >> 4);
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   const int spb = (ssteps + KS - 1) / KS;                      // super-steps per K-range slice
   const int t_lo = ks * spb, t_hi = min(ssteps, t_lo + spb);
@@ -303,15 +306,15 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   const uint32_t wid = p.layer_id * 4u;
   const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
 
-  float* lds_bias = lds + (size_t)nw * 8 * 64 * 4;   // 16 floats
+  float* lds_bias = lds + (size_t)nw * MT * 64 * 4;   // 16 floats
   float* lds_red = lds_bias + 16;                    // 3 * nw floats
   f32x4* slab = reinterpret_cast<f32x4*>(lds);
 
   BNN_STAMP(0);
   BNN_STAMP_RT(8);
-  f32x4 acc[8];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
   if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0)
     p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
@@ -321,7 +324,15 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   float4 wraw_n = make_float4(0.f, 0.f, 0.f, 0.f);    // PRE: the lane's 8 sampled bf16 weights of the step
   auto load_params = [&](int t) {
     const int k = (t * R + c) * 32 + q * 8;
-    if (PRE) {
+    if (PRE && TRANS) {                             // input gradient over the forward's sampled weights [S, K, ldw]
+      bf16x8 tw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 v = p.w_pre[((size_t)s * K + min(k + j, K - 1)) * p.ldw + nc];
+        tw[j] = (k + j < K && n_ok) ? v : (__bf16)0.f;
+      }
+      wraw_n = __builtin_bit_cast(float4, tw);
+    } else if (PRE) {
       wraw_n = *reinterpret_cast<const float4*>(p.w_pre + ((size_t)s * N + nc) * K + min(k, K - 8));
     } else if (TRANS) {
 #pragma unroll
@@ -345,7 +356,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
   if (PRE) {
-    if (wave == nw - 1 && lane < F && n_ok && ks == 0) bmu_pre = p.b_pre[(size_t)s * N + n];
+    if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) bmu_pre = p.b_pre[(size_t)s * N + n];
   } else if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
@@ -358,7 +369,8 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
     const int valid = n_ok ? min(8, K - k) : 0;     // ALIGNED: 8 or <= 0
     // ---- x fragments of the first batch-tile chunk, issued ahead of the generator work.
     constexpr int FR = (XDT == BNN_F32) ? 2 : 1;                  // 16-byte loads per fragment
-    constexpr int MC = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));   // batch tiles staged at once
+    constexpr int MC0 = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));
+    constexpr int MC = MC0 > MT ? MT : MC0;                       // batch tiles staged at once
     float4 xraw[MC * R * FR];
     auto stage = [&](int ch) {
 #pragma unroll
@@ -478,10 +490,10 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
         wa[j] = (__bf16)w[j];
         wz[j] = (__bf16)0.f;
       }
-      if (PRE && valid > 0) wa = __builtin_bit_cast(bf16x8, wraw);     // padding lanes (k >= K, n >= N) stay zero
+      if (PRE && (TRANS || valid > 0)) wa = __builtin_bit_cast(bf16x8, wraw);   // padding (k >= K, n >= N) is zero
     }
 #pragma unroll
-    for (int ch = 0; ch < 8 / MC; ++ch) {
+    for (int ch = 0; ch < MT / MC; ++ch) {
       if (ch * MC < mtiles) {                     // block-uniform
 #pragma unroll
         for (int mm = 0; mm < MC; ++mm) {
@@ -515,23 +527,23 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
             }
           }
         }
-        if ((ch + 1) * MC < 8 && (ch + 1) * MC < mtiles) stage(ch + 1);
+        if ((ch + 1) * MC < MT && (ch + 1) * MC < mtiles) stage(ch + 1);
       }
     }
   }
 
-  asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
+  asm volatile("" :: "v"(acc[0][0]), "v"(acc[MT - 1][3]));
   BNN_STAMP(3);
   // ---- bias of the tile's F features: wave 0, lanes 0..F-1
   if (wave == nw - 1 && lane < 16) {
     float b = 0.f;
-    if (PRE) b = (lane < F && n_ok && ks == 0) ? bmu_pre : 0.f;
+    if (PRE) b = (!TRANS && lane < F && n_ok && ks == 0) ? bmu_pre : 0.f;
     else if (!TRANS && lane < F && n_ok && ks == 0) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
     lds_bias[lane] = b;
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < mtiles) slab[(wave * 8 + m) * 64 + lane] = acc[m];
+  for (int m = 0; m < MT; ++m)
+    if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = acc[m];
   if (do_stats) {
     const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
     if (lane == 0) {
@@ -554,7 +566,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   }
   float* fin_lg = lds_red + 3 * nw;               // FINAL only: [128][16] final logits + reduce scratch
   if (!FINAL || KS == 1) {
-    epilogue_store<R>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
+    epilogue_store<R, MT>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
   }
   BNN_STAMP(6);
   BNN_STAMP_RT(9);
@@ -713,9 +725,16 @@ __global__ __launch_bounds__(768) void bbb_fwd_tail2_kernel(const BbbK p2, const
 }
 
 // matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
-template <int XDT, int R>
+template <int XDT, int R, int MT>
 __global__ __launch_bounds__(768) void bbb_fwd_pre_kernel(const BbbK p) {
-  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false, false, true>(p, nullptr);
+  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false, false, true, MT>(p, nullptr);
+}
+
+// input gradient over the bf16 weights the forward sampled (no generator work: the transposed generator draws a
+// whole Philox group per weight it needs, four times the forward's cost)
+template <int R, bool ALIGNED, int MT>
+__global__ __launch_bounds__(768) void bbb_input_grad_pre_kernel(const BbbK p) {
+  bbb_fwd_body<BNN_MATH_BF16, BNN_F32, R, ALIGNED, false, true, true, MT>(p, nullptr);
 }
 
 template <int MATH, int R, bool ALIGNED>
@@ -1179,27 +1198,34 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     // ---- matmul half only: same tile machinery, no generator work.  (A variant that issued every load of a wave
     // in one round -- 10 waves x 2 steps of 64 k, 136 landing registers -- measured slower: 11.8 against 8.7 us at
     // 128 x 1200 x 1200; the launch is bound by its ~300 KB of x per block through L1, not by dependent rounds.)
+    // Batch tiles per block: 2 (32 rows).  Without generator work a block's cost is the x it pulls through its CU's L1
+    // -- all of K for its rows -- so four times the blocks each ingest a quarter of it (BNN_HIP_PRE_MT=8: 128 rows).
+    const int mt = env_int("BNN_HIP_PRE_MT", 2) == 8 ? 8 : 2;
+    const int mbs_p = (a->batch + 16 * mt - 1) / (16 * mt);
     Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, true, a->concurrency);
+    if (mt == 2 || pl.R > 2) {                           // enough blocks already: whole 16-feature tiles
+      pl.R = 1;
+      pl.tiles = (a->out_features + 15) / 16;
+    }
     const int fr = env_int("BNN_HIP_PRE_R", 0), fw = env_int("BNN_HIP_PRE_WAVES", 0);
-    if (fr == 1 || fr == 2 || fr == 4) {
+    if (fr == 1 || fr == 2) {
       pl.R = fr;
       pl.tiles = (a->out_features + 16 / fr - 1) / (16 / fr);
     }
     if (fw >= 1 && fw <= 12) pl.nw = fw;
-    const long total = (long)pl.tiles * a->n_samples * mbs;
+    const long total = (long)pl.tiles * a->n_samples * mbs_p;
     const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-    const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
-#define BNN_PRE(XDT, RR)                                                                     \
-  do {                                                                                       \
-    err = allow_big_lds(bbb_fwd_pre_kernel<XDT, RR>, lds);                                   \
-    if (err == hipSuccess)                                                                   \
-      hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, RR>), grid, block, lds, stream, k);        \
+    const size_t lds = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+#define BNN_PRE(XDT, RR, MTT)                                                                     \
+  do {                                                                                            \
+    err = allow_big_lds(bbb_fwd_pre_kernel<XDT, RR, MTT>, lds);                                   \
+    if (err == hipSuccess)                                                                        \
+      hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, RR, MTT>), grid, block, lds, stream, k);        \
   } while (0)
-#define BNN_PRE_R(XDT)                      \
-  do {                                      \
-    if (pl.R == 1) BNN_PRE(XDT, 1);         \
-    else if (pl.R == 2) BNN_PRE(XDT, 2);    \
-    else BNN_PRE(XDT, 4);                   \
+#define BNN_PRE_R(XDT)                                               \
+  do {                                                               \
+    if (mt == 2) { if (pl.R == 1) BNN_PRE(XDT, 1, 2); else BNN_PRE(XDT, 2, 2); }  \
+    else { if (pl.R == 1) BNN_PRE(XDT, 1, 8); else BNN_PRE(XDT, 2, 8); }          \
   } while (0)
     if (xdt == BNN_F32) BNN_PRE_R(BNN_F32); else BNN_PRE_R(BNN_BF16);
 #undef BNN_PRE
@@ -1445,6 +1471,8 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   k.ldw = a->in_features;
   k.mask = a->gx_relu_mask ? a->x : nullptr;
   k.mask_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
+  k.w_pre = reinterpret_cast<const __bf16*>(a->w_sampled);
+  k.b_pre = nullptr;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = 0; k.relu = 0; k.y_bf16 = 0; k.spb = 1;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
@@ -1472,7 +1500,23 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
     else if (pl.R == 2) BNN_IG(MATH, 2, true);         \
     else BNN_IG(MATH, 4, true);                        \
   } while (0)
-  if (a->math == BNN_MATH_BF16) BNN_IG_R(BNN_MATH_BF16); else BNN_IG_R(BNN_MATH_F32);
+#define BNN_IGP(RR, AL, MTT)                                                                         \
+  do {                                                                                               \
+    err = allow_big_lds(bbb_input_grad_pre_kernel<RR, AL, MTT>, ldsp);                               \
+    if (err == hipSuccess)                                                                           \
+      hipLaunchKernelGGL((bbb_input_grad_pre_kernel<RR, AL, MTT>), gridp, block, ldsp, stream, k);   \
+  } while (0)
+  if (a->w_sampled) {
+    if (a->math != BNN_MATH_BF16) return BNN_ERR_ENUM;   // the sampled weights are the bf16 operands of that mode
+    // 32-row batch blocks, as the matmul-only forward (no generator work to repeat per batch block)
+    const int mt = env_int("BNN_HIP_PRE_MT", 2) == 8 ? 8 : 2;
+    const long totalp = (long)((k.N + 15) / 16) * k.S * ((k.B + 16 * mt - 1) / (16 * mt));
+    const dim3 gridp((unsigned)(((totalp + 7) / 8) * 8));
+    const size_t ldsp = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+    if (mt == 2) { if (!al) BNN_IGP(1, false, 2); else BNN_IGP(1, true, 2); }
+    else { if (!al) BNN_IGP(1, false, 8); else BNN_IGP(1, true, 8); }
+  } else if (a->math == BNN_MATH_BF16) BNN_IG_R(BNN_MATH_BF16); else BNN_IG_R(BNN_MATH_F32);
+#undef BNN_IGP
 #undef BNN_IG
 #undef BNN_IG_R
   if (err != hipSuccess) return (int)err;

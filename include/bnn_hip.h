@@ -397,6 +397,10 @@ typedef struct bnn_bbb_bwd_args {
   size_t workspace_bytes;
   const uint32_t* sample_counter; /* optional device word added to sample_offset at run time (the value
                                      the forward of the same step read), as in bnn_bbb_fwd_args */
+  const void* w_sampled;      /* optional bf16 [n_samples,out,in]: the weights the forward of this step sampled
+                                 (bnn_bbb_sample_weights).  g_x = gz . w_sampled is then a plain matmul instead of
+                                 regenerating w through the transposed generator (bf16 math only); the weight
+                                 gradients still regenerate eps */
 } bnn_bbb_bwd_args;
 
 size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features);

@@ -251,6 +251,41 @@ def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), k
 
 
+def test_graphed_step_with_presampled_weights_equals_the_fused_step(monkeypatch):
+    """bf16 math: the hand-chained step that samples every layer once per step (bnn_bbb_sample_weights), runs
+    matmul-only forwards and reuses the sampled weights in the input-gradient launches, against the same step with
+    sampling fused into every launch: same Philox elements, so parameters agree to fp32 summation order."""
+    import networks
+    from bnn_hip import train
+    from bnn_hip.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    bnn_hip.set_math("bf16")
+    mp = dict(input_shape=784, classes=10, batch_size=128, hidden_units=400, mode="classification", mu_init=[-0.2, 0.2],
+              rho_init=[-5, -4], prior_init=[1.0], mixture_prior=False, local_reparam=False)
+    rs = np.random.RandomState(5)
+    xs = [torch.from_numpy(rs.uniform(0, 1, (128, 784)).astype(np.float32)).to(dev) for _ in range(3)]
+    ys = [torch.from_numpy(rs.randint(0, 10, 128)).to(dev) for _ in range(3)]
+    res = []
+    for pre in (True, False):
+        monkeypatch.setattr(train, "TRAIN_PRESAMPLE", pre)
+        torch.manual_seed(3)
+        net = networks.BayesianNetwork(mp).to(dev).train()
+        opt = FusedAdam(net.parameters(), lr=1e-3, capturable=True)
+        bnn_hip.manual_seed(17, counter=900)
+        g = train.GraphedTrainStep(net, opt, xs[0], ys[0], 2)
+        assert g.presample == pre
+        outs = [[o.clone() for o in g.step(xs[i], ys[i], 0.25)] for i in range(3)]
+        res.append((outs, {k: v.clone() for k, v in net.state_dict().items()}, [p.grad.clone() for p in g.params]))
+    (oa, sa, ga), (ob, sb, gb) = res
+    for a, b in zip(oa, ob):
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= 2e-4 * (float(v.abs().max()) + 1e-6)
+    for u, v in zip(ga, gb):                                   # last step's gradients
+        assert float((u - v).abs().max()) <= 2e-3 * (float(v.abs().max()) + 1e-9)
+    for k in sa:
+        assert float((sa[k] - sb[k]).abs().max()) <= 2e-4 * float(sb[k].abs().max()), k
+
+
 DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, r"{repo}"); sys.path.insert(0, os.path.join(r"{repo}", "bayesian-neural-network_amd"))
