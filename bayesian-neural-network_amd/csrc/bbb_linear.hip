@@ -1195,9 +1195,11 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (a->split_scratch_bytes < (size_t)ksl * part_bytes || (reinterpret_cast<uintptr_t>(a->split_scratch) & 15)) ksl = 1;
   }
   if (a->w_sampled) {
-    // ---- matmul half only: same tile machinery, no generator work.  (A variant that issued every load of a wave
-    // in one round -- 10 waves x 2 steps of 64 k, 136 landing registers -- measured slower: 11.8 against 8.7 us at
-    // 128 x 1200 x 1200; the launch is bound by its ~300 KB of x per block through L1, not by dependent rounds.)
+    // ---- matmul half only: same tile machinery, no generator work.  Two rebuilds of it measured slower and were
+    // dropped: every load of a wave issued in one round (10 waves x 2 steps of 64 k, 136 landing registers: 11.8
+    // against 8.7 us at 128 x 1200 x 1200), and a dedicated kernel whose blocks own 2 feature tiles x 4 batch tiles so
+    // that each fragment feeds more MFMAs (half the L2 -> L1 bytes: 6.1 against 5.2 us per two layers with four
+    // evaluations side by side).  What did help is below: 32-row batch blocks.
     // Batch tiles per block: 2 (32 rows).  Without generator work a block's cost is the x it pulls through its CU's L1
     // -- all of K for its rows -- so four times the blocks each ingest a quarter of it (BNN_HIP_PRE_MT=8: 128 rows).
     const int mt = env_int("BNN_HIP_PRE_MT", 2) == 8 ? 8 : 2;
@@ -1508,8 +1510,9 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   } while (0)
   if (a->w_sampled) {
     if (a->math != BNN_MATH_BF16) return BNN_ERR_ENUM;   // the sampled weights are the bf16 operands of that mode
-    // 32-row batch blocks, as the matmul-only forward (no generator work to repeat per batch block)
-    const int mt = env_int("BNN_HIP_PRE_MT", 2) == 8 ? 8 : 2;
+    // 128-row batch blocks here: a lane's 8 reduction-consecutive weights are 8 strided 2-byte loads in this
+    // direction, and 32-row blocks would repeat them four times (28.8 against 21.4 us at 2 x 128 x 1200 x 1200)
+    const int mt = env_int("BNN_HIP_PRE_MT_BWD", 8) == 2 ? 2 : 8;
     const long totalp = (long)((k.N + 15) / 16) * k.S * ((k.B + 16 * mt - 1) / (16 * mt));
     const dim3 gridp((unsigned)(((totalp + 7) / 8) * 8));
     const size_t ldsp = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);

