@@ -37,6 +37,12 @@ SPLIT_MIN_WEIGHTS = 0 if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else 4_000
 PRESAMPLE_MAX_SAMPLES = int(os.environ.get("BNN_HIP_PRESAMPLE", "0"))
 
 
+# BBB, bf16 math, one MC sample per evaluation, several evaluations per graph launch: the output layer + finalize of
+# evaluation j share ONE launch with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd) -- the output layer
+# is a few latency-bound blocks that otherwise hold the stream's chain of dependent launches for ~10 us.
+PIPELINE_EVALS = os.environ.get("BNN_HIP_PIPELINE_EVALS", "1") != "0"
+
+
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
 # chip; BNN_HIP_FUSED_ELBO=0 keeps one node per layer (the form the identical-eps parity path always uses)
 FUSED_ELBO_NODE = os.environ.get("BNN_HIP_FUSED_ELBO", "1") != "0"
@@ -375,6 +381,13 @@ class GraphedElbo:
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
                           if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
+        # software pipeline over the evaluations of one graph launch (see PIPELINE_EVALS): the first layer's statistics
+        # workspace alternates, every evaluation has its own static sample offset and only the last finalize of a
+        # replay advances the device counter, so an evaluation's first layer depends on nothing its predecessor writes
+        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S == 1 and
+                          hid == torch.bfloat16 and nl >= 2 and self.specs[-1].in_out[1] <= 16 and B <= 128 and
+                          self.split[0] is None and self.wsigma[0] is None and self.x16 is None)
+        self.ws0_alt = ops.bbb_workspace(S, self.specs[0].in_out[1], dev) if self.pipelined else None
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -391,8 +404,11 @@ class GraphedElbo:
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    for _ in range(self.per_replay):
-                        self._enqueue()
+                    if self.pipelined:
+                        self._enqueue_pipelined()
+                    else:
+                        for _ in range(self.per_replay):
+                            self._enqueue()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = g
 
@@ -458,7 +474,47 @@ class GraphedElbo:
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
 
+    def _enqueue_pipelined(self):
+        """per_replay one-sample BBB evaluations as L0(e0) L1..(e0) [final(e0) + L0(e1)] L1..(e1) ... final(e_last)."""
+        E, last = self.per_replay, len(self.specs) - 1
+        inc = self.samples * self.stride                   # global MC indices one evaluation of this evaluator spans
+        math_mode = state.math
+
+        def layer_call(i, j):
+            sp = self.specs[i]
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            ws = (self.ws[0], self.ws0_alt)[j & 1] if i == 0 else self.ws[i]
+            h = self.x if i == 0 else self.bufs[i - 1]
+            kw = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
+                      eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo + j * inc,
+                      sample_counter=self.counter, workspace=ws, out=self.bufs[i], concurrency=self.stride,
+                      prior=sp.m._prior_spec, want_stats=True)
+            return (h,) + p, kw
+
+        for j in range(E):
+            if j == 0:
+                a0, k0 = layer_call(0, 0)
+                ops.bbb_linear_fwd(*a0, **k0)
+            for i in range(1, last):
+                ai, ki = layer_call(i, j)
+                ops.bbb_linear_fwd(*ai, **ki)
+            al, kl = layer_call(last, j)
+            fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                          local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
+                          target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                          sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
+                          ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring,
+                          workspaces=[(self.ws[0], self.ws0_alt)[j & 1]] + self.ws[1:last])
+            if j < E - 1:
+                an, kn = layer_call(0, j + 1)
+                ops.bbb_final_next_fwd(al, kl, fin_kw, an, kn)
+            else:
+                ops.bbb_final_fwd(al, kl, fin_kw)
+
     def _eager(self):
+        if self.pipelined:
+            self._enqueue_pipelined()
+            return
         for _ in range(self.per_replay):
             self._enqueue()
 

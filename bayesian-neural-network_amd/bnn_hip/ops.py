@@ -406,6 +406,21 @@ def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
     return res, out
 
 
+def bbb_final_next_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict, next_args: tuple, next_kw: dict):
+    """bnn_bbb_final_next_fwd: the output layer + finalize of one evaluation and the first layer of the next one in
+    one launch.  Arguments as for bbb_final_fwd plus those of bbb_linear_fwd for the next evaluation's first layer.
+    Returns (layer result, finalize result, next layer result)."""
+    lib = L.load()
+    a, res, keep1 = _bbb_build(*layer_args, **layer_kw)
+    fin_kw = dict(fin_kw)
+    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
+    fin_kw["logits"] = res["y"]
+    f, out, keep2 = _fin_build(**fin_kw)
+    n, resn, keep3 = _bbb_build(*next_args, **next_kw)
+    L.check(lib.bnn_bbb_final_next_fwd(C.byref(a), C.byref(f), C.byref(n), _stream()), "bnn_bbb_final_next_fwd")
+    return res, out, resn
+
+
 def bbb_tail2_fwd(hidden_args: tuple, hidden_kw: dict, last_args: tuple, last_kw: dict, fin_kw: dict):
     """Last hidden BBB layer + output layer + finalize through bnn_bbb_tail2_fwd (one launch for a one-sample
     evaluation).  `last_args[0]` (the output layer's x) must be the hidden layer's `out` tensor; `fin_kw` carries the

@@ -690,6 +690,16 @@ __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const 
   bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
 }
 
+// K1e  the output layer + finalize of ONE evaluation and the FIRST layer of the next one in one launch: two independent
+// pieces of work (the caller keeps their buffers apart).  The output layer is a handful of latency-bound blocks
+// (five K-slice blocks and a hand-off at the MNIST shape, ~10 us); as a launch of its own it holds its stream's chain
+// for that long, next to the next evaluation's first layer it costs the chain nothing.
+template <int XDT1, int R1>
+__global__ __launch_bounds__(768) void bbb_fwd_final_next_kernel(const BbbK p3, const FinPack fp, const BbbK p1, int nf) {
+  if ((int)blockIdx.x < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, (int)blockIdx.x);
+  else bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, (int)blockIdx.x - nf);
+}
+
 // K1d  one-sample tail of an evaluation in ONE launch: the last hidden layer (K1a, any tile plan) and, run by
 // whichever of its blocks finishes last, the output layer + finalize (K1c without K-slices).  Every block
 // drains its stores, one lane releases at agent scope and takes a ticket; the last arriver acquires and
@@ -1312,7 +1322,7 @@ extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
 // Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
 // tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
 // the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
-extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
+static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* next, void* stream_) {
   BbbK k;
   bool al = false;
   int rc = prepare(a, k, al);
@@ -1329,7 +1339,9 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   if (!fuse) {
     rc = bnn_bbb_linear_fwd(a, stream_);
     if (rc != BNN_OK) return rc;
-    return bnn_elbo_finalize(f, stream_);
+    rc = bnn_elbo_finalize(f, stream_);
+    if (rc != BNN_OK || !next) return rc;
+    return bnn_bbb_linear_fwd(next, stream_);
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   fp.sums = f->sums;
@@ -1371,9 +1383,42 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
     fp.ks_tiles = reinterpret_cast<float*>(base + ((S * 4 + 255) / 256) * 256 + S * kFinalMaxSlices * 16);
   }
   const long total = (long)a->n_samples * KS;           // one tile, one batch block, KS slices
+  hipError_t err = hipSuccess;
+  if (next) {
+    // ---- combined launch with the next evaluation's first layer, when both take the plain tile forms
+    BbbK k1;
+    bool al1 = false;
+    rc = prepare(next, k1, al1);
+    if (rc != BNN_OK) return rc;
+    const int mbs1 = (next->batch + 127) / 128;
+    const long gemm_blocks1 = (long)((next->out_features + 63) / 64) * next->n_samples * mbs1;
+    const bool combine = !tail_kernel && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && next->math == BNN_MATH_BF16 &&
+                         al1 && !next->w_sampled && !next->split_scratch && !next->log_prior && !next->log_q &&
+                         gemm_blocks1 < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1 && env_int("BNN_HIP_FINAL_NEXT", 1) != 0;
+    if (combine) {
+      const Plan pl1 = make_plan(next->n_samples, next->batch, next->in_features, next->out_features, true, next->concurrency);
+      if (pl1.R <= 2) {
+        const int nwc = pl1.nw > nw ? pl1.nw : nw;
+        const long total1 = (long)pl1.tiles * next->n_samples * mbs1;
+        const dim3 gridc((unsigned)(total + total1)), blockc(nwc * 64);
+        const size_t ldsc = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
+#define BNN_FN(XDT1, RR)                                                                                          \
+  do {                                                                                                            \
+    err = allow_big_lds(bbb_fwd_final_next_kernel<XDT1, RR>, ldsc);                                               \
+    if (err == hipSuccess)                                                                                        \
+      hipLaunchKernelGGL((bbb_fwd_final_next_kernel<XDT1, RR>), gridc, blockc, ldsc, stream, k, fp, k1, (int)total); \
+  } while (0)
+        if (next->x_dtype == BNN_F32) { if (pl1.R == 1) BNN_FN(BNN_F32, 1); else BNN_FN(BNN_F32, 2); }
+        else { if (pl1.R == 1) BNN_FN(BNN_BF16, 1); else BNN_FN(BNN_BF16, 2); }
+#undef BNN_FN
+        if (err != hipSuccess) return (int)err;
+        err = hipGetLastError();
+        return err == hipSuccess ? BNN_OK : (int)err;
+      }
+    }
+  }
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
   const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
-  hipError_t err = hipSuccess;
 #define BNN_FIN(MATH, XDT)                                                                     \
   do {                                                                                         \
     err = allow_big_lds(bbb_fwd_final_kernel<MATH, XDT>, lds);                                 \
@@ -1389,8 +1434,23 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  if (tail_kernel) return bnn_elbo_sums_(f, stream_);
-  return BNN_OK;
+  if (tail_kernel) {
+    rc = bnn_elbo_sums_(f, stream_);
+    if (rc != BNN_OK) return rc;
+  }
+  return next ? bnn_bbb_linear_fwd(next, stream_) : BNN_OK;
+}
+
+extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
+  return final_fwd_impl(a, f, nullptr, stream_);
+}
+
+// bnn_bbb_final_fwd(last, fin) and bnn_bbb_linear_fwd(next_first) -- the first layer of the NEXT, independent
+// evaluation -- in one launch when both take their plain tile forms; the two calls otherwise.
+extern "C" int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* next,
+                                      void* stream_) {
+  if (!next) return BNN_ERR_NULL;
+  return final_fwd_impl(a, f, next, stream_);
 }
 
 // The last hidden layer + the output layer + finalize of a ONE-sample evaluation in one launch (K1d) when the

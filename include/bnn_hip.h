@@ -342,6 +342,15 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
 size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 
+/* bnn_bbb_final_next_fwd — bnn_bbb_final_fwd(layer, fin) of one evaluation and bnn_bbb_linear_fwd(next_first), the
+ * first layer of the NEXT evaluation, in ONE launch (the same results as the two calls).  The two are independent
+ * work: the caller guarantees that next_first neither writes what layer / fin read (its statistics workspace must
+ * not be one of fin->layer_workspace, its y not an input of layer) nor depends on what they write (give it a static
+ * sample_offset rather than a sample counter that fin advances).  The output layer is a few latency-bound blocks;
+ * beside the next evaluation's first layer it no longer holds its stream's chain of dependent launches. */
+int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* next_first,
+                           void* stream);
+
 /* bnn_bbb_tail2_fwd — the last HIDDEN layer, the output layer and the finalize of a ONE-sample evaluation in one
  * launch: the same results as bnn_bbb_linear_fwd(hidden) followed by bnn_bbb_final_fwd(last, fin) with
  * last->x == hidden->y (bf16) and fin's two last workspaces those of the two layers, but whichever block of the

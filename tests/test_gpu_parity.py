@@ -837,3 +837,38 @@ def test_presampled_evaluation_equals_the_fused_evaluation(dev, monkeypatch, sam
             close(pa[k], pb[k].cpu().numpy(), rtol=2e-2 if k == "nll" else 2e-6)
         close(sa[:2], sb[:2].cpu().numpy(), rtol=2e-6)
     assert not torch.equal(ra[0][0], ra[1][0])
+
+
+@pytest.mark.parametrize("stride", [1, 4])
+def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride):
+    """E one-sample evaluations per graph launch with the output layer + finalize of evaluation j sharing a launch
+    with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd): every evaluation's 4-vector is the one the
+    plain sequence gives for the same global sample indices -- bitwise, the kernels and their summation order are the
+    same -- over several replays (alternating statistics workspace, static per-evaluation sample offsets, one
+    counter advance per replay)."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, False, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    E, reps, ring_len = 4, 3, 16
+    got = {}
+    for pipe in (True, False):
+        monkeypatch.setattr(engine, "PIPELINE_EVALS", pipe)
+        slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
+        bnn_hip.manual_seed(41, counter=700)
+        ev = engine.GraphedElbo(net, xd, yd, 1, counter_stride=stride, sums_ring=(slab.view(-1), ring_len, 4),
+                                evals_per_replay=E)
+        assert ev.pipelined == pipe
+        slab.fill_(-7.0)
+        for _ in range(reps):
+            ev.replay()
+        torch.cuda.synchronize()
+        got[pipe] = (slab.clone(), int(ev.counter.item()), ev.logits.clone(), {k: v.clone() for k, v in ev.out.items()})
+    (sa, ca, la, oa), (sb, cb, lb, ob) = got[True], got[False]
+    assert ca == cb
+    assert torch.equal(sa[:E * reps], sb[:E * reps]) and bool((sa[:E * reps, 0, 3] == 1.0).all())
+    assert len({tuple(float(v) for v in row[0, :3]) for row in sa[:E * reps]}) == E * reps   # every evaluation drew its own eps
+    assert torch.equal(la, lb)
+    for k in oa:
+        assert torch.equal(oa[k], ob[k])
