@@ -23,7 +23,7 @@ EXPORTS = (
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_next_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_next_fwd", "bnn_bbb_stage_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
 )
 
 
@@ -202,6 +202,9 @@ def load():
     lib.bnn_mc_softmax_mean.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bnn_bbb_final_next_fwd.restype = C.c_int
     lib.bnn_bbb_final_next_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs), C.c_void_p]
+    lib.bnn_bbb_stage_fwd.restype = C.c_int
+    lib.bnn_bbb_stage_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs),
+                                      C.POINTER(BbbFwdArgs), C.c_void_p]
     lib.bnn_bbb_tail2_fwd.restype = C.c_int
     lib.bnn_bbb_tail2_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.c_void_p]
     lib.bnn_elbo_loss.restype = C.c_int

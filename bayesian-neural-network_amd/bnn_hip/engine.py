@@ -41,6 +41,7 @@ PRESAMPLE_MAX_SAMPLES = int(os.environ.get("BNN_HIP_PRESAMPLE", "0"))
 # evaluation j share ONE launch with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd) -- the output layer
 # is a few latency-bound blocks that otherwise hold the stream's chain of dependent launches for ~10 us.
 PIPELINE_EVALS = os.environ.get("BNN_HIP_PIPELINE_EVALS", "1") != "0"
+PIPELINE_DEPTH3 = os.environ.get("BNN_HIP_PIPELINE_DEPTH", "3") != "2"
 
 
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
@@ -388,6 +389,13 @@ class GraphedElbo:
                           hid == torch.bfloat16 and nl >= 2 and self.specs[-1].in_out[1] <= 16 and B <= 128 and
                           self.split[0] is None and self.wsigma[0] is None and self.x16 is None)
         self.ws0_alt = ops.bbb_workspace(S, self.specs[0].in_out[1], dev) if self.pipelined else None
+        # three-layer nets go one step further: first layer of evaluation j+2, hidden layer of j+1 and output layer of j
+        # in ONE launch (bnn_bbb_stage_fwd), activations and statistics of the two hidden layers buffered three deep
+        self.pipe3 = self.pipelined and nl == 3 and PIPELINE_DEPTH3 and self.split[1] is None and self.wsigma[1] is None
+        if self.pipe3:
+            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(2)]
+            self.slot_ws = [[self.ws[i]] + [ops.bbb_workspace(S, self.specs[i].in_out[1], dev) for _ in range(2)]
+                            for i in range(2)]
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -479,6 +487,9 @@ class GraphedElbo:
         E, last = self.per_replay, len(self.specs) - 1
         inc = self.samples * self.stride                   # global MC indices one evaluation of this evaluator spans
         math_mode = state.math
+        if self.pipe3:
+            self._enqueue_pipelined3(E, inc, math_mode)
+            return
 
         def layer_call(i, j):
             sp = self.specs[i]
@@ -510,6 +521,39 @@ class GraphedElbo:
                 ops.bbb_final_next_fwd(al, kl, fin_kw, an, kn)
             else:
                 ops.bbb_final_fwd(al, kl, fin_kw)
+
+    def _enqueue_pipelined3(self, E, inc, math_mode):
+        """Launch t = {output layer + finalize of evaluation t-2, hidden layer of t-1, first layer of t}: E + 2 launches
+        for E evaluations; evaluation j lives in buffer slot j % 3."""
+        def layer_call(i, j):
+            sp = self.specs[i]
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            slot = j % 3
+            h = self.x if i == 0 else self.slot_bufs[i - 1][slot]
+            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
+            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+            kw = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX,
+                      seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo + j * inc, sample_counter=self.counter,
+                      workspace=ws, out=out, concurrency=self.stride, prior=sp.m._prior_spec, want_stats=True)
+            return (h,) + p, kw
+
+        for t in range(E + 2):
+            final = mid = first = None
+            if t < E:
+                first = layer_call(0, t)
+            if 0 <= t - 1 < E:
+                mid = layer_call(1, t - 1)
+            if 0 <= t - 2 < E:
+                j = t - 2
+                al, kl = layer_call(2, j)
+                fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                              local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
+                              target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                              sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
+                              ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring,
+                              workspaces=[self.slot_ws[0][j % 3], self.slot_ws[1][j % 3]])
+                final = (al, kl, fin_kw)
+            ops.bbb_stage_fwd(final=final, mid=mid, first=first)
 
     def _eager(self):
         if self.pipelined:

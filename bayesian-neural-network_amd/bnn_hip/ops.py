@@ -421,6 +421,30 @@ def bbb_final_next_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict, next_arg
     return res, out, resn
 
 
+def bbb_stage_fwd(final=None, mid=None, first=None):
+    """bnn_bbb_stage_fwd: `final` = (layer_args, layer_kw, fin_kw) as for bbb_final_fwd, `mid` / `first` =
+    (args, kw) as for bbb_linear_fwd, any of them None: the given pieces, which must be independent, in one launch."""
+    lib = L.load()
+    keep = []
+    a = f = m = n = None
+    if final is not None:
+        la, lk, fin_kw = final
+        a, res, k1 = _bbb_build(*la, **lk)
+        fin_kw = dict(fin_kw)
+        fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
+        fin_kw["logits"] = res["y"]
+        f, out, k2 = _fin_build(**fin_kw)
+        keep += [k1, k2]
+    if mid is not None:
+        m, _, k3 = _bbb_build(*mid[0], **mid[1])
+        keep.append(k3)
+    if first is not None:
+        n, _, k4 = _bbb_build(*first[0], **first[1])
+        keep.append(k4)
+    ref = lambda x: C.byref(x) if x is not None else None
+    L.check(lib.bnn_bbb_stage_fwd(ref(a), ref(f), ref(m), ref(n), _stream()), "bnn_bbb_stage_fwd")
+
+
 def bbb_tail2_fwd(hidden_args: tuple, hidden_kw: dict, last_args: tuple, last_kw: dict, fin_kw: dict):
     """Last hidden BBB layer + output layer + finalize through bnn_bbb_tail2_fwd (one launch for a one-sample
     evaluation).  `last_args[0]` (the output layer's x) must be the hidden layer's `out` tensor; `fin_kw` carries the

@@ -33,6 +33,7 @@
 #include "bnn_device.h"
 #include "bnn_fin.h"
 #include "../../include/bnn_hip.h"
+#include <string.h>
 
 namespace bnn {
 
@@ -694,10 +695,15 @@ __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const 
 // pieces of work (the caller keeps their buffers apart).  The output layer is a handful of latency-bound blocks
 // (five K-slice blocks and a hand-off at the MNIST shape, ~10 us); as a launch of its own it holds its stream's chain
 // for that long, next to the next evaluation's first layer it costs the chain nothing.
+// One step further (three-layer nets): the hidden layer of evaluation j+1 joins as a third independent piece
+// (blocks [nf, nf + nm), bf16 x, the first layer's tile plan), so that in steady state an evaluation is ONE launch.
 template <int XDT1, int R1>
-__global__ __launch_bounds__(768) void bbb_fwd_final_next_kernel(const BbbK p3, const FinPack fp, const BbbK p1, int nf) {
-  if ((int)blockIdx.x < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, (int)blockIdx.x);
-  else bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, (int)blockIdx.x - nf);
+__global__ __launch_bounds__(768) void bbb_fwd_final_next_kernel(const BbbK p3, const FinPack fp, const BbbK pm, const BbbK p1,
+                                                                 int nf, int nm) {
+  const int b = (int)blockIdx.x;
+  if (b < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, b);
+  else if (b < nf + nm) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, R1, true, false>(pm, nullptr, b - nf);
+  else bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, b - nf - nm);
 }
 
 // K1d  one-sample tail of an evaluation in ONE launch: the last hidden layer (K1a, any tile plan) and, run by
@@ -1322,7 +1328,67 @@ extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
 // Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
 // tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
 // the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
-static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* next, void* stream_) {
+// a plain layer that may ride in a combined launch: K1a tile form, bf16 math, vector path, nothing on the side
+static bool stage_ok(const bnn_bbb_fwd_args* l, bool al) {
+  const int mbs = (l->batch + 127) / 128;
+  const long gemm_blocks = (long)((l->out_features + 63) / 64) * l->n_samples * mbs;
+  return al && l->math == BNN_MATH_BF16 && !l->w_sampled && !l->split_scratch && !l->log_prior && !l->log_q &&
+         gemm_blocks < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1;
+}
+
+#define BNN_STAGE_LAUNCH(NEXT, PLR, GRID, BLOCK, LDS, ...)                                                     \
+  do {                                                                                                         \
+    if ((NEXT)->x_dtype == BNN_F32) {                                                                          \
+      if ((PLR) == 1) {                                                                                        \
+        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_F32, 1>, LDS);                                       \
+        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_F32, 1>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
+      } else {                                                                                                 \
+        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_F32, 2>, LDS);                                       \
+        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_F32, 2>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      if ((PLR) == 1) {                                                                                        \
+        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_BF16, 1>, LDS);                                      \
+        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_BF16, 1>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
+      } else {                                                                                                 \
+        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_BF16, 2>, LDS);                                      \
+        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_BF16, 2>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+
+// two independent plain layers (the hidden layer of one evaluation, the first layer of the next) in one launch
+static int stage_pair(const bnn_bbb_fwd_args* mid, const bnn_bbb_fwd_args* next, void* stream_) {
+  BbbK km, k1;
+  bool alm = false, al1 = false;
+  int rc = prepare(mid, km, alm);
+  if (rc != BNN_OK) return rc;
+  rc = prepare(next, k1, al1);
+  if (rc != BNN_OK) return rc;
+  const Plan plm = make_plan(mid->n_samples, mid->batch, mid->in_features, mid->out_features, true, mid->concurrency);
+  const Plan pl1 = make_plan(next->n_samples, next->batch, next->in_features, next->out_features, true, next->concurrency);
+  if (!(stage_ok(mid, alm) && stage_ok(next, al1) && mid->x_dtype == BNN_BF16 && plm.R == pl1.R && pl1.R <= 2 &&
+        env_int("BNN_HIP_FINAL_NEXT", 1) != 0)) {
+    rc = bnn_bbb_linear_fwd(mid, stream_);
+    return rc != BNN_OK ? rc : bnn_bbb_linear_fwd(next, stream_);
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nwc = plm.nw > pl1.nw ? plm.nw : pl1.nw;
+  const long totm = (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128);
+  const long tot1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
+  const dim3 grid((unsigned)(totm + tot1)), block(nwc * 64);
+  const size_t lds = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc) * sizeof(float);
+  FinPack fp;
+  memset(&fp, 0, sizeof(fp));
+  hipError_t err = hipSuccess;
+  BNN_STAGE_LAUNCH(next, pl1.R, grid, block, lds, km, fp, km, k1, 0, (int)totm);
+  if (err != hipSuccess) return (int)err;
+  err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* mid,
+                          const bnn_bbb_fwd_args* next, void* stream_) {
   BbbK k;
   bool al = false;
   int rc = prepare(a, k, al);
@@ -1340,8 +1406,10 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
     rc = bnn_bbb_linear_fwd(a, stream_);
     if (rc != BNN_OK) return rc;
     rc = bnn_elbo_finalize(f, stream_);
-    if (rc != BNN_OK || !next) return rc;
-    return bnn_bbb_linear_fwd(next, stream_);
+    if (rc != BNN_OK) return rc;
+    if (mid && next) return stage_pair(mid, next, stream_);
+    if (mid) return bnn_bbb_linear_fwd(mid, stream_);
+    return next ? bnn_bbb_linear_fwd(next, stream_) : BNN_OK;
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   fp.sums = f->sums;
@@ -1384,36 +1452,44 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
   }
   const long total = (long)a->n_samples * KS;           // one tile, one batch block, KS slices
   hipError_t err = hipSuccess;
+  if (!next && mid) {                                  // one plain layer beside the output layer: same kernel, it rides as `next`
+    next = mid;
+    mid = nullptr;
+  }
   if (next) {
-    // ---- combined launch with the next evaluation's first layer, when both take the plain tile forms
-    BbbK k1;
-    bool al1 = false;
+    // ---- combined launch with the next evaluation's first layer (and the hidden layer of the one between), when
+    // all take the plain tile forms
+    BbbK k1, km;
+    bool al1 = false, alm = false;
     rc = prepare(next, k1, al1);
     if (rc != BNN_OK) return rc;
-    const int mbs1 = (next->batch + 127) / 128;
-    const long gemm_blocks1 = (long)((next->out_features + 63) / 64) * next->n_samples * mbs1;
-    const bool combine = !tail_kernel && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && next->math == BNN_MATH_BF16 &&
-                         al1 && !next->w_sampled && !next->split_scratch && !next->log_prior && !next->log_q &&
-                         gemm_blocks1 < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1 && env_int("BNN_HIP_FINAL_NEXT", 1) != 0;
+    if (mid) {
+      rc = prepare(mid, km, alm);
+      if (rc != BNN_OK) return rc;
+    }
+    const bool combine = !tail_kernel && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && stage_ok(next, al1) &&
+                         env_int("BNN_HIP_FINAL_NEXT", 1) != 0;
     if (combine) {
       const Plan pl1 = make_plan(next->n_samples, next->batch, next->in_features, next->out_features, true, next->concurrency);
+      Plan plm = pl1;
+      bool mid_in = false;
+      if (mid) {
+        plm = make_plan(mid->n_samples, mid->batch, mid->in_features, mid->out_features, true, mid->concurrency);
+        mid_in = stage_ok(mid, alm) && mid->x_dtype == BNN_BF16 && plm.R == pl1.R;
+      }
       if (pl1.R <= 2) {
-        const int nwc = pl1.nw > nw ? pl1.nw : nw;
-        const long total1 = (long)pl1.tiles * next->n_samples * mbs1;
-        const dim3 gridc((unsigned)(total + total1)), blockc(nwc * 64);
+        int nwc = pl1.nw > nw ? pl1.nw : nw;
+        if (mid_in && plm.nw > nwc) nwc = plm.nw;
+        const long total1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
+        const long totalm = mid_in ? (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128) : 0;
+        const dim3 gridc((unsigned)(total + totalm + total1)), blockc(nwc * 64);
         const size_t ldsc = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
-#define BNN_FN(XDT1, RR)                                                                                          \
-  do {                                                                                                            \
-    err = allow_big_lds(bbb_fwd_final_next_kernel<XDT1, RR>, ldsc);                                               \
-    if (err == hipSuccess)                                                                                        \
-      hipLaunchKernelGGL((bbb_fwd_final_next_kernel<XDT1, RR>), gridc, blockc, ldsc, stream, k, fp, k1, (int)total); \
-  } while (0)
-        if (next->x_dtype == BNN_F32) { if (pl1.R == 1) BNN_FN(BNN_F32, 1); else BNN_FN(BNN_F32, 2); }
-        else { if (pl1.R == 1) BNN_FN(BNN_BF16, 1); else BNN_FN(BNN_BF16, 2); }
-#undef BNN_FN
+        if (!mid_in) km = k1;
+        BNN_STAGE_LAUNCH(next, pl1.R, gridc, blockc, ldsc, k, fp, km, k1, (int)total, (int)totalm);
         if (err != hipSuccess) return (int)err;
         err = hipGetLastError();
-        return err == hipSuccess ? BNN_OK : (int)err;
+        if (err != hipSuccess) return (int)err;
+        return (mid && !mid_in) ? bnn_bbb_linear_fwd(mid, stream_) : BNN_OK;
       }
     }
   }
@@ -1438,11 +1514,25 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
     rc = bnn_elbo_sums_(f, stream_);
     if (rc != BNN_OK) return rc;
   }
+  if (mid && next) return stage_pair(mid, next, stream_);
+  if (mid) return bnn_bbb_linear_fwd(mid, stream_);
   return next ? bnn_bbb_linear_fwd(next, stream_) : BNN_OK;
 }
 
 extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
-  return final_fwd_impl(a, f, nullptr, stream_);
+  return final_fwd_impl(a, f, nullptr, nullptr, stream_);
+}
+
+// One stage of a software pipeline over independent evaluations: any of {output layer + finalize of evaluation j,
+// hidden layer of evaluation j+1, first layer of evaluation j+2} in ONE launch (see include/bnn_hip.h).
+extern "C" int bnn_bbb_stage_fwd(const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* mid,
+                                 const bnn_bbb_fwd_args* first, void* stream_) {
+  if ((last == nullptr) != (fin == nullptr)) return BNN_ERR_NULL;
+  if (last) return final_fwd_impl(last, fin, mid, first, stream_);
+  if (mid && first) return stage_pair(mid, first, stream_);
+  if (mid) return bnn_bbb_linear_fwd(mid, stream_);
+  if (first) return bnn_bbb_linear_fwd(first, stream_);
+  return BNN_ERR_NULL;
 }
 
 // bnn_bbb_final_fwd(last, fin) and bnn_bbb_linear_fwd(next_first) -- the first layer of the NEXT, independent
@@ -1450,7 +1540,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
 extern "C" int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* next,
                                       void* stream_) {
   if (!next) return BNN_ERR_NULL;
-  return final_fwd_impl(a, f, next, stream_);
+  return final_fwd_impl(a, f, nullptr, next, stream_);
 }
 
 // The last hidden layer + the output layer + finalize of a ONE-sample evaluation in one launch (K1d) when the

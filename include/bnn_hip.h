@@ -351,6 +351,18 @@ int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fi
 int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* next_first,
                            void* stream);
 
+/* bnn_bbb_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer net: any of
+ *   last + fin : output layer + finalize of evaluation j      (as bnn_bbb_final_fwd; both NULL or both set)
+ *   mid        : hidden layer of evaluation j + 1             (as bnn_bbb_linear_fwd; bf16 x)
+ *   first      : first layer of evaluation j + 2              (as bnn_bbb_linear_fwd)
+ * in ONE launch, so that in steady state an evaluation costs its stream one launch instead of three dependent
+ * ones.  Same results as the separate calls.  The caller keeps the pieces independent: each evaluation in flight
+ * has its own activation and statistics buffers and a static sample_offset (only the finalize that ends a batch of
+ * evaluations advances a shared sample counter).  Pieces that cannot ride together (other tile plans, fp32 math, an
+ * output layer wider than 16 ...) are launched one after the other. */
+int bnn_bbb_stage_fwd(const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* mid,
+                      const bnn_bbb_fwd_args* first, void* stream);
+
 /* bnn_bbb_tail2_fwd — the last HIDDEN layer, the output layer and the finalize of a ONE-sample evaluation in one
  * launch: the same results as bnn_bbb_linear_fwd(hidden) followed by bnn_bbb_final_fwd(last, fin) with
  * last->x == hidden->y (bf16) and fin's two last workspaces those of the two layers, but whichever block of the

@@ -839,8 +839,9 @@ def test_presampled_evaluation_equals_the_fused_evaluation(dev, monkeypatch, sam
     assert not torch.equal(ra[0][0], ra[1][0])
 
 
+@pytest.mark.parametrize("depth3", [True, False])
 @pytest.mark.parametrize("stride", [1, 4])
-def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride):
+def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, depth3):
     """E one-sample evaluations per graph launch with the output layer + finalize of evaluation j sharing a launch
     with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd): every evaluation's 4-vector is the one the
     plain sequence gives for the same global sample indices -- bitwise, the kernels and their summation order are the
@@ -855,11 +856,12 @@ def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride):
     got = {}
     for pipe in (True, False):
         monkeypatch.setattr(engine, "PIPELINE_EVALS", pipe)
+        monkeypatch.setattr(engine, "PIPELINE_DEPTH3", depth3)
         slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
         bnn_hip.manual_seed(41, counter=700)
         ev = engine.GraphedElbo(net, xd, yd, 1, counter_stride=stride, sums_ring=(slab.view(-1), ring_len, 4),
                                 evals_per_replay=E)
-        assert ev.pipelined == pipe
+        assert ev.pipelined == pipe and (not pipe or ev.pipe3 == depth3)
         slab.fill_(-7.0)
         for _ in range(reps):
             ev.replay()
