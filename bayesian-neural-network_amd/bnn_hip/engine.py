@@ -555,6 +555,35 @@ class GraphedElbo:
                 final = (al, kl, fin_kw)
             ops.bbb_stage_fwd(final=final, mid=mid, first=first)
 
+    def steady_state_stage(self):
+        """For measurement (bench.py's roofline): a closure that enqueues ONE steady-state launch of the three-deep
+        pipeline -- output layer + finalize of the evaluation in slot 0, hidden layer of the one in slot 1, first layer
+        of the one in slot 2 -- without advancing the sample counter or the sums ring."""
+        if not self.pipe3:
+            raise ops.BnnHipError("steady_state_stage: this evaluator is not three-deep pipelined")
+        math_mode = state.math
+        sums = torch.zeros(4, dtype=torch.float32, device=self.x.device)
+
+        def call(i, slot):
+            sp = self.specs[i]
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            h = self.x if i == 0 else self.slot_bufs[i - 1][slot]
+            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
+            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+            return (h,) + p, dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=out.dtype,
+                                  eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
+                                  sample_counter=self.counter, workspace=ws, out=out, concurrency=self.stride,
+                                  prior=sp.m._prior_spec, want_stats=True)
+
+        al, kl = call(2, 0)
+        fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                      local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
+                      mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter, sample_counter_inc=0,
+                      out=self.out, sums=sums, ticket=self.ticket, scratch=self.scratch,
+                      workspaces=[self.slot_ws[0][0], self.slot_ws[1][0]])
+        mid, first = call(1, 1), call(0, 2)
+        return lambda: ops.bbb_stage_fwd(final=(al, kl, fin_kw), mid=mid, first=first)
+
     def _eager(self):
         if self.pipelined:
             self._enqueue_pipelined()
