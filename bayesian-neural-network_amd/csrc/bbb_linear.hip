@@ -145,11 +145,12 @@ __device__ __forceinline__ void load_xfrag(const char* __restrict__ xs, long off
   }
 }
 
-__device__ __forceinline__ float mix_logp(const BbbK& p, float w) {
+// the mixture density itself (argument of the log), for add_log
+__device__ __forceinline__ float mix_p(const BbbK& p, float w) {
   const float w2 = w * w;
   const float p1 = fast_exp(__builtin_fmaf(-w2, p.inv2var1, p.c1));
   const float p2 = fast_exp(__builtin_fmaf(-w2, p.inv2var2, p.c2));
-  return fast_log(p.pi * p1 + (1.0f - p.pi) * p2);
+  return __builtin_fmaf(p.pi, p1, (1.0f - p.pi) * p2);
 }
 
 // Sampled bias of feature n for global sample gs (+ its stats); returns b.
@@ -173,8 +174,8 @@ __device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brh
   const float b = __builtin_fmaf(sig, e, bmu);
   if (do_stats) {
     s_e2 = __builtin_fmaf(e, e, s_e2);
-    s_a += (p.prior_kind == BNN_PRIOR_GAUSS) ? b * b : mix_logp(p, b);
-    if (do_ls) s_ls += fast_log(sig);
+    s_a = (p.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, mix_p(p, b));
+    if (do_ls) s_ls = add_log(s_ls, sig);
   }
   return b;
 }
@@ -459,7 +460,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
         const bool ok = ALIGNED ? true : (j < valid);
         sg[j] = softplus(sg[j]);
         w[j] = ok ? __builtin_fmaf(sg[j], e[j], mu[j]) : 0.f;
-        e2 += ok ? e[j] * e[j] : 0.f;
+        e2 = ok ? __builtin_fmaf(e[j], e[j], e2) : e2;
       }
     }
     if (do_stats && !PRE) {
@@ -468,11 +469,11 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
         for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a += (ALIGNED || j < valid) ? mix_logp(p, w[j]) : 0.f;
+        for (int j = 0; j < 8; ++j) a = (ALIGNED || j < valid) ? add_log(a, mix_p(p, w[j])) : a;
       }
       if (do_ls) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ls += (ALIGNED || j < valid) ? fast_log(sg[j]) : 0.f;
+        for (int j = 0; j < 8; ++j) ls = (ALIGNED || j < valid) ? add_log(ls, sg[j]) : ls;
       }
       const bool lane_ok = !ALIGNED || valid > 0;
       s_e2 += lane_ok ? e2 : 0.f;
@@ -881,11 +882,11 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
         for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a += mix_logp(p, w[j]);
+        for (int j = 0; j < 8; ++j) a = add_log(a, mix_p(p, w[j]));
       }
       if (do_ls) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ls += fast_log(sg[j]);
+        for (int j = 0; j < 8; ++j) ls = add_log(ls, sg[j]);
       }
       s_e2 += lane_ok ? e2 : 0.f;
       s_a += lane_ok ? a : 0.f;

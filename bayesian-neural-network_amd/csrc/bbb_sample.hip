@@ -55,11 +55,12 @@ struct SampleK {
   int cast_first;          // first block of the cast job (after every layer's blocks)
 };
 
-__device__ __forceinline__ float sample_mix_logp(const SampleL& L, float w) {
+// the mixture density (argument of the log; accumulated with add_log: explicit contraction, see bnn_device.h)
+__device__ __forceinline__ float sample_mix_p(const SampleL& L, float w) {
   const float w2 = w * w;
   const float p1 = fast_exp(__builtin_fmaf(-w2, L.inv2var1, L.c1));
   const float p2 = fast_exp(__builtin_fmaf(-w2, L.inv2var2, L.c2));
-  return fast_log(L.pi * p1 + (1.0f - L.pi) * p2);
+  return __builtin_fmaf(L.pi, p1, (1.0f - L.pi) * p2);
 }
 
 __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const SampleK p) {
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const Sample
       w[j] = __builtin_fmaf(sg, e[j], mu[j]);
       e2 = __builtin_fmaf(e[j], e[j], e2);
       if (L.prior_kind == BNN_PRIOR_GAUSS) a = __builtin_fmaf(w[j], w[j], a);
-      else a += sample_mix_logp(L, w[j]);
-      if (do_ls) ls += fast_log(sg);
+      else a = add_log(a, sample_mix_p(L, w[j]));
+      if (do_ls) ls = add_log(ls, sg);
     }
     s_e2 += ok ? e2 : 0.f;
     s_a += ok ? a : 0.f;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const Sample
     const float b = __builtin_fmaf(sg, e, bmu);
     L.b_out[(size_t)s * N + bn] = b;
     s_e2 = __builtin_fmaf(e, e, s_e2);
-    s_a += (L.prior_kind == BNN_PRIOR_GAUSS) ? b * b : sample_mix_logp(L, b);
-    if (do_ls) s_ls += fast_log(sg);
+    s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
+    if (do_ls) s_ls = add_log(s_ls, sg);
   }
   const float a0 = wave_sum(s_e2), a1 = wave_sum(s_a), a2 = wave_sum(s_ls);
   if (lane == 0) {

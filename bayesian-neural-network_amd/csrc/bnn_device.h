@@ -58,6 +58,10 @@ __device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample,
 // ---------------------------------------------------------------------------- math
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+// acc + log(x) as ONE explicit fma.  The statistics sums must not depend on which kernel a piece of code is inlined
+// into: with -ffp-contract=fast `acc += fast_log(x)` is an fma in one kernel and mul + add in another (the pipelined
+// evaluator's results are compared bitwise with the plain sequence's), so every accumulation states its contraction.
+__device__ __forceinline__ float add_log(float acc, float x) { return __builtin_fmaf(__builtin_amdgcn_logf(x), kLn2, acc); }
 
 // sigma = log1p(exp(rho)) (networks.py:39), no threshold trick: +inf once exp overflows, 0 once
 // it underflows, like the reference.  With u = fl(1 + e) and d = u - 1 (exact),

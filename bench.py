@@ -383,7 +383,7 @@ def main():
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "evaluations_in_flight": nstr,
                    "evaluations_per_graph_launch": per_replay,
                    "pipelined_evaluations": bool(getattr(evs[0], "pipelined", False)),   # output layer + finalize of one
-                   # evaluation share a launch with the next one's first layer (results bitwise those of one launch per layer)
+                   # evaluation share a launch with the next ones' hidden and first layers (same per-evaluation results)
                    "parallelism": (f"mc-sample-shard x{world}; RCCL sum all-reduce of the 4 ELBO scalars of every evaluation, "
                                    f"{args.allreduce_every * nstr} evaluations per call, asynchronous") if world > 1 else "single GPU"},
         "kl_elements_per_s": value * nst,

@@ -874,3 +874,34 @@ def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, dep
     assert torch.equal(la, lb)
     for k in oa:
         assert torch.equal(oa[k], ob[k])
+
+
+@pytest.mark.parametrize("dims,mode,B,mixture", [((1, 50, 1), "regression", 100, False), ((64, 72, 10), "classification", 37, True),
+                                                  ((784, 1200, 10), "classification", 128, True)])
+def test_pipelined_evaluations_on_shapes_that_cannot_share_a_launch(dev, monkeypatch, dims, mode, B, mixture):
+    """The pipelined evaluator on nets whose layers cannot ride in one launch (unaligned widths: bnn_bbb_stage_fwd then
+    runs its pieces one after the other) and with the mixture prior: still the plain sequence's results."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, False, dims, mode, prior_init=(1.0, 0.0, -6.0) if mixture else (1.0,), mixture=mixture, B=B)
+    x, y = synth.synth_batch(mode, B, dims[0], dims[2])
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    E, reps, ring_len = 4, 2, 8
+    got = {}
+    for pipe in (True, False):
+        monkeypatch.setattr(engine, "PIPELINE_EVALS", pipe)
+        slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
+        bnn_hip.manual_seed(43, counter=300)
+        ev = engine.GraphedElbo(net, xd, yd, 1, counter_stride=2, sums_ring=(slab.view(-1), ring_len, 4), evals_per_replay=E)
+        assert ev.pipelined == pipe
+        slab.fill_(-7.0)
+        for _ in range(reps):
+            ev.replay()
+        torch.cuda.synchronize()
+        got[pipe] = (slab.clone(), int(ev.counter.item()), ev.logits.clone())
+    assert got[True][1] == got[False][1]
+    # the scalars to the last bit or two of fp32 (the output layer's block has 12 waves in the shared launch, 8 alone;
+    # one evaluation in eight was seen 1 ulp apart in log q at this tile plan), the logits exactly
+    close(got[True][0], got[False][0].cpu().numpy(), rtol=3e-7)
+    assert bool((got[True][0][:, 0, 3] == 1.0).all())
+    assert torch.equal(got[True][2], got[False][2])
