@@ -67,6 +67,7 @@ class GraphedTrainStep:
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
+        self.fin_scratch = None if net.local_reparam else ops.final_scratch(self.samples, dev)   # K-slices of the fused output layer
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
         self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
         offs, tot = [], 0
@@ -154,8 +155,23 @@ class GraphedTrainStep:
                       b_rho=sp.m.bias_rho.detach(), prior=sp.m._prior_spec, layer_id=sp.layer_id, workspace=self.wstat[i],
                       w_out=self.wsamp[i], b_out=self.bsamp[i]) for i, sp in enumerate(specs)],
                 n_samples=S, seed=state.seed, sample_offset=first, sample_counter=self.counter)
+        fin = None
+        fin_kw = dict(layer_in=[sp.in_out[0] for sp in specs], layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr,
+                      prior=specs[0].m._prior_spec, n_samples=S, target=self.y, mode=net.mode, nll_sigma=self.sigma,
+                      ticket=self.fin_ticket if S > 1 else None)
         for i, sp in enumerate(specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            if not lr and i == len(specs) - 1:
+                # output layer + finalize in one launch (it samples its own few weights -- the same Philox elements the
+                # sampling launch drew for the backward's w_sampled)
+                res, fin = ops.bbb_final_fwd((h,) + p, dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math,
+                                                            relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
+                                                            seed=state.seed, layer_id=sp.layer_id, sample_offset=first,
+                                                            sample_counter=self.counter, want_stats=True),
+                                             dict(workspaces=wss, scratch=self.fin_scratch, **fin_kw))
+                saved.append((h, res["y"], None, p))
+                h = res["y"]
+                continue
             if self.presample:
                 y = ops.bbb_sampled_matmul(h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu, y_dtype=torch.float32)
                 saved.append((h, y, None, p))
@@ -171,10 +187,8 @@ class GraphedTrainStep:
             saved.append((h, out["y"], out.get("v"), p))
             wss.append(out["workspace"])
             h = out["y"]
-        fin = ops.elbo_finalize(workspaces=wss, layer_in=[sp.in_out[0] for sp in specs],
-                                layer_out=[sp.in_out[1] for sp in specs], local_reparam=lr, prior=specs[0].m._prior_spec,
-                                n_samples=S, logits=h, target=self.y, mode=net.mode, nll_sigma=self.sigma,
-                                ticket=self.fin_ticket if S > 1 else None)
+        if fin is None:
+            fin = ops.elbo_finalize(workspaces=wss, logits=h, **fin_kw)
         # loss, backward seeds and d nll / d logits in one launch (the NLL seed is the constant 1 / (S ranks))
         out4, g_a, g_b, g_kl3, g = ops.elbo_loss_nll_bwd(fin["kl"] if lr else fin["log_prior"], None if lr else fin["log_q"],
                                                          fin["nll"], self.beta, S, lr, h, self.y, net.mode, self.sigma,
