@@ -159,6 +159,7 @@ class FinalizeArgs(C.Structure):
         ("sample_counter", C.c_void_p), ("sample_counter_inc", C.c_uint32), ("reserved", C.c_uint32),
         ("sums", C.c_void_p), ("ticket", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
         ("sums_ring_pos", C.c_void_p), ("sums_ring_len", C.c_uint32), ("sums_ring_stride", C.c_uint32),
+        ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_dst_sq", C.c_void_p), ("cast_n", C.c_int64),
     ]
 
 

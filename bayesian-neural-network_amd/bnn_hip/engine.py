@@ -412,15 +412,13 @@ class GraphedElbo:
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    if self.pipelined:
-                        self._enqueue_pipelined()
-                    else:
-                        for _ in range(self.per_replay):
-                            self._enqueue()
+                    self._eager()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = g
 
-    def _enqueue(self):
+    def _enqueue(self, skip_cast: bool = False, ride_cast: bool = False):
+        """One evaluation.  LR with several evaluations per graph launch: the input cast of evaluation j + 1 rides on the
+        finalize launch of evaluation j (`ride_cast`; the next call then passes `skip_cast`), one launch less on the chain."""
         math_mode = state.math
         h_sq = None
         if self.presample:
@@ -434,6 +432,8 @@ class GraphedElbo:
             h = self.x16 if self.x16 is not None else self.x
         elif self.x16 is None:
             h = self.x
+        elif skip_cast:
+            h, h_sq = self.x16, (self.x16_sq if self.lr_sq else None)
         elif self.lr_sq:
             h, h_sq = ops.cast_bf16(self.x, out=self.x16, out_sq=self.x16_sq)
         else:
@@ -480,7 +480,8 @@ class GraphedElbo:
                                    w_sigma=self.wsigma[i], **common)
             h = self.bufs[i]
         if self.lr:
-            ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
+            ops.elbo_finalize(workspaces=self.ws, logits=h,
+                              cast=(self.x, self.x16, self.x16_sq if self.lr_sq else None) if ride_cast else None, **fin_kw)
 
     def _enqueue_pipelined(self):
         """per_replay one-sample BBB evaluations as L0(e0) L1..(e0) [final(e0) + L0(e1)] L1..(e1) ... final(e_last)."""
@@ -588,8 +589,9 @@ class GraphedElbo:
         if self.pipelined:
             self._enqueue_pipelined()
             return
-        for _ in range(self.per_replay):
-            self._enqueue()
+        ride = PIPELINE_EVALS and self.lr and self.x16 is not None and self.per_replay > 1
+        for j in range(self.per_replay):
+            self._enqueue(skip_cast=ride and j > 0, ride_cast=ride and j < self.per_replay - 1)
 
     def replay(self) -> torch.Tensor:
         if self.stream is not None:

@@ -326,7 +326,7 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
 def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
                logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
                nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
-               ticket=None, scratch=None, sums_ring=None):
+               ticket=None, scratch=None, sums_ring=None, cast=None):
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -376,6 +376,14 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
         require_device(ring_pos)
         a.sums_ring_pos, a.sums_ring_len, a.sums_ring_stride = ring_pos.data_ptr(), int(ring_len), int(ring_stride)
         keep.append(ring_pos)
+    if cast is not None:                           # (fp32 src, bf16 dst, bf16 dst_sq | None): rides on bnn_elbo_finalize
+        src, dst, dsq = cast
+        require_device(src, dst, dsq)
+        if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.numel() != dst.numel() or \
+                not src.is_contiguous() or not dst.is_contiguous() or (dsq is not None and dsq.numel() != src.numel()):
+            raise BnnHipError("finalize cast rider: contiguous fp32 source, bf16 destination(s) of the same size")
+        a.cast_src, a.cast_dst, a.cast_dst_sq, a.cast_n = src.data_ptr(), dst.data_ptr(), _ptr(dsq), src.numel()
+        keep += [src, dst, dsq]
     a.ticket = _ptr(ticket)
     a.scratch = _ptr(scratch)
     a.scratch_bytes = scratch.numel() * scratch.element_size() if scratch is not None else 0

@@ -97,13 +97,62 @@ static inline int kl_blocks(long n) {
 }
 
 // ----------------------------------------------------------------------------- K4
+// fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
+// the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
+__device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                               __bf16* __restrict__ dsq, long n, int vec_ok, long tid, long nt) {
+  if (vec_ok) {
+    const long n8 = n >> 3;
+    for (long i = tid; i < n8; i += nt) {
+      const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      bf16x8 v, q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (__bf16)f[j];
+        q[j] = (__bf16)(f[j] * f[j]);
+      }
+      reinterpret_cast<bf16x8*>(dst)[i] = v;
+      if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
+    }
+    for (long i = (n8 << 3) + tid; i < n; i += nt) {
+      dst[i] = (__bf16)src[i];
+      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+    }
+  } else {
+    for (long i = tid; i < n; i += nt) {
+      dst[i] = (__bf16)src[i];
+      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+    }
+  }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, __bf16* __restrict__ dsq,
+                                 long n, int vec_ok) {
+  cast_bf16_span(src, dst, dsq, n, vec_ok, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// An independent cast that rides on a finalize launch (blocks >= nfin): the NEXT evaluation's input batch.
+struct CastJob {
+  const float* src;
+  __bf16* dst;
+  __bf16* dsq;
+  long n;
+  int vec_ok;
+};
+
 // grid = n_samples blocks (one sample each), or ONE block looping over all samples when `single`: then the
 // block also writes the 4-vector of sums, in sample order.  With a `ticket` word the one-block-per-sample form
 // does that too: the last-arriving block folds the per-sample scalars (release / ticket / acquire, nobody
 // waits), so a handful of samples is finalized in parallel and still in one launch (8 samples: 31.7 us serially).
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums,
-                                                            uint32_t* ticket) {
+                                                            uint32_t* ticket, int nfin, const CastJob cj) {
   __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
+  if ((int)blockIdx.x >= nfin) {                           // rider blocks: block-uniform, before any barrier
+    cast_bf16_span(cj.src, cj.dst, cj.dsq, cj.n, cj.vec_ok, (long)((int)blockIdx.x - nfin) * blockDim.x + threadIdx.x,
+                   (long)((int)gridDim.x - nfin) * blockDim.x);
+    return;
+  }
   int T[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l)
@@ -207,37 +256,6 @@ __global__ void softplus_kernel(const float* __restrict__ rho, float* __restrict
     for (long i = ((n >> 2) << 2) + tid; i < n; i += nt) sigma[i] = softplus(rho[i]);
   } else {
     for (long i = tid; i < n; i += nt) sigma[i] = softplus(rho[i]);
-  }
-}
-
-// fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
-// the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).
-__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, __bf16* __restrict__ dsq,
-                                 long n, int vec_ok) {
-  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
-  if (vec_ok) {
-    const long n8 = n >> 3;
-    for (long i = tid; i < n8; i += nt) {
-      const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      bf16x8 v, q;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = (__bf16)f[j];
-        q[j] = (__bf16)(f[j] * f[j]);
-      }
-      reinterpret_cast<bf16x8*>(dst)[i] = v;
-      if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
-    }
-    for (long i = (n8 << 3) + tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
-    }
-  } else {
-    for (long i = tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
-    }
   }
 }
 
@@ -491,8 +509,23 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   const bool small = (long)a->n_samples * a->batch * a->classes <= 65536;
   const bool ticketed = a->n_samples > 1 && a->n_samples <= 64 && a->ticket != nullptr;
   const int single = a->n_samples == 1 || (a->n_samples <= 16 && small && !ticketed);
-  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(single ? 1 : a->n_samples), dim3(256), 0, stream, k, cst, single, a->sums,
-                     (single || !ticketed) ? (uint32_t*)nullptr : a->ticket);
+  const int nfin = single ? 1 : a->n_samples;
+  CastJob cj{nullptr, nullptr, nullptr, 0, 0};
+  int nrider = 0;
+  if (a->cast_n > 0) {                                      // the next evaluation's input cast rides on this launch
+    if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(a->cast_src) & 3) || (reinterpret_cast<uintptr_t>(a->cast_dst) & 1)) return BNN_ERR_ALIGN;
+    cj.src = a->cast_src; cj.dst = reinterpret_cast<__bf16*>(a->cast_dst); cj.dsq = reinterpret_cast<__bf16*>(a->cast_dst_sq);
+    cj.n = (long)a->cast_n;
+    cj.vec_ok = !((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst) |
+                   reinterpret_cast<uintptr_t>(a->cast_dst_sq)) & 15);
+    long nb = (cj.n / 8 + 255) / 256;
+    nrider = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  } else if (a->cast_n < 0) {
+    return BNN_ERR_SHAPE;
+  }
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3((unsigned)(nfin + nrider)), dim3(256), 0, stream, k, cst, single, a->sums,
+                     (single || !ticketed) ? (uint32_t*)nullptr : a->ticket, nfin, cj);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->sums && !single && !ticketed) {

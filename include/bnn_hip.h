@@ -329,6 +329,10 @@ typedef struct bnn_finalize_args {
                                        that a sharded job all-reduces once per many evaluations. */
   uint32_t sums_ring_len;
   uint32_t sums_ring_stride;        /* floats between consecutive slots (>= 4) */
+  const float* cast_src;            /* bnn_elbo_finalize only, optional rider on the same launch: an INDEPENDENT */
+  void* cast_dst;                   /* bnn_cast_bf16(cast_src, cast_dst, cast_dst_sq, cast_n) -- the next         */
+  void* cast_dst_sq;                /* evaluation's input batch, so that its cast costs the chain of dependent   */
+  int64_t cast_n;                   /* launches nothing; 0 = none                                                */
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);

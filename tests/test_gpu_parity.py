@@ -905,3 +905,32 @@ def test_pipelined_evaluations_on_shapes_that_cannot_share_a_launch(dev, monkeyp
     close(got[True][0], got[False][0].cpu().numpy(), rtol=3e-7)
     assert bool((got[True][0][:, 0, 3] == 1.0).all())
     assert torch.equal(got[True][2], got[False][2])
+
+
+@pytest.mark.parametrize("S", [1, 8])
+def test_lr_evaluations_with_the_cast_riding_on_the_previous_finalize(dev, monkeypatch, S):
+    """LR, several evaluations per graph launch: the input cast (and, from 8 samples, x^2) of evaluation j + 1 is done by
+    extra blocks of evaluation j's finalize launch (bnn_finalize_args.cast_*); every evaluation's 4-vector is bitwise
+    that of the plain sequence."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, True, (784, 1200, 10), "classification")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    E, reps, ring_len = 4, 2, 8
+    got = {}
+    for pipe in (True, False):
+        monkeypatch.setattr(engine, "PIPELINE_EVALS", pipe)
+        slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
+        bnn_hip.manual_seed(47, counter=100)
+        ev = engine.GraphedElbo(net, xd, yd, S, counter_stride=4, sums_ring=(slab.view(-1), ring_len, 4), evals_per_replay=E)
+        ev.x16.zero_()                                           # the riders (or the per-evaluation casts) must refill it
+        slab.fill_(-7.0)
+        for _ in range(reps):
+            ev.replay()
+        torch.cuda.synchronize()
+        got[pipe] = (slab.clone(), int(ev.counter.item()), ev.logits.clone(), ev.x16.clone())
+    assert got[True][1] == got[False][1]
+    assert torch.equal(got[True][0], got[False][0]) and bool((got[True][0][:, 0, 3] == float(S)).all())
+    assert torch.equal(got[True][2], got[False][2]) and torch.equal(got[True][3], got[False][3])
+    assert torch.equal(got[True][3], xd.view(128, -1).to(torch.bfloat16))
