@@ -21,7 +21,7 @@ EXPORTS = (
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_stage_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_next_fwd", "bnn_bbb_stage_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
 )
@@ -203,6 +203,8 @@ def load():
     lib.bnn_mc_softmax_mean.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bnn_bbb_final_next_fwd.restype = C.c_int
     lib.bnn_bbb_final_next_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs), C.c_void_p]
+    lib.bnn_lr_stage_fwd.restype = C.c_int
+    lib.bnn_lr_stage_fwd.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.c_void_p]
     lib.bnn_bbb_stage_fwd.restype = C.c_int
     lib.bnn_bbb_stage_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs),
                                       C.POINTER(BbbFwdArgs), C.c_void_p]

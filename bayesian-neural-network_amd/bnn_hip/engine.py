@@ -396,6 +396,14 @@ class GraphedElbo:
             self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(2)]
             self.slot_ws = [[self.ws[i]] + [ops.bbb_workspace(S, self.specs[i].in_out[1], dev) for _ in range(2)]
                             for i in range(2)]
+        # LR, three layers: the same three-deep pipeline (bnn_lr_stage_fwd); the finalize stays a launch of its own and
+        # carries the input cast of a later evaluation
+        self.lr_pipe3 = (PIPELINE_EVALS and PIPELINE_DEPTH3 and self.lr and self.per_replay > 1 and nl == 3 and
+                         hid == torch.bfloat16 and self.x16 is not None and not self.lr_sq and
+                         all(w is None for w in self.wfrag))
+        if self.lr_pipe3:
+            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(2)]
+            self.slot_ws = [[self.ws[i]] + [ops.lr_workspace(self.specs[i].in_out[1], dev) for _ in range(2)] for i in range(2)]
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -585,9 +593,49 @@ class GraphedElbo:
         mid, first = call(1, 1), call(0, 2)
         return lambda: ops.bbb_stage_fwd(final=(al, kl, fin_kw), mid=mid, first=first)
 
+    def _enqueue_lr_pipelined(self):
+        """LR: stage t = {output layer of evaluation t-2, hidden layer of t-1, first layer of t} in one launch, then the
+        finalize of evaluation t-2 (carrying the input cast of evaluation t+1 when there is one)."""
+        E = self.per_replay
+        inc = self.samples * self.stride
+        math_mode = state.math
+
+        def layer_call(i, j):
+            sp = self.specs[i]
+            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            slot = j % 3
+            h = self.x16 if i == 0 else self.slot_bufs[i - 1][slot]
+            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
+            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+            return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
+                                  relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
+                                  layer_id=sp.layer_id, sample_offset=self.lo + j * inc, sample_counter=self.counter,
+                                  want_kl=True, workspace=ws, out=out, concurrency=self.stride)
+
+        cast = lambda: ops.cast_bf16(self.x, out=self.x16)
+        cast()                                                # evaluation 0 (the same batch for every evaluation of the replay:
+        for t in range(E + 2):                                # later casts rewrite x16 with the same bytes, off the chain)
+            ops.lr_stage_fwd(last=layer_call(2, t - 2) if 0 <= t - 2 < E else None,
+                             mid=layer_call(1, t - 1) if 0 <= t - 1 < E else None,
+                             first=layer_call(0, t) if t < E else None)
+            j = t - 2
+            if 0 <= j < E:
+                rider = (self.x, self.x16, None) if t + 1 < E else None
+                ops.elbo_finalize(workspaces=[self.slot_ws[0][j % 3], self.slot_ws[1][j % 3], self.ws[2]], logits=self.bufs[2],
+                                  layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                                  local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
+                                  target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                                  sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
+                                  ticket=self.ticket, sums_ring=self.ring, cast=rider)
+            elif t + 1 < E:
+                cast()                                        # no finalize to ride on yet
+
     def _eager(self):
         if self.pipelined:
             self._enqueue_pipelined()
+            return
+        if self.lr_pipe3:
+            self._enqueue_lr_pipelined()
             return
         ride = PIPELINE_EVALS and self.lr and self.x16 is not None and self.per_replay > 1
         for j in range(self.per_replay):

@@ -248,13 +248,12 @@ def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dt
     return y
 
 
-def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
+def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
                   out_sq=None, w_frag=None, want_v: bool = False, concurrency: int = 0):
-    """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
-    lib = L.load()
+    """Argument block of K3 + the result dict + the tensors it points at."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
@@ -304,8 +303,29 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float
     if want_v:                                       # the variance the kernel sampled from: saved for bnn_lr_linear_bwd
         v = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
         a.v_out = v.data_ptr()
+    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace)
+    return a, res, keep
+
+
+def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
+    """K3.  Weights are [in, out].  Returns dict(y, workspace, kl3, eps_act, eps_b)."""
+    lib = L.load()
+    a, res, keep = _lr_build(x, w_mu, w_rho, b_mu, b_rho, **kw)
     L.check(lib.bnn_lr_linear_fwd(C.byref(a), _stream()), "bnn_lr_linear_fwd")
-    return dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v)
+    return res
+
+
+def lr_stage_fwd(last=None, mid=None, first=None):
+    """bnn_lr_stage_fwd: `last` / `mid` / `first` = (args, kw) as for lr_linear_fwd (any may be None): the output layer
+    of one evaluation, the hidden layer of the next and the first layer of the one after, independent, in one launch."""
+    lib = L.load()
+    built = [(_lr_build(*c[0], **c[1]) if c is not None else None) for c in (last, mid, first)]
+    ref = lambda t_: C.byref(t_[0]) if t_ is not None else None
+    L.check(lib.bnn_lr_stage_fwd(ref(built[0]), ref(built[1]), ref(built[2]), _stream()), "bnn_lr_stage_fwd")
+    return [t_[1] if t_ is not None else None for t_ in built]
+
+
 
 
 def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tensor:

@@ -68,8 +68,10 @@ struct LrK {
 // MT = batch tiles (of 16 rows) per block: 8, or 2 for a narrow layer (the 10-class output layer is
 // 3 feature tiles: with 128 rows per block three blocks would each ingest all of x; 32-row blocks
 // make 12 of them, each with a quarter of x, 8 accumulators and room for 12 waves).
+// `forced_item` >= 0 runs that work item whatever the block index is (the stage kernel below places several layers'
+// blocks in one grid).
 template <int MATH, int XDT, int R, int MT>
-__global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p) {
+__device__ __forceinline__ void lr_fwd_body(const LrK& p, int forced_item) {
   constexpr int F = 16 / R, FG = F / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
   const int c = r / F, f = r % F;
   const int K = p.K, N = p.N, B = p.B;
   const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
-  int item;
-  if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
+  int item = forced_item;
+  if (forced_item < 0 && !xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int n = nt * F + f;
   const bool n_ok = n < N;
@@ -400,6 +402,22 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
   }
   LR_STAMP(7);
   LR_STAMP_RT(9);
+}
+
+template <int MATH, int XDT, int R, int MT>
+__global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p) {
+  lr_fwd_body<MATH, XDT, R, MT>(p, -1);
+}
+
+// K3e  one stage of the evaluation pipeline for the MNIST-shaped LR net (see K1e in bbb_linear.hip): the narrow output
+// layer of evaluation j (R = 4 feature classes, 32-row blocks), the hidden layer of evaluation j + 1 and the first
+// layer of evaluation j + 2 (whole 16-feature tiles, 128-row blocks) as three block ranges of ONE grid of 8-wave
+// blocks.  Independent pieces: the caller keeps their buffers apart and gives each a static sample offset.
+__global__ __launch_bounds__(512) void lr_stage_kernel(const LrK p2, const LrK p1, const LrK p0, int n2, int n1) {
+  const int b = (int)blockIdx.x;
+  if (b < n2) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 4, 2>(p2, b);
+  else if (b < n2 + n1) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p1, b - n2);
+  else lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p0, b - n2 - n1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -780,7 +798,8 @@ extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 
-extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
+// validate the arguments and fill the kernel parameter block
+static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_lr_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
@@ -799,9 +818,6 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   const bool ybf = a->y_dtype == BNN_BF16;
   if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y) & (ybf ? 7 : 15))) return BNN_ERR_ALIGN;
   if ((a->in_features % 8 == 0) && (reinterpret_cast<uintptr_t>(a->x) & 15)) return BNN_ERR_ALIGN;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-
-  LrK k;
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
@@ -820,6 +836,55 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     k.dbg = v ? reinterpret_cast<unsigned long long*>(strtoull(v, nullptr, 0)) : nullptr;
   }
 #endif
+  return BNN_OK;
+}
+
+// tile plan of the K3a form: a function of the shape (and the concurrency hint) only
+struct LrPlan {
+  int R, MT, nw;
+  long total;       // blocks
+  bool gemm;        // the launch would take the K3b block-GEMM form instead
+};
+
+static LrPlan lr_plan(const bnn_lr_fwd_args* a) {
+  LrPlan pl{};
+  const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
+  const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
+  const int force = lr_env_int("BNN_HIP_LR_GEMM", -1);
+  const bool can = !a->v_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+                   !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
+  pl.gemm = can && (force == 1 || (force != 0 && gemm_blocks >= 300));
+  int R = 1;
+  const long want_blocks = 120 / (a->concurrency > 1 ? a->concurrency : 1);
+  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < want_blocks) R *= 2;
+  const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
+  if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
+  const int F = 16 / R;
+  const int ssteps = (K + 32 * R - 1) / (32 * R);
+  int MT = ((long)((N + F - 1) / F) * a->n_samples * mbs < 64 && N <= 64 && a->batch > 32) ? 2 : 8;
+  const int forceMT = lr_env_int("BNN_HIP_LR_MT", 0);
+  if (forceMT == 2 || forceMT == 8) MT = forceMT;
+  const int max_nw = MT == 2 ? 12 : 8;
+  int spw = 1;
+  while ((ssteps + spw - 1) / spw > max_nw) ++spw;
+  int nw = (ssteps + spw - 1) / spw;
+  nw = nw < 1 ? 1 : nw;
+  if (ssteps >= 4 && lr_env_int("BNN_HIP_LR_WAVES4", 1)) nw = (ssteps >= max_nw ? max_nw : ssteps) & ~3;
+  const int mt = a->batch >= 16 * MT ? MT : (a->batch + 15) / 16;
+  const int need = (mt * 16 * (F / 4) + 127) / 128;
+  if (nw < need) nw = need;
+  pl.R = R; pl.MT = MT; pl.nw = nw;
+  pl.total = (long)((N + F - 1) / F) * a->n_samples * ((a->batch + 16 * MT - 1) / (16 * MT));
+  return pl;
+}
+
+extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
+  LrK k;
+  {
+    const int rc = lr_fill(a, k);
+    if (rc != BNN_OK) return rc;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 
   // launch geometry: a function of the shape only
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
@@ -922,4 +987,49 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     if (err != hipSuccess) return (int)err;
   }
   return BNN_OK;
+}
+
+// One stage of the evaluation pipeline (see include/bnn_hip.h): the three independent layers in one launch when they
+// take the tile plans lr_stage_kernel is built for, one after the other otherwise.
+extern "C" int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first,
+                                void* stream_) {
+  const bnn_lr_fwd_args* parts[3] = {last, mid, first};
+  if (!last && !mid && !first) return BNN_ERR_NULL;
+  auto sequential = [&]() {
+    for (int i = 0; i < 3; ++i)
+      if (parts[i]) {
+        const int rc = bnn_lr_linear_fwd(parts[i], stream_);
+        if (rc != BNN_OK) return rc;
+      }
+    return (int)BNN_OK;
+  };
+  if (lr_env_int("BNN_HIP_LR_STAGE", 1) == 0) return sequential();
+  LrK k[3];
+  long n[3] = {0, 0, 0};
+  int present = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (!parts[i]) continue;
+    ++present;
+    const bnn_lr_fwd_args* a = parts[i];
+    const int rc = lr_fill(a, k[i]);
+    if (rc != BNN_OK) return rc;
+    const LrPlan pl = lr_plan(a);
+    const bool shape_ok = i == 0 ? (pl.R == 4 && pl.MT == 2) : (pl.R == 1 && pl.MT == 8);
+    if (pl.gemm || !shape_ok || pl.nw > 8 || a->math != BNN_MATH_BF16 || a->x_dtype != BNN_BF16 || a->kl_out ||
+        (a->in_features & 7))
+      return sequential();
+    n[i] = pl.total;
+  }
+  if (present < 2) return sequential();
+  for (int i = 0; i < 3; ++i)
+    if (!parts[i]) k[i] = k[parts[0] ? 0 : (parts[1] ? 1 : 2)];            // placeholder, its block range is empty
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const size_t lds = ((size_t)8 * 8 * 64 * 4 + 16 + 3 * 8) * sizeof(float);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(lr_stage_kernel, dim3((unsigned)(n[0] + n[1] + n[2])), dim3(512), lds, stream, k[0], k[1], k[2], (int)n[0],
+                     (int)n[1]);
+  err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
 }

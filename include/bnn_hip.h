@@ -257,6 +257,13 @@ typedef struct bnn_lr_fwd_args {
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
 int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
 
+/* bnn_lr_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer LR net (the LR
+ * counterpart of bnn_bbb_stage_fwd): the output layer of evaluation j, the hidden layer of evaluation j + 1 and the
+ * first layer of evaluation j + 2, any of them NULL, in ONE launch; the same results as bnn_lr_linear_fwd on each.
+ * The caller keeps the pieces independent (own activation and KL workspaces per evaluation in flight, static
+ * sample_offset).  Pieces whose tile plan the combined kernel is not built for run one after the other. */
+int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first, void* stream);
+
 /* bnn_lr_prepare — the eps-independent half of BayesianLinearLR.forward, once per ELBO
  * evaluation instead of once per MC sample (the reference recomputes it inside its sample loop,
  * networks.py:118-119, :134-136): sigma^2 = softplus(rho)^2, both GEMM operands rounded to bf16

@@ -907,11 +907,12 @@ def test_pipelined_evaluations_on_shapes_that_cannot_share_a_launch(dev, monkeyp
     assert torch.equal(got[True][2], got[False][2])
 
 
-@pytest.mark.parametrize("S", [1, 8])
+@pytest.mark.parametrize("S", [1, 2, 8])
 def test_lr_evaluations_with_the_cast_riding_on_the_previous_finalize(dev, monkeypatch, S):
-    """LR, several evaluations per graph launch: the input cast (and, from 8 samples, x^2) of evaluation j + 1 is done by
-    extra blocks of evaluation j's finalize launch (bnn_finalize_args.cast_*); every evaluation's 4-vector is bitwise
-    that of the plain sequence."""
+    """LR, several evaluations per graph launch: below 8 samples the three-deep pipeline (bnn_lr_stage_fwd: three
+    independent layers per launch, static sample offsets, slot buffers), from 8 samples the input cast and x^2 of
+    evaluation j + 1 done by extra blocks of evaluation j's finalize launch (bnn_finalize_args.cast_*); every
+    evaluation's 4-vector is bitwise that of the plain sequence."""
     from bnn_hip import engine
     bnn_hip.set_math("bf16")
     net, _ = build_net(dev, True, (784, 1200, 10), "classification")
@@ -924,6 +925,7 @@ def test_lr_evaluations_with_the_cast_riding_on_the_previous_finalize(dev, monke
         slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
         bnn_hip.manual_seed(47, counter=100)
         ev = engine.GraphedElbo(net, xd, yd, S, counter_stride=4, sums_ring=(slab.view(-1), ring_len, 4), evals_per_replay=E)
+        assert ev.lr_pipe3 == (pipe and S < 8)
         ev.x16.zero_()                                           # the riders (or the per-evaluation casts) must refill it
         slab.fill_(-7.0)
         for _ in range(reps):
