@@ -568,6 +568,21 @@ class GraphedElbo:
         """For measurement (bench.py's roofline): a closure that enqueues ONE steady-state launch of the three-deep
         pipeline -- output layer + finalize of the evaluation in slot 0, hidden layer of the one in slot 1, first layer
         of the one in slot 2 -- without advancing the sample counter or the sums ring."""
+        if self.lr_pipe3:
+            math_mode = state.math
+
+            def lcall(i, slot):
+                sp = self.specs[i]
+                p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+                h = self.x16 if i == 0 else self.slot_bufs[i - 1][slot]
+                out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
+                ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+                return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
+                                      relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
+                                      layer_id=sp.layer_id, sample_offset=self.lo, sample_counter=self.counter, want_kl=True,
+                                      workspace=ws, out=out, concurrency=self.stride)
+            last, mid, first = lcall(2, 0), lcall(1, 1), lcall(0, 2)
+            return lambda: ops.lr_stage_fwd(last=last, mid=mid, first=first)
         if not self.pipe3:
             raise ops.BnnHipError("steady_state_stage: this evaluator is not three-deep pipelined")
         math_mode = state.math

@@ -172,6 +172,23 @@ def layer2_roofline(ev, net, dims, batch, S_local, lr, math_name):
     import bnn_hip
     from bnn_hip import ops, _lib as L
     hid_b = 4 if math_name == "f32" else 2
+    if getattr(ev, "lr_pipe3", False):
+        launch = ev.steady_state_stage()
+        us = kernel_alone_us(launch, torch.cuda.current_stream())
+        abytes = S_local * (algorithmic_bytes_layer(dims[0], dims[1], batch, hid_b, hid_b) +
+                            algorithmic_bytes_layer(dims[1], dims[1], batch, hid_b, hid_b) +
+                            algorithmic_bytes_layer(dims[1], dims[2], batch, hid_b, 4))
+        achieved = abytes / (us * 1e-6) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "traffic_key": f"lr_S{S_local}_{math_name}_stage",
+                "kernel": "K3e lr_stage_kernel: one pipeline stage = all three LR layers of one evaluation "
+                          f"({dims[0]}x{dims[1]}, {dims[1]}x{dims[1]}, {dims[1]}x{dims[2]}; the finalize is a launch of its own)",
+                "algorithmic_bytes_per_launch": abytes, "mc_samples_per_launch": S_local, "avg_launch_us": us,
+                "note": "HIP events around back-to-back graph launches of this kernel, ALONE on its stream (incl. the "
+                        "dependent-launch boundary), with the tile plan of the timed region"
+                        + (f" (sized for 1/{ev.stride} of the chip because {ev.stride} evaluators run side by side there)"
+                           if ev.stride > 1 else "")
+                        + "; un-amortised 8 B/param/sample formula of SURVEY 8(d) summed over the three layers, bf16 activations"}
     if getattr(ev, "pipe3", False):
         # the timed region's launches are pipeline stages: one launch = one whole evaluation's work (first layer of
         # evaluation j+2, hidden layer of j+1, output layer + finalize of j)
