@@ -204,7 +204,8 @@ def load():
     lib.bnn_bbb_final_next_fwd.restype = C.c_int
     lib.bnn_bbb_final_next_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs), C.c_void_p]
     lib.bnn_lr_stage_fwd.restype = C.c_int
-    lib.bnn_lr_stage_fwd.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.c_void_p]
+    lib.bnn_lr_stage_fwd.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(FinalizeArgs),
+                                     C.c_void_p]
     lib.bnn_bbb_stage_fwd.restype = C.c_int
     lib.bnn_bbb_stage_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs),
                                       C.POINTER(BbbFwdArgs), C.c_void_p]

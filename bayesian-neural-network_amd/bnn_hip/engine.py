@@ -402,8 +402,10 @@ class GraphedElbo:
                          hid == torch.bfloat16 and self.x16 is not None and not self.lr_sq and
                          all(w is None for w in self.wfrag))
         if self.lr_pipe3:
-            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(2)]
-            self.slot_ws = [[self.ws[i]] + [ops.lr_workspace(self.specs[i].in_out[1], dev) for _ in range(2)] for i in range(2)]
+            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(3)]
+            self.slot_ws = [[self.ws[i]] + [ops.lr_workspace(self.specs[i].in_out[1], dev) for _ in range(2)] for i in range(3)]
+            self.x16_alt = torch.empty_like(self.x16)     # the cast of evaluation t + 1 rides beside the first layer of t
+            self._last_slot = 0
         self.graph = None
         self._enqueue()                      # warm-up (also validates arguments eagerly)
         take_samples(self.samples)
@@ -575,14 +577,19 @@ class GraphedElbo:
                 sp = self.specs[i]
                 p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
                 h = self.x16 if i == 0 else self.slot_bufs[i - 1][slot]
-                out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
-                ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+                out, ws = self.slot_bufs[i][slot], self.slot_ws[i][slot]
                 return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
                                       relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
                                       layer_id=sp.layer_id, sample_offset=self.lo, sample_counter=self.counter, want_kl=True,
                                       workspace=ws, out=out, concurrency=self.stride)
             last, mid, first = lcall(2, 0), lcall(1, 1), lcall(0, 2)
-            return lambda: ops.lr_stage_fwd(last=last, mid=mid, first=first)
+            sums = torch.zeros(4, dtype=torch.float32, device=self.x.device)
+            fin_kw = dict(workspaces=[self.slot_ws[i][1] for i in range(3)], logits=self.slot_bufs[2][1],
+                          layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                          local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
+                          mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter, sample_counter_inc=0,
+                          out=self.out, sums=sums, ticket=self.ticket, cast=(self.x, self.x16_alt, None))
+            return lambda: ops.lr_stage_fwd(last=last, mid=mid, first=first, fin_kw=fin_kw)
         if not self.pipe3:
             raise ops.BnnHipError("steady_state_stage: this evaluator is not three-deep pipelined")
         math_mode = state.math
@@ -609,41 +616,45 @@ class GraphedElbo:
         return lambda: ops.bbb_stage_fwd(final=(al, kl, fin_kw), mid=mid, first=first)
 
     def _enqueue_lr_pipelined(self):
-        """LR: stage t = {output layer of evaluation t-2, hidden layer of t-1, first layer of t} in one launch, then the
-        finalize of evaluation t-2 (carrying the input cast of evaluation t+1 when there is one)."""
+        """LR: launch t = {output layer of evaluation t-2, hidden layer of t-1, first layer of t, finalize of t-3, input
+        cast of t+1} (bnn_lr_stage_fwd): E + 3 launches for E evaluations, one per evaluation in steady state.  Evaluation
+        j lives in buffer slot j % 3, its bf16 input in x16 buffer j % 2."""
         E = self.per_replay
         inc = self.samples * self.stride
         math_mode = state.math
+        x16 = (self.x16, self.x16_alt)
 
         def layer_call(i, j):
             sp = self.specs[i]
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             slot = j % 3
-            h = self.x16 if i == 0 else self.slot_bufs[i - 1][slot]
-            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
-            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
+            h = x16[j % 2] if i == 0 else self.slot_bufs[i - 1][slot]
             return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
-                                  relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
+                                  relu=sp.relu, y_dtype=self.slot_bufs[i][slot].dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
                                   layer_id=sp.layer_id, sample_offset=self.lo + j * inc, sample_counter=self.counter,
-                                  want_kl=True, workspace=ws, out=out, concurrency=self.stride)
+                                  want_kl=True, workspace=self.slot_ws[i][slot], out=self.slot_bufs[i][slot],
+                                  concurrency=self.stride)
 
-        cast = lambda: ops.cast_bf16(self.x, out=self.x16)
-        cast()                                                # evaluation 0 (the same batch for every evaluation of the replay:
-        for t in range(E + 2):                                # later casts rewrite x16 with the same bytes, off the chain)
+        def fin_call(j, t):
+            slot = j % 3
+            rider = (self.x, x16[(t + 1) % 2], None) if t + 1 < E else None
+            return dict(workspaces=[self.slot_ws[i][slot] for i in range(3)], logits=self.slot_bufs[2][slot],
+                        layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
+                        local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
+                        mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
+                        sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums, ticket=self.ticket,
+                        sums_ring=self.ring, cast=rider)
+
+        ops.cast_bf16(self.x, out=x16[0])                     # evaluation 0
+        for t in range(E + 3):
+            j = t - 3
+            fin_kw = fin_call(j, t) if 0 <= j < E else None
+            if fin_kw is None and t + 1 < E:                  # no finalize to carry the next cast yet
+                ops.cast_bf16(self.x, out=x16[(t + 1) % 2])
             ops.lr_stage_fwd(last=layer_call(2, t - 2) if 0 <= t - 2 < E else None,
                              mid=layer_call(1, t - 1) if 0 <= t - 1 < E else None,
-                             first=layer_call(0, t) if t < E else None)
-            j = t - 2
-            if 0 <= j < E:
-                rider = (self.x, self.x16, None) if t + 1 < E else None
-                ops.elbo_finalize(workspaces=[self.slot_ws[0][j % 3], self.slot_ws[1][j % 3], self.ws[2]], logits=self.bufs[2],
-                                  layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                                  local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
-                                  target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                                  sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
-                                  ticket=self.ticket, sums_ring=self.ring, cast=rider)
-            elif t + 1 < E:
-                cast()                                        # no finalize to ride on yet
+                             first=layer_call(0, t) if t < E else None, fin_kw=fin_kw)
+        self._last_slot = (E - 1) % 3
 
     def _eager(self):
         if self.pipelined:
@@ -669,4 +680,6 @@ class GraphedElbo:
 
     @property
     def logits(self) -> torch.Tensor:
+        if getattr(self, "lr_pipe3", False):               # of the last evaluation of a replay
+            return self.slot_bufs[2][self._last_slot]
         return self.bufs[-1]

@@ -316,13 +316,15 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
     return res
 
 
-def lr_stage_fwd(last=None, mid=None, first=None):
+def lr_stage_fwd(last=None, mid=None, first=None, fin_kw=None):
     """bnn_lr_stage_fwd: `last` / `mid` / `first` = (args, kw) as for lr_linear_fwd (any may be None): the output layer
-    of one evaluation, the hidden layer of the next and the first layer of the one after, independent, in one launch."""
+    of one evaluation, the hidden layer of the next and the first layer of the one after, independent, in one launch;
+    `fin_kw`: the elbo_finalize keywords (with its `cast` rider) of a still earlier evaluation, riding along."""
     lib = L.load()
     built = [(_lr_build(*c[0], **c[1]) if c is not None else None) for c in (last, mid, first)]
+    f = _fin_build(**fin_kw) if fin_kw is not None else None
     ref = lambda t_: C.byref(t_[0]) if t_ is not None else None
-    L.check(lib.bnn_lr_stage_fwd(ref(built[0]), ref(built[1]), ref(built[2]), _stream()), "bnn_lr_stage_fwd")
+    L.check(lib.bnn_lr_stage_fwd(ref(built[0]), ref(built[1]), ref(built[2]), ref(f), _stream()), "bnn_lr_stage_fwd")
     return [t_[1] if t_ is not None else None for t_ in built]
 
 

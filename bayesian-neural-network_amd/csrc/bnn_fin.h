@@ -300,4 +300,37 @@ __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b
   if (p.nll) p.nll[s] = nll;
 }
 
+// The one-block form of K4 as a device function (a pipeline-stage kernel runs it beside the layers of later
+// evaluations): walks all samples, stores the per-sample scalars, then the 4-vector of sums, and advances the counter.
+// `part`: LDS scratch as for fin_sample.
+__device__ __forceinline__ void fin_single_block(const FinK& p, const FinC& cst, float* sums, float* part) {
+  int T[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l)
+    T[l] = (l < p.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(p.ws[l])[0].x) : 0;
+  double tot_a = 0, tot_b = 0, tot_n = 0;
+  for (int s = 0; s < p.S; ++s) {
+    float a = 0.f, b = 0.f, nll = 0.f;
+    const float* lg = p.logits ? p.logits + (size_t)s * p.B * p.C : nullptr;
+    fin_sample(p, cst, s, T, lg, p.C, -1, 0.f, 0.f, 0.f, part, a, b, nll);
+    if (threadIdx.x == 0) {
+      fin_store(p, s, a, b, nll);
+      tot_a += a;
+      tot_b += b;
+      tot_n += nll;
+    }
+    if (s + 1 < p.S) __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (sums) {
+      float* so = fin_sums_slot(p, sums);
+      so[0] = (float)tot_a;
+      so[1] = (float)tot_b;
+      so[2] = (float)tot_n;
+      so[3] = (float)p.S;
+    }
+    if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
+  }
+}
+
 }  // namespace bnn

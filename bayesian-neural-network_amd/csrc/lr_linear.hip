@@ -21,7 +21,9 @@
 //     of one batch row = one Philox call).
 // The mean and variance slabs go through the same LDS region one after the other.
 #include "bnn_device.h"
+#include "bnn_fin.h"
 #include "../../include/bnn_hip.h"
+#include <string.h>
 
 namespace bnn {
 
@@ -413,11 +415,29 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
 // layer of evaluation j (R = 4 feature classes, 32-row blocks), the hidden layer of evaluation j + 1 and the first
 // layer of evaluation j + 2 (whole 16-feature tiles, 128-row blocks) as three block ranges of ONE grid of 8-wave
 // blocks.  Independent pieces: the caller keeps their buffers apart and gives each a static sample offset.
-__global__ __launch_bounds__(512) void lr_stage_kernel(const LrK p2, const LrK p1, const LrK p0, int n2, int n1) {
+// Two more independent pieces may ride: the finalize of evaluation j - 1 (one block: K4's one-block form) and the input
+// cast of evaluation j + 3 -- then an LR evaluation is ONE launch in steady state.
+struct LrStageExtra {
+  FinK fk;
+  FinC fc;
+  float* sums;
+  CastJob cj;
+  int nfin;     // 0 or 1
+};
+
+__global__ __launch_bounds__(512) void lr_stage_kernel(const LrK p2, const LrK p1, const LrK p0, int n2, int n1, int n0,
+                                                       const LrStageExtra ex) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = (int)blockIdx.x;
   if (b < n2) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 4, 2>(p2, b);
   else if (b < n2 + n1) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p1, b - n2);
-  else lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p0, b - n2 - n1);
+  else if (b < n2 + n1 + n0) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p0, b - n2 - n1);
+  else if (b < n2 + n1 + n0 + ex.nfin) fin_single_block(ex.fk, ex.fc, ex.sums, lds);
+  else {
+    const int first = n2 + n1 + n0 + ex.nfin;
+    cast_bf16_span(ex.cj.src, ex.cj.dst, ex.cj.dsq, ex.cj.n, ex.cj.vec_ok, (long)(b - first) * blockDim.x + threadIdx.x,
+                   (long)((int)gridDim.x - first) * blockDim.x);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -989,21 +1009,23 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   return BNN_OK;
 }
 
-// One stage of the evaluation pipeline (see include/bnn_hip.h): the three independent layers in one launch when they
-// take the tile plans lr_stage_kernel is built for, one after the other otherwise.
+// One stage of the evaluation pipeline (see include/bnn_hip.h): the independent pieces in one launch when they take the
+// tile plans lr_stage_kernel is built for, one after the other otherwise.
+extern "C" int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
+
 extern "C" int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first,
-                                void* stream_) {
+                                const bnn_finalize_args* fin, void* stream_) {
   const bnn_lr_fwd_args* parts[3] = {last, mid, first};
-  if (!last && !mid && !first) return BNN_ERR_NULL;
-  auto sequential = [&]() {
+  if (!last && !mid && !first && !fin) return BNN_ERR_NULL;
+  auto sequential = [&](bool with_fin) {
     for (int i = 0; i < 3; ++i)
       if (parts[i]) {
         const int rc = bnn_lr_linear_fwd(parts[i], stream_);
         if (rc != BNN_OK) return rc;
       }
-    return (int)BNN_OK;
+    return (with_fin && fin) ? bnn_elbo_finalize(fin, stream_) : (int)BNN_OK;
   };
-  if (lr_env_int("BNN_HIP_LR_STAGE", 1) == 0) return sequential();
+  if (lr_env_int("BNN_HIP_LR_STAGE", 1) == 0) return sequential(true);
   LrK k[3];
   long n[3] = {0, 0, 0};
   int present = 0;
@@ -1017,10 +1039,37 @@ extern "C" int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_ar
     const bool shape_ok = i == 0 ? (pl.R == 4 && pl.MT == 2) : (pl.R == 1 && pl.MT == 8);
     if (pl.gemm || !shape_ok || pl.nw > 8 || a->math != BNN_MATH_BF16 || a->x_dtype != BNN_BF16 || a->kl_out ||
         (a->in_features & 7))
-      return sequential();
+      return sequential(true);
     n[i] = pl.total;
   }
-  if (present < 2) return sequential();
+  if (present == 0) return bnn_elbo_finalize(fin, stream_);
+  LrStageExtra ex;
+  memset(&ex, 0, sizeof(ex));
+  bool fin_in = false;
+  int ncast = 0;
+  if (fin) {
+    // the one-block finalize (one sample per evaluation) and its cast rider join the launch
+    const int rc = make_fin(fin, ex.fk, ex.fc);
+    if (rc != BNN_OK) return rc;
+    fin_in = fin->n_samples == 1 && lr_env_int("BNN_HIP_LR_STAGE_FIN", 1) != 0;
+    if (fin_in) {
+      ex.sums = fin->sums;
+      ex.nfin = 1;
+      if (fin->cast_n > 0) {
+        if (!fin->cast_src || !fin->cast_dst) return BNN_ERR_NULL;
+        if ((reinterpret_cast<uintptr_t>(fin->cast_src) & 3) || (reinterpret_cast<uintptr_t>(fin->cast_dst) & 1)) return BNN_ERR_ALIGN;
+        ex.cj.src = fin->cast_src;
+        ex.cj.dst = reinterpret_cast<__bf16*>(fin->cast_dst);
+        ex.cj.dsq = reinterpret_cast<__bf16*>(fin->cast_dst_sq);
+        ex.cj.n = (long)fin->cast_n;
+        ex.cj.vec_ok = !((reinterpret_cast<uintptr_t>(fin->cast_src) | reinterpret_cast<uintptr_t>(fin->cast_dst) |
+                          reinterpret_cast<uintptr_t>(fin->cast_dst_sq)) & 15);
+        long nb = (ex.cj.n / 8 + 511) / 512;
+        ncast = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+      }
+    }
+  }
+  if (present < 2 && !fin_in) return sequential(true);
   for (int i = 0; i < 3; ++i)
     if (!parts[i]) k[i] = k[parts[0] ? 0 : (parts[1] ? 1 : 2)];            // placeholder, its block range is empty
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -1028,8 +1077,9 @@ extern "C" int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_ar
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
   if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(lr_stage_kernel, dim3((unsigned)(n[0] + n[1] + n[2])), dim3(512), lds, stream, k[0], k[1], k[2], (int)n[0],
-                     (int)n[1]);
+  hipLaunchKernelGGL(lr_stage_kernel, dim3((unsigned)(n[0] + n[1] + n[2] + ex.nfin + ncast)), dim3(512), lds, stream, k[0], k[1],
+                     k[2], (int)n[0], (int)n[1], (int)n[2], ex);
   err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
+  if (err != hipSuccess) return (int)err;
+  return (fin && !fin_in) ? bnn_elbo_finalize(fin, stream_) : (int)BNN_OK;
 }

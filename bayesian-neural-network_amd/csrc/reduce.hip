@@ -97,49 +97,10 @@ static inline int kl_blocks(long n) {
 }
 
 // ----------------------------------------------------------------------------- K4
-// fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
-// the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
-__device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,
-                                               __bf16* __restrict__ dsq, long n, int vec_ok, long tid, long nt) {
-  if (vec_ok) {
-    const long n8 = n >> 3;
-    for (long i = tid; i < n8; i += nt) {
-      const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      bf16x8 v, q;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = (__bf16)f[j];
-        q[j] = (__bf16)(f[j] * f[j]);
-      }
-      reinterpret_cast<bf16x8*>(dst)[i] = v;
-      if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
-    }
-    for (long i = (n8 << 3) + tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
-    }
-  } else {
-    for (long i = tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
-    }
-  }
-}
-
 __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, __bf16* __restrict__ dsq,
                                  long n, int vec_ok) {
   cast_bf16_span(src, dst, dsq, n, vec_ok, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
-
-// An independent cast that rides on a finalize launch (blocks >= nfin): the NEXT evaluation's input batch.
-struct CastJob {
-  const float* src;
-  __bf16* dst;
-  __bf16* dsq;
-  long n;
-  int vec_ok;
-};
 
 // grid = n_samples blocks (one sample each), or ONE block looping over all samples when `single`: then the
 // block also writes the 4-vector of sums, in sample order.  With a `ticket` word the one-block-per-sample form

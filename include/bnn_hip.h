@@ -257,12 +257,6 @@ typedef struct bnn_lr_fwd_args {
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
 int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
 
-/* bnn_lr_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer LR net (the LR
- * counterpart of bnn_bbb_stage_fwd): the output layer of evaluation j, the hidden layer of evaluation j + 1 and the
- * first layer of evaluation j + 2, any of them NULL, in ONE launch; the same results as bnn_lr_linear_fwd on each.
- * The caller keeps the pieces independent (own activation and KL workspaces per evaluation in flight, static
- * sample_offset).  Pieces whose tile plan the combined kernel is not built for run one after the other. */
-int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first, void* stream);
 
 /* bnn_lr_prepare — the eps-independent half of BayesianLinearLR.forward, once per ELBO
  * evaluation instead of once per MC sample (the reference recomputes it inside its sample loop,
@@ -373,6 +367,16 @@ int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_arg
  * output layer wider than 16 ...) are launched one after the other. */
 int bnn_bbb_stage_fwd(const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* mid,
                       const bnn_bbb_fwd_args* first, void* stream);
+
+/* bnn_lr_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer LR net (the LR
+ * counterpart of bnn_bbb_stage_fwd): the output layer of evaluation j, the hidden layer of evaluation j + 1 and the
+ * first layer of evaluation j + 2, any of them NULL, in ONE launch; the same results as bnn_lr_linear_fwd on each.
+ * The caller keeps the pieces independent (own activation and KL workspaces per evaluation in flight, static
+ * sample_offset).  `fin` (optional): the finalize of a still earlier evaluation, bnn_elbo_finalize(fin) with its cast
+ * rider; with one sample per evaluation it joins the launch as two more independent pieces.  Pieces whose tile plan
+ * the combined kernel is not built for run one after the other. */
+int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first,
+                     const bnn_finalize_args* fin, void* stream);
 
 /* bnn_bbb_tail2_fwd — the last HIDDEN layer, the output layer and the finalize of a ONE-sample evaluation in one
  * launch: the same results as bnn_bbb_linear_fwd(hidden) followed by bnn_bbb_final_fwd(last, fin) with
