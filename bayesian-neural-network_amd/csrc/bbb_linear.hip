@@ -700,11 +700,22 @@ __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const 
 // (blocks [nf, nf + nm), bf16 x, the first layer's tile plan), so that in steady state an evaluation is ONE launch.
 template <int XDT1, int R1>
 __global__ __launch_bounds__(768) void bbb_fwd_final_next_kernel(const BbbK p3, const FinPack fp, const BbbK pm, const BbbK p1,
-                                                                 int nf, int nm) {
+                                                                 int nf, int nm, int n1, int plain) {
+  // the two plain layers' block ranges start on, and are padded to, a multiple of 8 blocks, so the XCD-aware work order
+  // of the stand-alone launch can hold inside each (`plain` = 0).  Measured for this kernel it does not pay: the stage
+  // alone 14.8 against 15.4 us, but four evaluators side by side 105.8 k against 106.8 k samples/s on the same box
+  // ([out,in] weights are read along their rows: no line is shared between tiles) -- block order is the default here;
+  // the LR stage, whose tiles share the lines of gathered [in,out] weights, keeps the XCD order.
   const int b = (int)blockIdx.x;
-  if (b < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, b);
-  else if (b < nf + nm) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, R1, true, false>(pm, nullptr, b - nf);
-  else bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, b - nf - nm);
+  const int ef = (nf + 7) & ~7, em = ef + ((nm + 7) & ~7);
+  int item;
+  if (b < ef) {
+    if (b < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, b);
+  } else if (b < em) {
+    if (xcd_piece_item(b - ef, nm, item, plain)) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, R1, true, false>(pm, nullptr, item);
+  } else {
+    if (xcd_piece_item(b - em, n1, item, plain)) bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, item);
+  }
 }
 
 // K1d  one-sample tail of an evaluation in ONE launch: the last hidden layer (K1a, any tile plan) and, run by
@@ -1377,12 +1388,12 @@ static int stage_pair(const bnn_bbb_fwd_args* mid, const bnn_bbb_fwd_args* next,
   const int nwc = plm.nw > pl1.nw ? plm.nw : pl1.nw;
   const long totm = (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128);
   const long tot1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
-  const dim3 grid((unsigned)(totm + tot1)), block(nwc * 64);
+  const dim3 grid((unsigned)(((totm + 7) & ~7L) + ((tot1 + 7) & ~7L))), block(nwc * 64);
   const size_t lds = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc) * sizeof(float);
   FinPack fp;
   memset(&fp, 0, sizeof(fp));
   hipError_t err = hipSuccess;
-  BNN_STAGE_LAUNCH(next, pl1.R, grid, block, lds, km, fp, km, k1, 0, (int)totm);
+  BNN_STAGE_LAUNCH(next, pl1.R, grid, block, lds, km, fp, km, k1, 0, (int)totm, (int)tot1, env_int("BNN_HIP_STAGE_PLAIN_ORDER", 1));
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
@@ -1483,10 +1494,11 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
         if (mid_in && plm.nw > nwc) nwc = plm.nw;
         const long total1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
         const long totalm = mid_in ? (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128) : 0;
-        const dim3 gridc((unsigned)(total + totalm + total1)), blockc(nwc * 64);
+        const dim3 gridc((unsigned)(((total + 7) & ~7L) + ((totalm + 7) & ~7L) + ((total1 + 7) & ~7L))), blockc(nwc * 64);
         const size_t ldsc = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
         if (!mid_in) km = k1;
-        BNN_STAGE_LAUNCH(next, pl1.R, gridc, blockc, ldsc, k, fp, km, k1, (int)total, (int)totalm);
+        BNN_STAGE_LAUNCH(next, pl1.R, gridc, blockc, ldsc, k, fp, km, k1, (int)total, (int)totalm, (int)total1,
+                         env_int("BNN_HIP_STAGE_PLAIN_ORDER", 1));
         if (err != hipSuccess) return (int)err;
         err = hipGetLastError();
         if (err != hipSuccess) return (int)err;
