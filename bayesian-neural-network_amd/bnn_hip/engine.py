@@ -385,7 +385,7 @@ class GraphedElbo:
         # software pipeline over the evaluations of one graph launch (see PIPELINE_EVALS): the first layer's statistics
         # workspace alternates, every evaluation has its own static sample offset and only the last finalize of a
         # replay advances the device counter, so an evaluation's first layer depends on nothing its predecessor writes
-        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S == 1 and
+        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S <= 4 and
                           hid == torch.bfloat16 and nl >= 2 and self.specs[-1].in_out[1] <= 16 and B <= 128 and
                           self.split[0] is None and self.wsigma[0] is None and self.x16 is None)
         self.ws0_alt = ops.bbb_workspace(S, self.specs[0].in_out[1], dev) if self.pipelined else None

@@ -839,9 +839,10 @@ def test_presampled_evaluation_equals_the_fused_evaluation(dev, monkeypatch, sam
     assert not torch.equal(ra[0][0], ra[1][0])
 
 
+@pytest.mark.parametrize("S", [1, 3])
 @pytest.mark.parametrize("depth3", [True, False])
 @pytest.mark.parametrize("stride", [1, 4])
-def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, depth3):
+def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, depth3, S):
     """E one-sample evaluations per graph launch with the output layer + finalize of evaluation j sharing a launch
     with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd): every evaluation's 4-vector is the one the
     plain sequence gives for the same global sample indices -- bitwise, the kernels and their summation order are the
@@ -859,7 +860,7 @@ def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, dep
         monkeypatch.setattr(engine, "PIPELINE_DEPTH3", depth3)
         slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
         bnn_hip.manual_seed(41, counter=700)
-        ev = engine.GraphedElbo(net, xd, yd, 1, counter_stride=stride, sums_ring=(slab.view(-1), ring_len, 4),
+        ev = engine.GraphedElbo(net, xd, yd, S, counter_stride=stride, sums_ring=(slab.view(-1), ring_len, 4),
                                 evals_per_replay=E)
         assert ev.pipelined == pipe and (not pipe or ev.pipe3 == depth3)
         slab.fill_(-7.0)
@@ -869,7 +870,7 @@ def test_pipelined_evaluations_equal_one_at_a_time(dev, monkeypatch, stride, dep
         got[pipe] = (slab.clone(), int(ev.counter.item()), ev.logits.clone(), {k: v.clone() for k, v in ev.out.items()})
     (sa, ca, la, oa), (sb, cb, lb, ob) = got[True], got[False]
     assert ca == cb
-    assert torch.equal(sa[:E * reps], sb[:E * reps]) and bool((sa[:E * reps, 0, 3] == 1.0).all())
+    assert torch.equal(sa[:E * reps], sb[:E * reps]) and bool((sa[:E * reps, 0, 3] == float(S)).all())
     assert len({tuple(float(v) for v in row[0, :3]) for row in sa[:E * reps]}) == E * reps   # every evaluation drew its own eps
     assert torch.equal(la, lb)
     for k in oa:
