@@ -60,10 +60,12 @@ def n_stochastic(dims):
     return sum(i * o + o for i, o in ((dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])))
 
 
-def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
+def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16, tail=None):
     """W untimed + K timed steps (a step = ONE ELBO evaluation) bracketed by barrier + synchronize;
     returns seconds (max over ranks).  An evaluator replay runs `evs[0].per_replay` consecutive
     evaluations (one hipGraph launch): steps and warmup must be multiples of it.
+    `tail` = (evaluator with per_replay = r, its [r, 1, 4] slab or None): r more timed evaluations after the
+    replays, so that ANY K is timed exactly whatever the evaluations per graph launch are.
 
     Multi-GPU: every evaluation's 4 ELBO scalars are sum-all-reduced over RCCL.  The evaluators'
     graphs deposit them in consecutive rows of `slab` [2*ar_every, n_evaluators, 4] (device-side
@@ -125,6 +127,12 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16):
     t0 = time.perf_counter()
     for i in range(ns):
         replay(nw + i)
+    if tail is not None:
+        tail[0].replay()
+        if dist is not None and tail[1] is not None:    # its rows get their own collective
+            if tail[0].stream is not None:
+                main.wait_stream(tail[0].stream)
+            dist.all_reduce(tail[1], op=dist.ReduceOp.SUM)
     barrier(nw + ns)
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -357,12 +365,27 @@ def main():
     S_local, S_global = args.samples, args.samples * world
     nstr = max(1, args.streams)
     ar_every = max(1, args.allreduce_every)
-    per_replay = math.gcd(max(1, args.evals_per_graph), args.steps, args.warmup or args.steps,
-                          *((ar_every,) if dist is not None else ()))
+    # evaluations per graph launch: as asked (a divisor of the all-reduce period in the N>1 path); any K is then timed
+    # exactly as K // E replays plus ONE more graph launch holding the K % E remaining evaluations, and the warm-up is
+    # rounded up to whole replays (the evaluator pipelines the evaluations of a launch: E = 1 would forgo that)
+    per_replay = max(1, args.evals_per_graph)
+    if dist is not None:
+        per_replay = math.gcd(per_replay, ar_every)
+    while per_replay > 1 and per_replay > args.steps:
+        per_replay //= 2
+    main_steps = args.steps // per_replay * per_replay
+    tail_steps = args.steps - main_steps
+    warmup_run = (args.warmup + per_replay - 1) // per_replay * per_replay
     slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
     evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay,
                           streams=pre_streams[:nstr] if nstr > 1 else None)
     assert evs[0].n_local == S_local
+    tail = None
+    if tail_steps:
+        tslab = torch.zeros((tail_steps, 1, 4), dtype=torch.float32, device=dev) if dist is not None else None
+        tev = make_evaluators(engine, net, x, y, S_global, 1, graph=not args.no_graph, slab=tslab, per_replay=tail_steps,
+                              streams=[pre_streams[0]] if nstr > 1 else None)[0]
+        tail = (tev, tslab)
     if args.roofline_only:
         torch.cuda.synchronize()
         roof = layer2_roofline(evs[0], net, dims, args.batch, S_local, lr, args.math)
@@ -375,7 +398,7 @@ def main():
     # call starts counting its flushes from 0)
     lap = 2 * ar_every * nstr
     run_steps(evs, 0, prewarm if dist is None else (prewarm + lap - 1) // lap * lap, dist, slab, ar_every)
-    dt = run_steps(evs, args.steps, args.warmup, dist, slab, ar_every)
+    dt = run_steps(evs, main_steps, warmup_run, dist, slab, ar_every, tail=tail)
     if dist is not None and run_steps.last_flushed_half is not None:
         # every all-reduced row carries the GLOBAL sample count in its 4th word
         h = run_steps.last_flushed_half
@@ -389,6 +412,7 @@ def main():
         "metric": "MC-forward-samples/sec + KL-elements/sec, 784-1200-1200-10 BNN" if args.net == "mnist"
         else f"MC-forward-samples/sec + KL-elements/sec, {layers} BNN",
         "value": value, "unit": "MC-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "warmup_executed": warmup_run,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
         **({"rehearsal": "all ranks on cuda:0 over gloo; NOT a measurement"} if rehearsal else {}),
