@@ -369,8 +369,13 @@ def main():
     # exactly as K // E replays plus ONE more graph launch holding the K % E remaining evaluations, and the warm-up is
     # rounded up to whole replays (the evaluator pipelines the evaluations of a launch: E = 1 would forgo that)
     per_replay = max(1, args.evals_per_graph)
+    if args.steps < 4 * per_replay * nstr:
+        # a short timed region: one launch per evaluator (up to 8 evaluations each) instead of a few launches on some
+        # evaluators and none on others -- K = 20 on four evaluators is 4 launches of 5, not 5 launches of 4
+        per_replay = min(8, max(1, -(-args.steps // nstr)))
     if dist is not None:
-        per_replay = math.gcd(per_replay, ar_every)
+        while per_replay > 1 and ar_every % per_replay:
+            per_replay -= 1
     while per_replay > 1 and per_replay > args.steps:
         per_replay //= 2
     main_steps = args.steps // per_replay * per_replay
