@@ -447,6 +447,12 @@ def main():
                     roof["traffic_source"] = t[key].get("source", "profiles/traffic.json")
             except Exception:
                 pass
+        if roof.get("mc_samples_per_launch"):
+            # context, not the roofline figure: the same algorithmic bytes at the rate of the whole timed region (all
+            # evaluators side by side), where the kernel above shares the chip with its peers
+            evals_per_s = value / S_global
+            roof["timed_region_aggregate_GBps"] = roof["algorithmic_bytes_per_launch"] * evals_per_s / 1e9 \
+                if "one pipeline stage" in roof.get("kernel", "") else None
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, lr, args.batch)
