@@ -143,6 +143,25 @@ def run_steps(evs, steps, warmup, dist, slab=None, ar_every=16, tail=None):
     return dt
 
 
+def plan_steps(steps, warmup, evals_per_graph, nstr, ar_every=None):
+    """(evaluations per graph launch E, steps run as whole launches, remaining steps, warm-up run).
+    E is what was asked for (N>1: a divisor of the all-reduce period `ar_every`); any K is then timed exactly as K // E
+    launches round-robin over the evaluators plus ONE more launch holding the K % E remaining evaluations, and the
+    warm-up is rounded up to whole launches (the evaluator pipelines the evaluations of a launch: E = 1 would forgo
+    that).  A short timed region takes one launch per evaluator (up to 8 evaluations each) instead of a few launches on
+    some evaluators and none on others: K = 20 on four evaluators is 4 launches of 5, not 5 launches of 4."""
+    per_replay = max(1, evals_per_graph)
+    if steps < 4 * per_replay * nstr:
+        per_replay = min(8, max(1, -(-steps // nstr)))
+    if ar_every is not None:
+        while per_replay > 1 and ar_every % per_replay:
+            per_replay -= 1
+    while per_replay > 1 and per_replay > steps:
+        per_replay //= 2
+    main_steps = steps // per_replay * per_replay
+    return per_replay, main_steps, steps - main_steps, (warmup + per_replay - 1) // per_replay * per_replay
+
+
 def make_evaluators(engine, net, x, y, S_global, nstr, graph=True, slab=None, per_replay=1, streams=None):
     if streams is None:
         streams = [torch.cuda.Stream() for _ in range(nstr)] if nstr > 1 else [None]
@@ -365,22 +384,8 @@ def main():
     S_local, S_global = args.samples, args.samples * world
     nstr = max(1, args.streams)
     ar_every = max(1, args.allreduce_every)
-    # evaluations per graph launch: as asked (a divisor of the all-reduce period in the N>1 path); any K is then timed
-    # exactly as K // E replays plus ONE more graph launch holding the K % E remaining evaluations, and the warm-up is
-    # rounded up to whole replays (the evaluator pipelines the evaluations of a launch: E = 1 would forgo that)
-    per_replay = max(1, args.evals_per_graph)
-    if args.steps < 4 * per_replay * nstr:
-        # a short timed region: one launch per evaluator (up to 8 evaluations each) instead of a few launches on some
-        # evaluators and none on others -- K = 20 on four evaluators is 4 launches of 5, not 5 launches of 4
-        per_replay = min(8, max(1, -(-args.steps // nstr)))
-    if dist is not None:
-        while per_replay > 1 and ar_every % per_replay:
-            per_replay -= 1
-    while per_replay > 1 and per_replay > args.steps:
-        per_replay //= 2
-    main_steps = args.steps // per_replay * per_replay
-    tail_steps = args.steps - main_steps
-    warmup_run = (args.warmup + per_replay - 1) // per_replay * per_replay
+    per_replay, main_steps, tail_steps, warmup_run = plan_steps(args.steps, args.warmup, args.evals_per_graph, nstr,
+                                                                ar_every if dist is not None else None)
     slab = torch.zeros((2 * ar_every, nstr, 4), dtype=torch.float32, device=dev) if dist is not None else None
     evs = make_evaluators(engine, net, x, y, S_global, nstr, graph=not args.no_graph, slab=slab, per_replay=per_replay,
                           streams=pre_streams[:nstr] if nstr > 1 else None)

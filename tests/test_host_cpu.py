@@ -244,3 +244,18 @@ def test_bench_ring_allreduce_bookkeeping_two_ranks(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o
+
+
+def test_bench_times_any_step_count_exactly():
+    """bench.plan_steps: whole graph launches plus one tail launch always add up to the K the caller asked for, the
+    warm-up is never shorter than asked, E divides the all-reduce period in the N>1 path."""
+    import bench
+    for steps in (1, 2, 3, 5, 7, 20, 50, 97, 100, 1001, 3000):
+        for warmup in (0, 1, 5, 33, 300):
+            for nstr in (1, 3, 4):
+                for ar in (None, 16, 64):
+                    E, main, tail, wrun = bench.plan_steps(steps, warmup, 4, nstr, ar)
+                    assert E >= 1 and main % E == 0 and 0 <= tail < E and main + tail == steps
+                    assert wrun >= warmup and wrun % E == 0 and wrun - warmup < E
+                    assert ar is None or ar % E == 0
+    assert bench.plan_steps(3000, 300, 4, 4)[0] == 4 and bench.plan_steps(20, 5, 4, 4)[0] == 5
