@@ -42,6 +42,7 @@ PRESAMPLE_MAX_SAMPLES = int(os.environ.get("BNN_HIP_PRESAMPLE", "0"))
 # is a few latency-bound blocks that otherwise hold the stream's chain of dependent launches for ~10 us.
 PIPELINE_EVALS = os.environ.get("BNN_HIP_PIPELINE_EVALS", "1") != "0"
 PIPELINE_DEPTH3 = os.environ.get("BNN_HIP_PIPELINE_DEPTH", "3") != "2"
+PIPE_MAX_S = 3            # BBB evaluations of up to this many MC samples are pipelined (2: +11 %, 3: +2 %, 4: -1 %, 8: -24 %)
 
 
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
@@ -385,7 +386,7 @@ class GraphedElbo:
         # software pipeline over the evaluations of one graph launch (see PIPELINE_EVALS): the first layer's statistics
         # workspace alternates, every evaluation has its own static sample offset and only the last finalize of a
         # replay advances the device counter, so an evaluation's first layer depends on nothing its predecessor writes
-        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S <= 4 and
+        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S <= PIPE_MAX_S and
                           hid == torch.bfloat16 and nl >= 2 and self.specs[-1].in_out[1] <= 16 and B <= 128 and
                           self.split[0] is None and self.wsigma[0] is None and self.x16 is None)
         self.ws0_alt = ops.bbb_workspace(S, self.specs[0].in_out[1], dev) if self.pipelined else None
