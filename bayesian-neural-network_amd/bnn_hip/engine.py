@@ -399,7 +399,9 @@ class GraphedElbo:
                             for i in range(2)]
         # LR, three layers: the same three-deep pipeline (bnn_lr_stage_fwd); the finalize stays a launch of its own and
         # carries the input cast of a later evaluation
-        self.lr_pipe3 = (PIPELINE_EVALS and PIPELINE_DEPTH3 and self.lr and self.per_replay > 1 and nl == 3 and
+        # (one sample per evaluation only: from two samples on the stage cannot carry the finalize and measured 3-6 % slower
+        # than one launch per layer with the cast riding on the finalize)
+        self.lr_pipe3 = (PIPELINE_EVALS and PIPELINE_DEPTH3 and self.lr and self.per_replay > 1 and nl == 3 and S == 1 and
                          hid == torch.bfloat16 and self.x16 is not None and not self.lr_sq and
                          all(w is None for w in self.wfrag))
         if self.lr_pipe3:

@@ -926,7 +926,7 @@ def test_lr_evaluations_with_the_cast_riding_on_the_previous_finalize(dev, monke
         slab = torch.full((ring_len, 1, 4), -7.0, dtype=torch.float32, device=dev)
         bnn_hip.manual_seed(47, counter=100)
         ev = engine.GraphedElbo(net, xd, yd, S, counter_stride=4, sums_ring=(slab.view(-1), ring_len, 4), evals_per_replay=E)
-        assert ev.lr_pipe3 == (pipe and S < 8)
+        assert ev.lr_pipe3 == (pipe and S == 1)
         ev.x16.zero_()                                           # the riders (or the per-evaluation casts) must refill it
         slab.fill_(-7.0)
         for _ in range(reps):
