@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1
@@ -15,15 +15,16 @@ MATH_F32, MATH_BF16 = 0, 1
 EPS_PHILOX, EPS_MEMORY, EPS_ZERO = 0, 1, 2
 PRIOR_GAUSS, PRIOR_MIXTURE = 0, 1
 NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
+FORM_AUTO, FORM_TILE, FORM_GEMM, FORM_GEMM_KSLICE = 0, 1, 2, 3
 
 EXPORTS = (
     "bnn_version", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_stage_fwd", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_next_fwd", "bnn_bbb_stage_fwd", "bnn_bbb_tail2_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
 )
 
 
@@ -41,13 +42,13 @@ class BbbFwdArgs(C.Structure):
         ("eps_mode", C.c_int32), ("math", C.c_int32),
         ("eps_w", C.c_void_p), ("eps_b", C.c_void_p),
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
-        ("sample_counter", C.c_void_p),
+        ("sample_counter", C.c_void_p), ("sample_group", C.c_uint32), ("sample_group_stride", C.c_uint32),
         ("eps_w_dump", C.c_void_p), ("eps_b_dump", C.c_void_p),
         ("prior", Prior),
         ("want_stats", C.c_int32), ("relu", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
-        ("y", C.c_void_p), ("y_dtype", C.c_int32), ("concurrency", C.c_int32),
+        ("y", C.c_void_p), ("y_dtype", C.c_int32), ("form", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
         ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p),
     ]
@@ -83,9 +84,9 @@ class LrFwdArgs(C.Structure):
         ("eps_mode", C.c_int32), ("math", C.c_int32),
         ("eps_act", C.c_void_p), ("eps_b", C.c_void_p),
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
-        ("sample_counter", C.c_void_p),
+        ("sample_counter", C.c_void_p), ("sample_group", C.c_uint32), ("sample_group_stride", C.c_uint32),
         ("eps_act_dump", C.c_void_p), ("eps_b_dump", C.c_void_p),
-        ("sigma_p", C.c_float), ("want_kl", C.c_int32), ("relu", C.c_int32), ("concurrency", C.c_int32),
+        ("sigma_p", C.c_float), ("want_kl", C.c_int32), ("relu", C.c_int32), ("form", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
@@ -158,9 +159,13 @@ class FinalizeArgs(C.Structure):
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p), ("kl", C.c_void_p), ("nll", C.c_void_p),
         ("sample_counter", C.c_void_p), ("sample_counter_inc", C.c_uint32), ("reserved", C.c_uint32),
         ("sums", C.c_void_p), ("ticket", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
-        ("sums_ring_pos", C.c_void_p), ("sums_ring_len", C.c_uint32), ("sums_ring_stride", C.c_uint32),
-        ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_dst_sq", C.c_void_p), ("cast_n", C.c_int64),
+        ("group_samples", C.c_int32), ("target_per_group", C.c_int32),
     ]
+
+
+class Plan(C.Structure):
+    _fields_ = [("form", C.c_int32), ("k_classes", C.c_int32), ("waves", C.c_int32), ("batch_rows", C.c_int32),
+                ("k_slices", C.c_int32), ("blocks", C.c_int32), ("lds_bytes", C.c_int32), ("features_per_block", C.c_int32)]
 
 
 class BnnHipError(RuntimeError):
@@ -191,6 +196,10 @@ def load():
     lib.bnn_bbb_linear_fwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.bnn_bbb_linear_fwd.restype = C.c_int
     lib.bnn_bbb_linear_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.c_void_p]
+    lib.bnn_bbb_plan.restype = C.c_int
+    lib.bnn_bbb_plan.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(Plan)]
+    lib.bnn_lr_plan.restype = C.c_int
+    lib.bnn_lr_plan.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(Plan)]
     lib.bnn_bbb_linear_bwd_workspace_bytes.restype = C.c_size_t
     lib.bnn_bbb_linear_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.bnn_lr_linear_bwd_workspace_bytes.restype = C.c_size_t
@@ -201,16 +210,6 @@ def load():
     lib.bnn_adam_step.argtypes = [C.POINTER(AdamArgs), C.c_void_p]
     lib.bnn_mc_softmax_mean.restype = C.c_int
     lib.bnn_mc_softmax_mean.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.bnn_bbb_final_next_fwd.restype = C.c_int
-    lib.bnn_bbb_final_next_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs), C.c_void_p]
-    lib.bnn_lr_stage_fwd.restype = C.c_int
-    lib.bnn_lr_stage_fwd.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(LrFwdArgs), C.POINTER(FinalizeArgs),
-                                     C.c_void_p]
-    lib.bnn_bbb_stage_fwd.restype = C.c_int
-    lib.bnn_bbb_stage_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.POINTER(BbbFwdArgs),
-                                      C.POINTER(BbbFwdArgs), C.c_void_p]
-    lib.bnn_bbb_tail2_fwd.restype = C.c_int
-    lib.bnn_bbb_tail2_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(BbbFwdArgs), C.POINTER(FinalizeArgs), C.c_void_p]
     lib.bnn_elbo_loss.restype = C.c_int
     lib.bnn_elbo_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -20,34 +20,17 @@ from .runtime import state, take_samples
 CAST_INPUT_MIN_SAMPLES = 8    # BBB: below this the extra launch costs more than it saves
 # LR: from one sample on.  Its first layer squares every x fragment it loads, and fp32 x doubles the bytes each block
 # pulls through its CU's L1 (21.5 us for that layer against 14.7 us for the wider second one): casting first wins
-# even with the extra launch in the chain (one-sample evaluation 59.4 -> 55.3 us alone, 15.7 -> 14.6 us pipelined)
+# even with the extra launch in the chain (one-sample evaluation 59.4 -> 55.3 us)
 CAST_INPUT_MIN_SAMPLES_LR = 1
 LR_SQUARES_MIN_SAMPLES = 8    # LR: carry x^2 (bf16) between layers from here on (the block-GEMM form streams it)
-# BBB: K-sliced GEMM form (deterministic split-K + reduce kernel) for this range of samples per launch.
-# Measured on MI355X it only ties the K-split kernel on the 1200-wide layers (29+5 us vs 32 us per layer
-# at 8 samples) but wins on big layers below the plain GEMM form's threshold (4096x4096, 4 samples:
-# 126 vs 175 us), so it is on for layers of >= SPLIT_MIN_WEIGHTS weights, everywhere with BNN_HIP_SPLITK=1.
+# BBB: the K-sliced GEMM form needs a scratch for its fp32 partial tiles; the library's plan (bnn_bbb_plan) takes
+# that form for layers of >= 4 M weights in this range of samples per launch (4096x4096, 4 samples: 126 vs 175 us)
 SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = 4, 24
-SPLIT_MIN_WEIGHTS = 0 if os.environ.get("BNN_HIP_SPLITK", "0") == "1" else 4_000_000
-
-
-# BBB, bf16 math: evaluations of at most this many MC samples take the split form -- ONE streaming launch samples the
-# hidden layers' weights (bnn_bbb_sample_weights, the input cast riding on it), the hidden layers are then matmul-only
-# launches over the sampled bf16 weights, the output layer + finalize stay fused.  0 = never.
-PRESAMPLE_MAX_SAMPLES = int(os.environ.get("BNN_HIP_PRESAMPLE", "0"))
-
-
-# BBB, bf16 math, one MC sample per evaluation, several evaluations per graph launch: the output layer + finalize of
-# evaluation j share ONE launch with the first layer of evaluation j + 1 (bnn_bbb_final_next_fwd) -- the output layer
-# is a few latency-bound blocks that otherwise hold the stream's chain of dependent launches for ~10 us.
-PIPELINE_EVALS = os.environ.get("BNN_HIP_PIPELINE_EVALS", "1") != "0"
-PIPELINE_DEPTH3 = os.environ.get("BNN_HIP_PIPELINE_DEPTH", "3") != "2"
-PIPE_MAX_S = 3            # BBB evaluations of up to this many MC samples are pipelined (2: +11 %, 3: +2 %, 4: -1 %, 8: -24 %)
-
+SPLIT_MIN_WEIGHTS = 4_000_000
 
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
-# chip; BNN_HIP_FUSED_ELBO=0 keeps one node per layer (the form the identical-eps parity path always uses)
-FUSED_ELBO_NODE = os.environ.get("BNN_HIP_FUSED_ELBO", "1") != "0"
+# chip; the identical-eps parity path keeps one node per layer
+FUSED_ELBO_NODE = True
 
 
 def use_split(fin: int, fout: int, n_samples: int) -> bool:
@@ -146,7 +129,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 wfrag, ws_pre = (None, None)
                 if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]):
                     wfrag, ws_pre = ops.lr_prepare(*pd)
-                out = ops.lr_linear_fwd(h, *pd, w_frag=wfrag, workspace=ws_pre, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
+                out = ops.lr_linear_fwd(h, *pd, w_frag=wfrag, workspace=ws_pre, form=state.form, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_act=e_w, eps_b=e_b,
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
                                         want_kl=want_stats, x_sq=h_sq if lr_sq else None,
@@ -156,7 +139,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
             else:
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
-                          sample_offset=first_sample, want_stats=want_stats)
+                          sample_offset=first_sample, want_stats=want_stats, form=state.form)
                 if h.dtype == torch.bfloat16 and n_local >= SIGMA_HOIST_MIN_SAMPLES and eps_mode != L.EPS_ZERO and \
                         ((sp.in_out[1] + 63) // 64) * n_local >= 450:
                     kw["w_sigma"] = ops.softplus(pd[1])        # consumed by the throughput (GEMM) form only
@@ -213,6 +196,12 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
     dev = x.device
     differentiable = torch.is_grad_enabled() and any(
         p.requires_grad for sp in layers for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+    if differentiable and world > 1:
+        # each rank's autograd graph covers its own samples only and nothing here all-reduces parameter gradients:
+        # a per-rank optimizer.step() would make the replicas diverge silently
+        raise ops.BnnHipError(
+            "sample-sharded sample_elbo* is forward-only (use torch.no_grad()); for multi-GPU training shard the "
+            "minibatches instead: bnn_hip.train.GraphedTrainStep(data_parallel=True) sum-all-reduces the gradients")
     zero = torch.zeros((), dtype=torch.float32, device=dev)
     if n_local == 0:
         sums = torch.stack([zero, zero, zero])
@@ -304,43 +293,53 @@ def mc_predict(layers: Sequence[LayerSpec], x: torch.Tensor, samples: int):
 
 
 class GraphedElbo:
-    """One forward-only ELBO evaluation (all local MC samples: one launch per layer + the
-    finalize launch) captured once as a hipGraph and replayed.  The Philox sample index has
-    a device-resident part (`counter`) that the finalize kernel advances by the GLOBAL
-    sample count, so every replay draws fresh epsilon without re-capturing.
+    """Forward-only ELBO evaluations with static buffers: one launch per layer for ALL local MC samples (the last
+    BBB layer carries the finalize), captured once as a hipGraph and replayed.  The Philox sample index has a
+    device-resident part (`counter`) that the finalize kernel advances, so every replay draws fresh epsilon.
 
-    `replay()` returns the static float32[4] tensor {sum log p | sum KL, sum log q | 0,
-    sum nll, n_local}: the vector a sharded job all-reduces."""
+    `x` is one minibatch [B, ...] or a stack of G independent minibatches [G, B, ...] (`target` likewise [B] /
+    [G, B]): what the reference evaluates one after the other (class_task.py:89-103 walks the test loader) runs as
+    one launch per layer over the G x samples (minibatch, MC sample) pairs, exactly as the MC samples of one
+    minibatch do.  Every pair draws its own weights (its own global sample index).
+
+    `replay()` returns the static float32 tensor [G, 4] (or [4] for one minibatch) of
+    {sum log p | sum KL, sum log q | 0, sum nll, local sample count} per minibatch: the vector(s) a sharded job
+    all-reduces.  `out` holds the per-(minibatch, sample) scalars, `logits` the outputs [G * S_local, B, C]."""
 
     def __init__(self, net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0,
-                 capture: bool = True, counter_stride: int = 1, stream: Optional[torch.cuda.Stream] = None,
-                 sums_ring=None, evals_per_replay: int = 1):
-        """`evals_per_replay` E > 1: one replay runs E consecutive evaluations (one graph of E times
-        the kernels; a hipGraph launch costs the host ~10 us + ~1 us per node, so short evaluations
-        are launch-bound one at a time); `sums`/`out`/`logits` then hold the LAST one, the ring all.
-        `counter_stride` > 1: this evaluator is one of several that run concurrently on their
-        own streams and interleave the global MC sample index space (evaluator j of n starts j
-        evaluations in and advances by n evaluations per replay).
-        `sums_ring` = (base, ring_len, stride_floats): replay k deposits its 4-vector at
-        base.view(-1)[(k % ring_len) * stride : +4] instead of a fixed tensor (device-side cursor), so
-        a sharded job can all-reduce many evaluations' scalars with one collective."""
+                 capture: bool = True, stream: Optional[torch.cuda.Stream] = None, evals_per_replay: int = 1,
+                 stacked: bool = False):
+        """`stacked`: x / target carry a leading minibatch dimension G.
+        `evals_per_replay` E > 1: one replay runs E consecutive evaluations of the same inputs with fresh
+        epsilon (one graph of E times the kernels; a hipGraph launch costs the host ~10 us + ~1 us per node, so
+        short evaluations are launch-bound one at a time); `sums` / `out` / `logits` then hold the LAST one."""
         self.net, self.samples, self.sigma = net, int(samples), float(sigma)
-        self.stride = int(counter_stride)
         self.per_replay = max(1, int(evals_per_replay))
         self.stream = stream
         self.rank, self.world = dist_info()
-        self.lo, self.n_local = shard_range(self.samples, self.rank, self.world)
-        if self.n_local <= 0:
+        self.lo, self.s_local = shard_range(self.samples, self.rank, self.world)
+        if self.s_local <= 0:
             raise ops.BnnHipError("GraphedElbo: this rank owns no MC sample (samples < world size)")
         self.specs = net._specs()
         self.lr = bool(net.local_reparam)
         dev = x.device
-        self.x = net._flat(x).contiguous()
+        self.G = int(x.shape[0]) if stacked else 1
+        if stacked:
+            if target.shape[0] != self.G:
+                raise ops.BnnHipError("GraphedElbo: stacked x and target must agree in their leading dimension")
+            xf = torch.stack([net._flat(x[g]) for g in range(self.G)]) if self.G > 1 else net._flat(x[0])
+            target = target if self.G > 1 else target[0]
+        else:
+            xf = net._flat(x)
+        self.x = xf.contiguous()
         self.target = target.contiguous()
+        self.n_local = self.G * self.s_local                 # (minibatch, MC sample) pairs in a launch
+        self.group = self.s_local if self.G > 1 else 0       # samples per minibatch, as the library's group fields
+        self.total_samples = self.G * self.samples           # global sample indices one evaluation spans
         first = take_samples(0)
         self.counter = torch.tensor([first], dtype=torch.int32, device=dev)
         S = self.n_local
-        B = self.x.shape[0]
+        B = self.x.shape[-2]
         math_mode = state.math
         hid = torch.float32 if math_mode == L.MATH_F32 else torch.bfloat16
         self.bufs, self.ws = [], []
@@ -351,24 +350,13 @@ class GraphedElbo:
             self.ws.append(ops.lr_workspace(fout, dev) if self.lr else ops.bbb_workspace(S, fout, dev))
         keys = ("kl",) if self.lr else ("log_prior", "log_q")
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
-        self.sums = torch.zeros(4, dtype=torch.float32, device=dev) if sums_ring is None else sums_ring[0]
-        self.ring = None
-        if sums_ring is not None:
-            self.ring = (torch.zeros(1, dtype=torch.int32, device=dev), int(sums_ring[1]), int(sums_ring[2]))
+        self._sums = torch.zeros((self.G, 4), dtype=torch.float32, device=dev)
+        self.sums = self._sums if self.G > 1 else self._sums.view(4)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
-        nl = len(self.specs)
-        self.presample = (not self.lr and hid == torch.bfloat16 and 0 < S <= PRESAMPLE_MAX_SAMPLES and nl >= 2 and
-                          all(sp.in_out[0] % 8 == 0 for sp in self.specs[:-1]))
-        self.wsamp = self.bsamp = None
-        if self.presample:
-            self.wsamp = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) for sp in self.specs[:-1]]
-            self.bsamp = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) for sp in self.specs[:-1]]
-            for i, sp in enumerate(self.specs[:-1]):
-                self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
-                        (self.presample or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES))) else None)
+                        S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) else None)
         self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
@@ -383,43 +371,11 @@ class GraphedElbo:
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
                           if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
-        # software pipeline over the evaluations of one graph launch (see PIPELINE_EVALS): the first layer's statistics
-        # workspace alternates, every evaluation has its own static sample offset and only the last finalize of a
-        # replay advances the device counter, so an evaluation's first layer depends on nothing its predecessor writes
-        self.pipelined = (PIPELINE_EVALS and self.per_replay > 1 and not self.lr and not self.presample and S <= PIPE_MAX_S and
-                          hid == torch.bfloat16 and nl >= 2 and self.specs[-1].in_out[1] <= 16 and B <= 128 and
-                          self.split[0] is None and self.wsigma[0] is None and self.x16 is None)
-        self.ws0_alt = ops.bbb_workspace(S, self.specs[0].in_out[1], dev) if self.pipelined else None
-        # three-layer nets go one step further: first layer of evaluation j+2, hidden layer of j+1 and output layer of j
-        # in ONE launch (bnn_bbb_stage_fwd), activations and statistics of the two hidden layers buffered three deep
-        self.pipe3 = self.pipelined and nl == 3 and PIPELINE_DEPTH3 and self.split[1] is None and self.wsigma[1] is None
-        if self.pipe3:
-            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(2)]
-            self.slot_ws = [[self.ws[i]] + [ops.bbb_workspace(S, self.specs[i].in_out[1], dev) for _ in range(2)]
-                            for i in range(2)]
-        # LR, three layers: the same three-deep pipeline (bnn_lr_stage_fwd); the finalize stays a launch of its own and
-        # carries the input cast of a later evaluation
-        # (one sample per evaluation only: from two samples on the stage cannot carry the finalize and measured 3-6 % slower
-        # than one launch per layer with the cast riding on the finalize)
-        self.lr_pipe3 = (PIPELINE_EVALS and PIPELINE_DEPTH3 and self.lr and self.per_replay > 1 and nl == 3 and S == 1 and
-                         hid == torch.bfloat16 and self.x16 is not None and not self.lr_sq and
-                         all(w is None for w in self.wfrag))
-        if self.lr_pipe3:
-            self.slot_bufs = [[self.bufs[i]] + [torch.empty_like(self.bufs[i]) for _ in range(2)] for i in range(3)]
-            self.slot_ws = [[self.ws[i]] + [ops.lr_workspace(self.specs[i].in_out[1], dev) for _ in range(2)] for i in range(3)]
-            self.x16_alt = torch.empty_like(self.x16)     # the cast of evaluation t + 1 rides beside the first layer of t
-            self._last_slot = 0
         self.graph = None
-        self._enqueue()                      # warm-up (also validates arguments eagerly)
-        take_samples(self.samples)
-        torch.cuda.synchronize()
-        if self.stride > 1:                  # undo the warm-up's stride-sized advance: next index = first + S
-            self.counter.fill_(first + self.samples)
-            torch.cuda.synchronize()
-        if self.ring is not None:            # the warm-up used slot 0
-            self.ring[0].zero_()
-            torch.cuda.synchronize()
         if capture:
+            self._enqueue()                      # warm-up (also validates arguments eagerly)
+            take_samples(self.total_samples)
+            torch.cuda.synchronize()
             side = self.stream if self.stream is not None else torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -429,246 +385,49 @@ class GraphedElbo:
             torch.cuda.current_stream().wait_stream(side)
             self.graph = g
 
-    def _enqueue(self, skip_cast: bool = False, ride_cast: bool = False):
-        """One evaluation.  LR with several evaluations per graph launch: the input cast of evaluation j + 1 rides on the
-        finalize launch of evaluation j (`ride_cast`; the next call then passes `skip_cast`), one launch less on the chain."""
+    def _enqueue(self):
+        """One evaluation of all local (minibatch, MC sample) pairs."""
         math_mode = state.math
         h_sq = None
-        if self.presample:
-            hidden = self.specs[:-1]
-            ops.bbb_sample_weights(
-                [dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
-                      b_rho=sp.m.bias_rho.detach(), prior=sp.m._prior_spec, layer_id=sp.layer_id, workspace=self.ws[i],
-                      w_out=self.wsamp[i], b_out=self.bsamp[i]) for i, sp in enumerate(hidden)],
-                n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter,
-                cast=(self.x, self.x16) if self.x16 is not None else None)
-            h = self.x16 if self.x16 is not None else self.x
-        elif self.x16 is None:
+        if self.x16 is None:
             h = self.x
-        elif skip_cast:
-            h, h_sq = self.x16, (self.x16_sq if self.lr_sq else None)
         elif self.lr_sq:
             h, h_sq = ops.cast_bf16(self.x, out=self.x16, out_sq=self.x16_sq)
         else:
             h = ops.cast_bf16(self.x, out=self.x16)
         last = len(self.specs) - 1
+        grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
                       local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                      sample_counter_inc=self.samples * self.stride, out=self.out, sums=self.sums,
-                      ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring)
-        pending = None
+                      sample_counter_inc=self.total_samples, out=self.out, sums=self._sums,
+                      ticket=self.ticket, scratch=self.scratch, group_samples=self.group)
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
-                          sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i],
-                          concurrency=self.stride)      # evaluators that run side by side: size launches for a share of the chip
-            if self.presample and i < last:
-                ops.bbb_sampled_matmul(h, self.wsamp[i], self.bsamp[i], n_samples=self.n_local, relu=sp.relu,
-                                       y_dtype=self.bufs[i].dtype, out=self.bufs[i], concurrency=self.stride)
-            elif self.lr:
+                          sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i], form=state.form, **grp)
+            if self.lr:
                 if self.wfrag[i] is not None:
                     ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]
-            elif i == last and pending is not None:
-                # one sample: the last hidden layer, the output layer and the finalize in ONE launch
-                ops.bbb_tail2_fwd(pending[0], pending[1], (h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common),
-                                  dict(workspaces=self.ws[:last - 1], **fin_kw))
-            elif i == last:
-                if self.wsigma[i] is not None:
-                    ops.softplus(p[1], out=self.wsigma[i])
-                ops.bbb_final_fwd((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
-                                                 w_sigma=self.wsigma[i], **common),
-                                  dict(workspaces=self.ws[:last], **fin_kw))
-            elif i == last - 1 and not self.presample and self.n_local == 1 and self.bufs[i].dtype == torch.bfloat16 and \
-                    h.dtype == torch.bfloat16 and self.split[i] is None and self.wsigma[i] is None:
-                pending = ((h,) + p, dict(prior=sp.m._prior_spec, want_stats=True, **common))   # launched with the last layer
             else:
                 if self.wsigma[i] is not None:
                     ops.softplus(p[1], out=self.wsigma[i])
-                ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i],
-                                   w_sigma=self.wsigma[i], **common)
+                kw = dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], w_sigma=self.wsigma[i], **common)
+                if i == last:
+                    ops.bbb_final_fwd((h,) + p, kw, dict(workspaces=self.ws[:last], **fin_kw))
+                else:
+                    ops.bbb_linear_fwd(h, *p, **kw)
             h = self.bufs[i]
         if self.lr:
-            ops.elbo_finalize(workspaces=self.ws, logits=h,
-                              cast=(self.x, self.x16, self.x16_sq if self.lr_sq else None) if ride_cast else None, **fin_kw)
-
-    def _enqueue_pipelined(self):
-        """per_replay one-sample BBB evaluations as L0(e0) L1..(e0) [final(e0) + L0(e1)] L1..(e1) ... final(e_last)."""
-        E, last = self.per_replay, len(self.specs) - 1
-        inc = self.samples * self.stride                   # global MC indices one evaluation of this evaluator spans
-        math_mode = state.math
-        if self.pipe3:
-            self._enqueue_pipelined3(E, inc, math_mode)
-            return
-
-        def layer_call(i, j):
-            sp = self.specs[i]
-            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-            ws = (self.ws[0], self.ws0_alt)[j & 1] if i == 0 else self.ws[i]
-            h = self.x if i == 0 else self.bufs[i - 1]
-            kw = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
-                      eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo + j * inc,
-                      sample_counter=self.counter, workspace=ws, out=self.bufs[i], concurrency=self.stride,
-                      prior=sp.m._prior_spec, want_stats=True)
-            return (h,) + p, kw
-
-        for j in range(E):
-            if j == 0:
-                a0, k0 = layer_call(0, 0)
-                ops.bbb_linear_fwd(*a0, **k0)
-            for i in range(1, last):
-                ai, ki = layer_call(i, j)
-                ops.bbb_linear_fwd(*ai, **ki)
-            al, kl = layer_call(last, j)
-            fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                          local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
-                          target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                          sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
-                          ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring,
-                          workspaces=[(self.ws[0], self.ws0_alt)[j & 1]] + self.ws[1:last])
-            if j < E - 1:
-                an, kn = layer_call(0, j + 1)
-                ops.bbb_final_next_fwd(al, kl, fin_kw, an, kn)
-            else:
-                ops.bbb_final_fwd(al, kl, fin_kw)
-
-    def _enqueue_pipelined3(self, E, inc, math_mode):
-        """Launch t = {output layer + finalize of evaluation t-2, hidden layer of t-1, first layer of t}: E + 2 launches
-        for E evaluations; evaluation j lives in buffer slot j % 3."""
-        def layer_call(i, j):
-            sp = self.specs[i]
-            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-            slot = j % 3
-            h = self.x if i == 0 else self.slot_bufs[i - 1][slot]
-            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
-            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
-            kw = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX,
-                      seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo + j * inc, sample_counter=self.counter,
-                      workspace=ws, out=out, concurrency=self.stride, prior=sp.m._prior_spec, want_stats=True)
-            return (h,) + p, kw
-
-        for t in range(E + 2):
-            final = mid = first = None
-            if t < E:
-                first = layer_call(0, t)
-            if 0 <= t - 1 < E:
-                mid = layer_call(1, t - 1)
-            if 0 <= t - 2 < E:
-                j = t - 2
-                al, kl = layer_call(2, j)
-                fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                              local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
-                              target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                              sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums,
-                              ticket=self.ticket, scratch=self.scratch, sums_ring=self.ring,
-                              workspaces=[self.slot_ws[0][j % 3], self.slot_ws[1][j % 3]])
-                final = (al, kl, fin_kw)
-            ops.bbb_stage_fwd(final=final, mid=mid, first=first)
-
-    def steady_state_stage(self):
-        """For measurement (bench.py's roofline): a closure that enqueues ONE steady-state launch of the three-deep
-        pipeline -- output layer + finalize of the evaluation in slot 0, hidden layer of the one in slot 1, first layer
-        of the one in slot 2 -- without advancing the sample counter or the sums ring."""
-        if self.lr_pipe3:
-            math_mode = state.math
-
-            def lcall(i, slot):
-                sp = self.specs[i]
-                p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-                h = self.x16 if i == 0 else self.slot_bufs[i - 1][slot]
-                out, ws = self.slot_bufs[i][slot], self.slot_ws[i][slot]
-                return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
-                                      relu=sp.relu, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
-                                      layer_id=sp.layer_id, sample_offset=self.lo, sample_counter=self.counter, want_kl=True,
-                                      workspace=ws, out=out, concurrency=self.stride)
-            last, mid, first = lcall(2, 0), lcall(1, 1), lcall(0, 2)
-            sums = torch.zeros(4, dtype=torch.float32, device=self.x.device)
-            fin_kw = dict(workspaces=[self.slot_ws[i][1] for i in range(3)], logits=self.slot_bufs[2][1],
-                          layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                          local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
-                          mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter, sample_counter_inc=0,
-                          out=self.out, sums=sums, ticket=self.ticket, cast=(self.x, self.x16_alt, None))
-            return lambda: ops.lr_stage_fwd(last=last, mid=mid, first=first, fin_kw=fin_kw)
-        if not self.pipe3:
-            raise ops.BnnHipError("steady_state_stage: this evaluator is not three-deep pipelined")
-        math_mode = state.math
-        sums = torch.zeros(4, dtype=torch.float32, device=self.x.device)
-
-        def call(i, slot):
-            sp = self.specs[i]
-            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-            h = self.x if i == 0 else self.slot_bufs[i - 1][slot]
-            out = self.slot_bufs[i][slot] if i < 2 else self.bufs[2]
-            ws = self.slot_ws[i][slot] if i < 2 else self.ws[2]
-            return (h,) + p, dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=out.dtype,
-                                  eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
-                                  sample_counter=self.counter, workspace=ws, out=out, concurrency=self.stride,
-                                  prior=sp.m._prior_spec, want_stats=True)
-
-        al, kl = call(2, 0)
-        fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                      local_reparam=False, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
-                      mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter, sample_counter_inc=0,
-                      out=self.out, sums=sums, ticket=self.ticket, scratch=self.scratch,
-                      workspaces=[self.slot_ws[0][0], self.slot_ws[1][0]])
-        mid, first = call(1, 1), call(0, 2)
-        return lambda: ops.bbb_stage_fwd(final=(al, kl, fin_kw), mid=mid, first=first)
-
-    def _enqueue_lr_pipelined(self):
-        """LR: launch t = {output layer of evaluation t-2, hidden layer of t-1, first layer of t, finalize of t-3, input
-        cast of t+1} (bnn_lr_stage_fwd): E + 3 launches for E evaluations, one per evaluation in steady state.  Evaluation
-        j lives in buffer slot j % 3, its bf16 input in x16 buffer j % 2."""
-        E = self.per_replay
-        inc = self.samples * self.stride
-        math_mode = state.math
-        x16 = (self.x16, self.x16_alt)
-
-        def layer_call(i, j):
-            sp = self.specs[i]
-            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-            slot = j % 3
-            h = x16[j % 2] if i == 0 else self.slot_bufs[i - 1][slot]
-            return (h,) + p, dict(n_samples=self.n_local, sigma_p=sp.m._prior_spec.sigma_p, math_mode=math_mode,
-                                  relu=sp.relu, y_dtype=self.slot_bufs[i][slot].dtype, eps_mode=L.EPS_PHILOX, seed=state.seed,
-                                  layer_id=sp.layer_id, sample_offset=self.lo + j * inc, sample_counter=self.counter,
-                                  want_kl=True, workspace=self.slot_ws[i][slot], out=self.slot_bufs[i][slot],
-                                  concurrency=self.stride)
-
-        def fin_call(j, t):
-            slot = j % 3
-            rider = (self.x, x16[(t + 1) % 2], None) if t + 1 < E else None
-            return dict(workspaces=[self.slot_ws[i][slot] for i in range(3)], logits=self.slot_bufs[2][slot],
-                        layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
-                        local_reparam=True, prior=self.specs[0].m._prior_spec, n_samples=self.n_local, target=self.target,
-                        mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
-                        sample_counter_inc=E * inc if j == E - 1 else 0, out=self.out, sums=self.sums, ticket=self.ticket,
-                        sums_ring=self.ring, cast=rider)
-
-        ops.cast_bf16(self.x, out=x16[0])                     # evaluation 0
-        for t in range(E + 3):
-            j = t - 3
-            fin_kw = fin_call(j, t) if 0 <= j < E else None
-            if fin_kw is None and t + 1 < E:                  # no finalize to carry the next cast yet
-                ops.cast_bf16(self.x, out=x16[(t + 1) % 2])
-            ops.lr_stage_fwd(last=layer_call(2, t - 2) if 0 <= t - 2 < E else None,
-                             mid=layer_call(1, t - 1) if 0 <= t - 1 < E else None,
-                             first=layer_call(0, t) if t < E else None, fin_kw=fin_kw)
-        self._last_slot = (E - 1) % 3
+            ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
 
     def _eager(self):
-        if self.pipelined:
-            self._enqueue_pipelined()
-            return
-        if self.lr_pipe3:
-            self._enqueue_lr_pipelined()
-            return
-        ride = PIPELINE_EVALS and self.lr and self.x16 is not None and self.per_replay > 1
-        for j in range(self.per_replay):
-            self._enqueue(skip_cast=ride and j > 0, ride_cast=ride and j < self.per_replay - 1)
+        for _ in range(self.per_replay):
+            self._enqueue()
 
     def replay(self) -> torch.Tensor:
         if self.stream is not None:
@@ -678,11 +437,24 @@ class GraphedElbo:
             self.graph.replay()
         else:
             self._eager()
-        take_samples(self.samples * self.per_replay)     # keep the host-side counter in step
+        take_samples(self.total_samples * self.per_replay)     # keep the host-side counter in step
         return self.sums
 
     @property
     def logits(self) -> torch.Tensor:
-        if getattr(self, "lr_pipe3", False):               # of the last evaluation of a replay
-            return self.slot_bufs[2][self._last_slot]
         return self.bufs[-1]
+
+
+def elbo_many(net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0) -> torch.Tensor:
+    """Forward-only ELBO terms of G independent minibatches in ONE launch per layer: x [G, B, ...], target [G, B]
+    (or [G, B, out] for regression).  Returns float32 [G, 4] = per minibatch {sum_s log p | sum_s KL, sum_s log q | 0,
+    sum_s nll, samples}, all-reduced over the ranks when sample sharding is on -- what G calls of
+    sample_elbo / sample_elbo_lr under no_grad would give before their division by `samples`
+    (networks.py:199-208, :217-224), each (minibatch, sample) pair with its own epsilon."""
+    with torch.no_grad():
+        ev = GraphedElbo(net, x, target, samples, sigma=sigma, capture=False, stacked=True)
+        sums = ev.replay().clone().view(ev.G, 4)
+    if ev.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums

@@ -68,16 +68,18 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _x3(x: torch.Tensor, n_samples: int):
-    """Returns (contiguous x, batch, in_features, per_sample)."""
+    """Returns (contiguous x, batch, in_features, x_per_sample): 0 = one x for all samples, g >= 1 = sample s reads
+    x[s // g] (x [rows, batch, in] with rows * g == n_samples: g = 1 is one x per sample, g = S is one x per minibatch
+    of S MC samples)."""
     if x.dim() == 2:
         xs = x if x.is_contiguous() else x.contiguous()
         return xs, x.shape[0], x.shape[1], 0
     if x.dim() == 3:
-        if x.shape[0] != n_samples:
-            raise BnnHipError(f"x has {x.shape[0]} samples, expected {n_samples}")
+        if x.shape[0] < 1 or n_samples % x.shape[0]:
+            raise BnnHipError(f"x has {x.shape[0]} row blocks, which does not divide {n_samples} samples")
         xs = x if x.is_contiguous() else x.contiguous()
-        return xs, x.shape[1], x.shape[2], 1
-    raise BnnHipError(f"x must be [batch,in] or [samples,batch,in], got {tuple(x.shape)}")
+        return xs, x.shape[1], x.shape[2], n_samples // x.shape[0]
+    raise BnnHipError(f"x must be [batch,in] or [rows,batch,in], got {tuple(x.shape)}")
 
 
 def bbb_workspace(n_samples: int, out_features: int, device) -> torch.Tensor:
@@ -108,7 +110,8 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
-               out=None, split_scratch=None, w_sigma=None, concurrency: int = 0):
+               out=None, split_scratch=None, w_sigma=None, form: int = 0, sample_group: int = 0,
+               sample_group_stride: int = 0):
     """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -138,7 +141,8 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     a.eps_w, a.eps_b = _ptr(eps_w) if eps_mode == L.EPS_MEMORY else None, _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
     a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
     a.sample_counter = _ptr(sample_counter)
-    a.concurrency = int(concurrency)
+    a.sample_group, a.sample_group_stride = int(sample_group), int(sample_group_stride)
+    a.form = int(form)
     a.eps_w_dump, a.eps_b_dump = _ptr(dw), _ptr(db)
     a.prior = prior.c()
     a.want_stats, a.relu = int(want_stats), int(relu)
@@ -162,6 +166,18 @@ def bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
     a, res, keep = _bbb_build(x, w_mu, w_rho, b_mu, b_rho, **kw)
     L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
     return res
+
+
+def _plan_dict(pl: L.Plan) -> dict:
+    return {k: getattr(pl, k) for k, _ in L.Plan._fields_}
+
+
+def bbb_plan(x, w_mu, w_rho, b_mu, b_rho, **kw) -> dict:
+    """bnn_bbb_plan: the launch geometry bbb_linear_fwd would use for these arguments (no launch)."""
+    a, res, keep = _bbb_build(x, w_mu, w_rho, b_mu, b_rho, **kw)
+    pl = L.Plan()
+    L.check(L.load().bnn_bbb_plan(C.byref(a), C.byref(pl)), "bnn_bbb_plan")
+    return _plan_dict(pl)
 
 
 def sample_workspace(n_samples: int, fin: int, fout: int, device) -> torch.Tensor:
@@ -224,7 +240,7 @@ def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: 
     return res
 
 
-def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, concurrency: int = 0):
+def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):
     """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s])."""
     lib = L.load()
     require_device(x, w, b)
@@ -242,7 +258,6 @@ def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dt
     a.eps_mode, a.math = L.EPS_ZERO, L.MATH_BF16
     a.want_stats, a.relu = 0, int(relu)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
-    a.concurrency = int(concurrency)
     a.w_sampled, a.b_sampled = w.data_ptr(), b.data_ptr()
     L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
     return y
@@ -252,7 +267,8 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None, w_frag=None, want_v: bool = False, concurrency: int = 0):
+                  out_sq=None, w_frag=None, want_v: bool = False, form: int = 0, sample_group: int = 0,
+                  sample_group_stride: int = 0):
     """Argument block of K3 + the result dict + the tensors it points at."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -282,7 +298,8 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     a.eps_b = _ptr(eps_b) if eps_mode == L.EPS_MEMORY else None
     a.seed, a.layer_id, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, layer_id, sample_offset & 0xFFFFFFFF
     a.sample_counter = _ptr(sample_counter)
-    a.concurrency = int(concurrency)
+    a.sample_group, a.sample_group_stride = int(sample_group), int(sample_group_stride)
+    a.form = int(form)
     a.eps_act_dump, a.eps_b_dump = _ptr(da), _ptr(db)
     a.sigma_p, a.want_kl, a.relu = float(sigma_p), int(want_kl), int(relu)
     a.workspace = _ptr(workspace) if want_kl else None
@@ -316,18 +333,12 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
     return res
 
 
-def lr_stage_fwd(last=None, mid=None, first=None, fin_kw=None):
-    """bnn_lr_stage_fwd: `last` / `mid` / `first` = (args, kw) as for lr_linear_fwd (any may be None): the output layer
-    of one evaluation, the hidden layer of the next and the first layer of the one after, independent, in one launch;
-    `fin_kw`: the elbo_finalize keywords (with its `cast` rider) of a still earlier evaluation, riding along."""
-    lib = L.load()
-    built = [(_lr_build(*c[0], **c[1]) if c is not None else None) for c in (last, mid, first)]
-    f = _fin_build(**fin_kw) if fin_kw is not None else None
-    ref = lambda t_: C.byref(t_[0]) if t_ is not None else None
-    L.check(lib.bnn_lr_stage_fwd(ref(built[0]), ref(built[1]), ref(built[2]), ref(f), _stream()), "bnn_lr_stage_fwd")
-    return [t_[1] if t_ is not None else None for t_ in built]
-
-
+def lr_plan(x, w_mu, w_rho, b_mu, b_rho, **kw) -> dict:
+    """bnn_lr_plan: the launch geometry lr_linear_fwd would use for these arguments (no launch)."""
+    a, res, keep = _lr_build(x, w_mu, w_rho, b_mu, b_rho, **kw)
+    pl = L.Plan()
+    L.check(L.load().bnn_lr_plan(C.byref(a), C.byref(pl)), "bnn_lr_plan")
+    return _plan_dict(pl)
 
 
 def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tensor:
@@ -348,7 +359,9 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
 def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
                logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
                nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
-               ticket=None, scratch=None, sums_ring=None, cast=None):
+               ticket=None, scratch=None, group_samples: int = 0):
+    """`group_samples` g > 0: the n_samples are G = n_samples / g independent minibatches of g MC samples each;
+    `target` may then hold one target block per minibatch ([G, batch] / [G, batch, classes]) and `sums` is [G, 4]."""
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -372,18 +385,24 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
         S, B, Cc = lg.shape
         if S != n_samples:
             raise BnnHipError("logits must be [samples,batch,classes]")
+        G = n_samples // group_samples if group_samples else 1
+        if group_samples and n_samples % group_samples:
+            raise BnnHipError("group_samples must divide n_samples")
         if mode == "classification":
             tg = target.to(torch.int64).contiguous()
-            if tg.numel() != B:
-                raise BnnHipError("classification target must have `batch` elements")
+            if tg.numel() not in (B, G * B):
+                raise BnnHipError("classification target must have `batch` elements (per minibatch)")
             a.nll_mode = L.NLL_CLASSIFICATION
+            per_group = tg.numel() == G * B and G > 1
         elif mode == "regression":
             tg = _f32c(target.to(torch.float32), "target")
-            if tg.numel() != B * Cc:
-                raise BnnHipError("regression target must match the output shape")
+            if tg.numel() not in (B * Cc, G * B * Cc):
+                raise BnnHipError("regression target must match the output shape (per minibatch)")
             a.nll_mode = L.NLL_REGRESSION
+            per_group = tg.numel() == G * B * Cc and G > 1
         else:
             raise Exception("Training mode must be either 'regression' or 'classification'")
+        a.target_per_group = int(per_group)
         keep += [lg, tg]
         a.batch, a.classes = B, Cc
         a.logits, a.target, a.nll_sigma = lg.data_ptr(), tg.data_ptr(), float(nll_sigma)
@@ -391,21 +410,7 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
             out["nll"] = torch.empty(n_samples, dtype=torch.float32, device=dev)
     a.sample_counter, a.sample_counter_inc = _ptr(sample_counter), int(sample_counter_inc)
     a.sums = _ptr(sums)
-    if sums_ring is not None:                       # (pos uint32[1] tensor, ring length, slot stride in floats)
-        if sums is None:
-            raise BnnHipError("sums_ring needs `sums` (the slab base of this evaluator)")
-        ring_pos, ring_len, ring_stride = sums_ring
-        require_device(ring_pos)
-        a.sums_ring_pos, a.sums_ring_len, a.sums_ring_stride = ring_pos.data_ptr(), int(ring_len), int(ring_stride)
-        keep.append(ring_pos)
-    if cast is not None:                           # (fp32 src, bf16 dst, bf16 dst_sq | None): rides on bnn_elbo_finalize
-        src, dst, dsq = cast
-        require_device(src, dst, dsq)
-        if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.numel() != dst.numel() or \
-                not src.is_contiguous() or not dst.is_contiguous() or (dsq is not None and dsq.numel() != src.numel()):
-            raise BnnHipError("finalize cast rider: contiguous fp32 source, bf16 destination(s) of the same size")
-        a.cast_src, a.cast_dst, a.cast_dst_sq, a.cast_n = src.data_ptr(), dst.data_ptr(), _ptr(dsq), src.numel()
-        keep += [src, dst, dsq]
+    a.group_samples = int(group_samples)
     a.ticket = _ptr(ticket)
     a.scratch = _ptr(scratch)
     a.scratch_bytes = scratch.numel() * scratch.element_size() if scratch is not None else 0
@@ -434,60 +439,6 @@ def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
     f, out, keep2 = _fin_build(**fin_kw)
     L.check(lib.bnn_bbb_final_fwd(C.byref(a), C.byref(f), _stream()), "bnn_bbb_final_fwd")
     return res, out
-
-
-def bbb_final_next_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict, next_args: tuple, next_kw: dict):
-    """bnn_bbb_final_next_fwd: the output layer + finalize of one evaluation and the first layer of the next one in
-    one launch.  Arguments as for bbb_final_fwd plus those of bbb_linear_fwd for the next evaluation's first layer.
-    Returns (layer result, finalize result, next layer result)."""
-    lib = L.load()
-    a, res, keep1 = _bbb_build(*layer_args, **layer_kw)
-    fin_kw = dict(fin_kw)
-    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
-    fin_kw["logits"] = res["y"]
-    f, out, keep2 = _fin_build(**fin_kw)
-    n, resn, keep3 = _bbb_build(*next_args, **next_kw)
-    L.check(lib.bnn_bbb_final_next_fwd(C.byref(a), C.byref(f), C.byref(n), _stream()), "bnn_bbb_final_next_fwd")
-    return res, out, resn
-
-
-def bbb_stage_fwd(final=None, mid=None, first=None):
-    """bnn_bbb_stage_fwd: `final` = (layer_args, layer_kw, fin_kw) as for bbb_final_fwd, `mid` / `first` =
-    (args, kw) as for bbb_linear_fwd, any of them None: the given pieces, which must be independent, in one launch."""
-    lib = L.load()
-    keep = []
-    a = f = m = n = None
-    if final is not None:
-        la, lk, fin_kw = final
-        a, res, k1 = _bbb_build(*la, **lk)
-        fin_kw = dict(fin_kw)
-        fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
-        fin_kw["logits"] = res["y"]
-        f, out, k2 = _fin_build(**fin_kw)
-        keep += [k1, k2]
-    if mid is not None:
-        m, _, k3 = _bbb_build(*mid[0], **mid[1])
-        keep.append(k3)
-    if first is not None:
-        n, _, k4 = _bbb_build(*first[0], **first[1])
-        keep.append(k4)
-    ref = lambda x: C.byref(x) if x is not None else None
-    L.check(lib.bnn_bbb_stage_fwd(ref(a), ref(f), ref(m), ref(n), _stream()), "bnn_bbb_stage_fwd")
-
-
-def bbb_tail2_fwd(hidden_args: tuple, hidden_kw: dict, last_args: tuple, last_kw: dict, fin_kw: dict):
-    """Last hidden BBB layer + output layer + finalize through bnn_bbb_tail2_fwd (one launch for a one-sample
-    evaluation).  `last_args[0]` (the output layer's x) must be the hidden layer's `out` tensor; `fin_kw` carries the
-    workspaces of the layers BEFORE these two.  Returns (hidden result, last result, finalize result)."""
-    lib = L.load()
-    a2, res2, keep2 = _bbb_build(*hidden_args, **hidden_kw)
-    a3, res3, keep3 = _bbb_build(*last_args, **last_kw)
-    fin_kw = dict(fin_kw)
-    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res2["workspace"], res3["workspace"]]
-    fin_kw["logits"] = res3["y"]
-    f, out, keepf = _fin_build(**fin_kw)
-    L.check(lib.bnn_bbb_tail2_fwd(C.byref(a2), C.byref(a3), C.byref(f), _stream()), "bnn_bbb_tail2_fwd")
-    return res2, res3, out
 
 
 def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int, rows: int, cols: int,

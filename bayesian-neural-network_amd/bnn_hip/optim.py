@@ -54,6 +54,21 @@ class FusedAdam(torch.optim.Optimizer):
     def device_step(self, gi: int = 0) -> int:
         return int(self._dev[gi][0].item()) if gi in self._dev else 0
 
+    def state_dict(self):
+        """torch's format.  A capturable group counts its steps in a device word: mirror it into state[p]['step'] first,
+        so that a checkpoint resumes the bias correction where training stopped (one device read per group)."""
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._dev:
+                step = self.device_step(gi)
+                for p in group["params"]:
+                    if p in self.state and len(self.state[p]):
+                        self.state[p]["step"] = step
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._dev = {}                   # rebuilt from state[p]['step'] at the next step
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -25,6 +25,8 @@ class _State:
         self.host_eps = os.environ.get("BNN_HIP_EPS", "device").lower() == "host"
         self.counter = 0            # next unused GLOBAL MC sample index
         self.shard_samples = False  # split MC samples over torch.distributed ranks
+        self.form = L.FORM_AUTO     # kernel-form preference handed to every layer launch (bnn_form; the tests compare
+                                    # the forms with each other through it)
         self.device_counter = None  # device int32[1] added to every layer's sample index at run time
                                     # (set while a training step is captured as a hipGraph: train.py)
 

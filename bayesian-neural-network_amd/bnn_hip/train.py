@@ -37,9 +37,10 @@ TRAIN_PRESAMPLE = os.environ.get("BNN_HIP_TRAIN_PRESAMPLE", "1") != "0"
 class GraphedTrainStep:
     def __init__(self, net, optimizer: FusedAdam, x: torch.Tensor, y: torch.Tensor, samples: int, sigma: float = 1.0,
                  warmup: int = 2, autograd: bool = False, data_parallel: bool = False):
-        """`x`, `y`: an example minibatch (shape/dtype of every later one).  The warm-up steps run with
-        the optimiser's learning rate forced to zero and its state restored afterwards, so building
-        the graph leaves the model and the optimiser as they were.
+        """`x`, `y`: an example minibatch (shape/dtype of every later one).  The warm-up steps are real
+        updates; parameters, Adam moments, the (host or device) step count and the sample counter are snapshotted
+        before and restored afterwards, so building the graph -- also a second one on an already trained
+        optimiser -- leaves the model and the optimiser as they were.
 
         `data_parallel`: every rank of the default torch.distributed group (RCCL on GPUs) holds a replica
         and feeds its own minibatch; the backward kernels write all gradients into ONE flat fp32
@@ -94,6 +95,10 @@ class GraphedTrainStep:
         saved_p = [p.detach().clone() for p in params]
         saved_state = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
                        for p in params if p in optimizer.state and len(optimizer.state[p])}
+        # a capturable FusedAdam counts its steps in device words (state[p]["step"] is not written during training):
+        # snapshot them, so that a step object built on an already trained optimiser (another batch shape, a
+        # re-capture) leaves the bias-correction step where it was
+        saved_dev_step = {gi: d[0].clone() for gi, d in getattr(optimizer, "_dev", {}).items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         host_counter = state.counter
@@ -114,9 +119,12 @@ class GraphedTrainStep:
                 else:
                     st["exp_avg"].zero_()
                     st["exp_avg_sq"].zero_()
-        for gi in optimizer._dev:
-            steps = [int(saved_state[p]["step"]) for p in optimizer.param_groups[gi]["params"] if p in saved_state]
-            optimizer._dev[gi][0].fill_(max(steps) if steps else 0)
+        for gi in getattr(optimizer, "_dev", {}):
+            if gi in saved_dev_step:
+                optimizer._dev[gi][0].copy_(saved_dev_step[gi])
+            else:                                        # the warm-up created the device words: start from the host-side step
+                steps = [int(saved_state[p]["step"]) for p in optimizer.param_groups[gi]["params"] if p in saved_state]
+                optimizer._dev[gi][0].fill_(max(steps) if steps else 0)
         self.counter.zero_()
         torch.cuda.synchronize()
 

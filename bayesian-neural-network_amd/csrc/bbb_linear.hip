@@ -62,6 +62,8 @@ struct BbbK {
   long mask_sstride;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
+  int xg;                                 // samples sharing one x row block (x index = s / xg); x_sstride = 0: one x for all
+  uint32_t sgrp, sgrp_stride;             // sample groups (bnn_bbb_fwd_args.sample_group): 0 = none
   float inv2var1, c1, inv2var2, c2, pi;   // mixture: log N(w;0,s_i) = c_i - w^2 * inv2var_i
 #ifdef BNN_STAMPS
   unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
@@ -143,6 +145,14 @@ __device__ __forceinline__ void load_xfrag(const char* __restrict__ xs, long off
       for (int j = 0; j < 8; ++j) xv[j] = (float)xb[j];
     }
   }
+}
+
+// global MC sample index (Philox subsequence) of local sample s
+__device__ __forceinline__ uint32_t global_sample(const BbbK& p, int s) {
+  const uint32_t base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
+  if (p.sgrp == 0u) return base + (uint32_t)s;
+  const uint32_t g = (uint32_t)s / p.sgrp;
+  return base + g * p.sgrp_stride + ((uint32_t)s - g * p.sgrp);
 }
 
 // the mixture density itself (argument of the log), for add_log
@@ -270,14 +280,12 @@ struct FinPack {
 // output features): kernel "feature" n = original input index, kernel reduction index k =
 // original output index, weight element (k, n) lives at w[k * ldw + n]; its eps is slot n & 3 of
 // Philox group (k, n >> 2).  No bias, no statistics.
-// Returns false for the padding blocks of the XCD-aware grid (no work done).  `forced_item` >= 0 runs that
-// work item whatever the block index is (the fused-tail kernel hands the last layer to whichever block
-// finished the layer before it last).
+// Returns false for the padding blocks of the XCD-aware grid (no work done).
 // MT: 16-row batch tiles per block (8 = 128 rows).  The matmul-only forms use 2: without generator work a block's
 // cost is the x it pulls through its CU's L1 (all of K for its rows), so four times the blocks each ingest a quarter;
 // with sampling fused every batch block would redo the tile's sampling, hence 8 there.
 template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8>
-__device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, int forced_item = -1) {
+__device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -287,8 +295,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
   int item;
   const int KS = FINAL ? fp->ks : 1;                          // K-range slices per sample (FINAL only)
-  if (forced_item >= 0) item = forced_item;
-  else if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return false;   // block-uniform
+  if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return false;   // block-uniform
   const int ks = item % KS;
   item /= KS;
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
@@ -300,13 +307,13 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   const int spb = (ssteps + KS - 1) / KS;                      // super-steps per K-range slice
   const int t_lo = ks * spb, t_hi = min(ssteps, t_lo + spb);
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const uint32_t gs = global_sample(p, s);
   const bool do_stats = p.want_stats && mb == 0;
   const bool do_ls = do_stats && (s == 0 || FINAL);
   const bool do_dump = mb == 0;
   const int gpr = (K + 3) >> 2;
   const uint32_t wid = p.layer_id * 4u;
-  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
 
   float* lds_bias = lds + (size_t)nw * MT * 64 * 4;   // 16 floats
   float* lds_red = lds_bias + 16;                    // 3 * nw floats
@@ -649,7 +656,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
       fin_store(fk, s, a, b, nll);
       if (fk.S == 1) {
         if (fp->sums) {
-          float* so = fin_sums_slot(fk, fp->sums);
+          float* so = fp->sums;
           so[0] = a; so[1] = b; so[2] = nll; so[3] = 1.f;
         }
         if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
@@ -662,17 +669,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp, i
         if (tk == (uint32_t)fk.S - 1u) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (fp->sums) {
-            double ta = 0, tb = 0, tn = 0;
-            const float* pa = fk.local_reparam ? fk.kl : fk.log_prior;
-            for (int i = 0; i < fk.S; ++i) {
-              if (pa) ta += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (!fk.local_reparam && fk.log_q) tb += __hip_atomic_load(fk.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (fk.nll) tn += __hip_atomic_load(fk.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            float* so = fin_sums_slot(fk, fp->sums);
-            so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)fk.S;
-          }
+          if (fp->sums) fin_fold_sums(fk, fp->sums);
           *fp->ticket = 0u;
           if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
         }
@@ -690,66 +687,6 @@ __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
 template <int MATH, int XDT>
 __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const FinPack fp) {
   bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
-}
-
-// K1e  the output layer + finalize of ONE evaluation and the FIRST layer of the next one in one launch: two independent
-// pieces of work (the caller keeps their buffers apart).  The output layer is a handful of latency-bound blocks
-// (five K-slice blocks and a hand-off at the MNIST shape, ~10 us); as a launch of its own it holds its stream's chain
-// for that long, next to the next evaluation's first layer it costs the chain nothing.
-// One step further (three-layer nets): the hidden layer of evaluation j+1 joins as a third independent piece
-// (blocks [nf, nf + nm), bf16 x, the first layer's tile plan), so that in steady state an evaluation is ONE launch.
-template <int XDT1, int R1>
-__global__ __launch_bounds__(768) void bbb_fwd_final_next_kernel(const BbbK p3, const FinPack fp, const BbbK pm, const BbbK p1,
-                                                                 int nf, int nm, int n1, int plain) {
-  // the two plain layers' block ranges start on, and are padded to, a multiple of 8 blocks, so the XCD-aware work order
-  // of the stand-alone launch can hold inside each (`plain` = 0).  Measured for this kernel it does not pay: the stage
-  // alone 14.8 against 15.4 us, but four evaluators side by side 105.8 k against 106.8 k samples/s on the same box
-  // ([out,in] weights are read along their rows: no line is shared between tiles) -- block order is the default here;
-  // the LR stage, whose tiles share the lines of gathered [in,out] weights, keeps the XCD order.
-  const int b = (int)blockIdx.x;
-  const int ef = (nf + 7) & ~7, em = ef + ((nm + 7) & ~7);
-  int item;
-  if (b < ef) {
-    if (b < nf) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, true, true>(p3, &fp, b);
-  } else if (b < em) {
-    if (xcd_piece_item(b - ef, nm, item, plain)) bbb_fwd_body<BNN_MATH_BF16, BNN_BF16, R1, true, false>(pm, nullptr, item);
-  } else {
-    if (xcd_piece_item(b - em, n1, item, plain)) bbb_fwd_body<BNN_MATH_BF16, XDT1, R1, true, false>(p1, nullptr, item);
-  }
-}
-
-// K1d  one-sample tail of an evaluation in ONE launch: the last hidden layer (K1a, any tile plan) and, run by
-// whichever of its blocks finishes last, the output layer + finalize (K1c without K-slices).  Every block
-// drains its stores, one lane releases at agent scope and takes a ticket; the last arriver acquires and
-// carries on (no block ever waits for another: placement-independent, guide G16).  Saves a dependent launch
-// and the K-slice hand-off of the separate last-layer kernel on the latency chain of a one-sample evaluation.
-template <int MATH, int R2>
-__global__ __launch_bounds__(768) void bbb_fwd_tail2_kernel(const BbbK p2, const BbbK p3, const FinPack fp,
-                                                            uint32_t* ticket, uint32_t n_real_blocks) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // word 0 doubles as the "I am last" flag between the two
-  uint32_t& last_flag = *reinterpret_cast<uint32_t*>(lds);      // bodies (static LDS would eat into the 160 KiB the slabs need)
-  const bool real = bbb_fwd_body<MATH, BNN_BF16, R2, true, false>(p2, nullptr);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores of the layer's outputs and statistics
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t last = 0u;
-    if (real) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk == n_real_blocks - 1u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *ticket = 0u;                                    // ready for the next launch
-        last = 1u;
-      }
-    }
-    last_flag = last;
-  }
-  __syncthreads();
-  if (last_flag == 0u) return;                           // block-uniform
-  __syncthreads();
-  bbb_fwd_body<MATH, BNN_BF16, 1, true, true>(p3, &fp, 0);
 }
 
 // matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
@@ -802,13 +739,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   const int m0 = mb * 128;
   const int ksteps = (K + 31) >> 5;
   const int spb = (ksteps + KS - 1) / KS, t_lo = ks * spb, t_hi = min(ksteps, t_lo + spb);
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const uint32_t gs = global_sample(p, s);
   const bool do_stats = p.want_stats && mb == 0;
   const bool do_ls = do_stats && s == 0;
   const bool do_dump = mb == 0;
   const int gpr = (K + 3) >> 2;
   const uint32_t wid = p.layer_id * 4u;
-  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
   const int T = (N + 15) >> 4;
 
   if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T * KS), 0.f, 0.f, 0.f);
@@ -1060,33 +997,30 @@ extern "C" size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t 
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 namespace {
-struct Plan {
-  int R, nw, tiles;
+// Launch geometry of K1: a pure function of the shape and of what the arguments allow (bnn_bbb_plan exports it).
+struct BbbPlan {
+  int form;         // bnn_form
+  int R, nw, mt;    // TILE: k-range classes, waves per block, 16-row batch tiles per block
+  int tiles;        // TILE: feature tiles
+  int ksl;          // GEMM_KSLICE: slices
+  long blocks;
+  size_t lds;
 };
 
-// Launch geometry.  Depends only on the problem shape (and optional env overrides), never on
-// pointers: the same shape always runs the same summation order.
-Plan make_plan(int S, int B, int K, int N, bool aligned, int concurrency = 1) {
-  Plan pl{};
-  const int mbs = (B + 127) / 128;
-  const int forceR = env_int("BNN_HIP_BBB_R", 0);
-  const int forceNw = env_int("BNN_HIP_BBB_WAVES", 0);
+constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
+constexpr int kSliceMinBlocks = 300;         // ... or K-sliced from this many (group x sample x batch block x slice) items
+constexpr long kSliceMinWeights = 4000000;   // K-sliced GEMM only for layers this big: it ties the tile form on the
+                                             // 1200-wide layers (29 + 5 us against 32 us at 8 samples) and wins on
+                                             // 4096 x 4096 (126 against 175 us at 4 samples)
+
+// TILE form.  Narrower tiles (more k-range classes per MFMA tile) until the launch covers the chip; the block's waves
+// divide the super-steps evenly.
+void tile_plan(int S, int B, int K, int N, bool aligned, int mt, BbbPlan& pl) {
+  const int mbs = (B + 16 * mt - 1) / (16 * mt);
   int R = 1;
-  if (aligned) {
-    // narrower tiles (more k-range classes per MFMA tile) until the launch covers the chip
-    // ... or its share of the chip when `concurrency` launches like this one run side by side: with four
-    // one-sample evaluations in flight 75 tiles of 16 features each (300 blocks in all) beat 150 of 8 (measured
-    // 14.7 -> 12.5 us per evaluation) although one launch alone is slower that way (10.4 -> 13.5 us)
-    const long want = 120 / (concurrency > 1 ? concurrency : 1);
-    while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * S * mbs < want) R *= 2;
-    if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
-  }
+  if (aligned)
+    while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * S * mbs < 120) R *= 2;
   const int F = 16 / R;
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   int spw = 1;                                       // super-steps per wave; waves divide them evenly
@@ -1098,14 +1032,29 @@ Plan make_plan(int S, int B, int K, int N, bool aligned, int concurrency = 1) {
   if ((long)((N + F - 1) / F) * S * mbs >= 400 && ssteps >= 8) nw = 4;
   // a CU has 4 SIMDs: 10 waves sit 3,3,2,2 and the block waits for the crowded pair (stamps: 3.9 k cycles
   // of barrier wait); a multiple of 4 keeps the generator work per SIMD even (measured 11.2 -> 10.4 us per
-  // one-sample launch of the 1200x1200 layer, 16.2 -> 14.8 us per evaluation with four in flight)
-  else if (ssteps >= 4) nw = (ssteps >= 12 ? 12 : ssteps) & ~3;   // as many waves as there are k-steps, up to 12, in fours
-  if (forceNw > 0) nw = forceNw > 12 ? 12 : forceNw;
+  // one-sample launch of the 1200x1200 layer)
+  else if (ssteps >= 4) nw = (ssteps >= 12 ? 12 : ssteps) & ~3;
   if (nw > ssteps) nw = ssteps;
+  pl.form = BNN_FORM_TILE;
   pl.R = R;
   pl.nw = nw < 1 ? 1 : nw;
+  pl.mt = mt;
   pl.tiles = (N + F - 1) / F;
-  return pl;
+  pl.ksl = 1;
+  pl.blocks = (long)pl.tiles * S * mbs;
+  pl.lds = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+}
+
+// K-range slices of the GEMM form for `gemm_blocks` (group x sample x batch block) items: enough slices for ~600
+// blocks, at least 4 k-steps each, no more than the statistics workspace has entries for (ceil(N/4) per sample).
+int kslices(long gemm_blocks, int K, int N) {
+  const int ksteps = (K + 31) / 32;
+  int ksl = (int)((600 + gemm_blocks - 1) / gemm_blocks);
+  if (ksl > 8) ksl = 8;
+  if (ksl > ksteps / 4) ksl = ksteps / 4;
+  const int max_ks = ((N + 3) / 4) / ((N + 15) / 16);
+  if (ksl > max_ks) ksl = max_ks;
+  return ksl < 1 ? 1 : ksl;
 }
 
 template <typename KernelT>
@@ -1116,6 +1065,47 @@ hipError_t allow_big_lds(KernelT kernel, size_t lds) {
 }
 }  // namespace
 
+// `al`: the 16-byte vector path applies (K % 8 == 0, aligned bases).  Returns a bnn_status.
+static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
+  const int S = a->n_samples, B = a->batch, K = a->in_features, N = a->out_features;
+  const int mbs = (B + 127) / 128;
+  if (a->w_sampled) {
+    // matmul half only: same tile machinery, no generator work.  Without it a block's cost is the x it pulls through
+    // its CU's L1 -- all of K for its rows -- so 32-row batch blocks (four times the blocks, each ingesting a quarter)
+    // and whole 16-feature tiles (5.2 against 8.7 us at 128 x 1200 x 1200).
+    tile_plan(S, B, K, N, true, 8, pl);            // the wave count of the sampling form of this shape
+    pl.R = 1;
+    pl.mt = 2;
+    pl.tiles = (N + 15) / 16;
+    pl.blocks = (long)pl.tiles * S * ((B + 31) / 32);
+    pl.lds = ((size_t)pl.nw * 2 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+    return BNN_OK;
+  }
+  const long gemm_blocks = (long)((N + 63) / 64) * S * mbs;
+  const bool gemm_ok = al && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && K >= 8;
+  const bool slice_ok = gemm_ok && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15);
+  int ksl = slice_ok ? kslices(gemm_blocks, K, N) : 1;
+  if (ksl > 1 && a->split_scratch_bytes < (size_t)ksl * S * B * N * sizeof(float)) ksl = 1;
+  // a->form is a preference: taken when the arguments allow that form, otherwise the plan's own choice
+  int form = a->form;
+  if ((form == BNN_FORM_GEMM && !gemm_ok) || (form == BNN_FORM_GEMM_KSLICE && ksl <= 1)) form = BNN_FORM_AUTO;
+  if (form == BNN_FORM_AUTO) {
+    if (gemm_ok && gemm_blocks >= kGemmMinBlocks) form = BNN_FORM_GEMM;
+    else if (ksl > 1 && (long)K * N >= kSliceMinWeights && gemm_blocks * ksl >= kSliceMinBlocks) form = BNN_FORM_GEMM_KSLICE;
+    else form = BNN_FORM_TILE;
+  }
+  if (form == BNN_FORM_TILE) {
+    tile_plan(S, B, K, N, al, 8, pl);
+    return BNN_OK;
+  }
+  pl.form = form;
+  pl.R = 1; pl.nw = 4; pl.mt = 8; pl.tiles = (N + 15) / 16;
+  pl.ksl = form == BNN_FORM_GEMM_KSLICE ? ksl : 1;
+  pl.blocks = gemm_blocks * pl.ksl;
+  pl.lds = 2 * 8 * 64 * 16 + 4 * 16 * sizeof(float);
+  return BNN_OK;
+}
+
 // Validate the arguments and fill the kernel parameter block.  `al` = the 16-byte vector path
 // applies (K % 8 == 0, aligned bases).
 static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
@@ -1125,6 +1115,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
   if ((double)a->n_samples * ((a->batch + 127) / 128) * ((a->out_features + 3) / 4) > 2.0e9) return BNN_ERR_SHAPE;
+  if (a->x_per_sample < 0) return BNN_ERR_SHAPE;
   const bool pre = a->w_sampled != nullptr;
   if (!a->x || !a->y) return BNN_ERR_NULL;
   if (!pre && (!a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho)) return BNN_ERR_NULL;
@@ -1136,7 +1127,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
     if (!aligned16(a->x) || !aligned16(a->w_sampled)) return BNN_ERR_ALIGN;
   }
   if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u ||
-      (unsigned)a->prior.kind > 1u)
+      (unsigned)a->prior.kind > 1u || (unsigned)a->form > 3u)
     return BNN_ERR_ENUM;
   if (!pre && a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
   if (a->want_stats) {
@@ -1147,6 +1138,8 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   if ((a->log_prior || a->log_q) && !a->want_stats) return BNN_ERR_WORKSPACE;
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
+  k.xg = a->x_per_sample > 0 ? a->x_per_sample : 1;
+  k.sgrp = a->sample_group; k.sgrp_stride = a->sample_group_stride;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.w_sigma = a->w_sigma;
   if (a->w_sigma && (reinterpret_cast<uintptr_t>(a->w_sigma) & 15)) return BNN_ERR_ALIGN;
@@ -1190,112 +1183,78 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   return BNN_OK;
 }
 
+extern "C" int bnn_bbb_plan(const bnn_bbb_fwd_args* a, bnn_plan* out) {
+  if (!out) return BNN_ERR_NULL;
+  BbbK k;
+  bool al = false;
+  int rc = prepare(a, k, al);
+  if (rc != BNN_OK) return rc;
+  BbbPlan pl{};
+  rc = bbb_plan(a, al, pl);
+  if (rc != BNN_OK) return rc;
+  out->form = pl.form;
+  out->k_classes = pl.R;
+  out->waves = pl.nw;
+  out->batch_rows = 16 * pl.mt;
+  out->k_slices = pl.ksl;
+  out->blocks = (int32_t)pl.blocks;
+  out->lds_bytes = (int32_t)pl.lds;
+  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : 64;
+  return BNN_OK;
+}
+
 extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   BbbK k;
   bool al = false;
-  const int rc = prepare(a, k, al);
+  int rc = prepare(a, k, al);
+  if (rc != BNN_OK) return rc;
+  BbbPlan pl{};
+  rc = bbb_plan(a, al, pl);
   if (rc != BNN_OK) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int K = a->in_features;
   const int xdt = a->x_dtype, math = a->math;
   hipError_t err = hipSuccess;
-  const int mbs = (a->batch + 127) / 128;
-  // Throughput form (block GEMM, x tile shared through LDS) once the launch has enough
-  // (feature-tile-group x sample) blocks to fill the chip several waves deep.
-  const long gemm_blocks = (long)((a->out_features + 63) / 64) * a->n_samples * mbs;
-  const int force = env_int("BNN_HIP_BBB_GEMM", -1);
-  // K-range slices for the GEMM form when a modest number of samples would leave the chip
-  // under-filled: slices write fp32 partial tiles into the caller's split scratch and a tiny
-  // reduce kernel sums them in slice order (deterministic), applies ReLU and the down-conversion.
-  int ksl = 1;
-  const int ksteps_g = (K + 31) / 32;
-  const size_t part_bytes = (size_t)a->n_samples * a->batch * a->out_features * sizeof(float);
-  if (a->split_scratch && gemm_blocks < 450) {
-    ksl = (int)((600 + gemm_blocks - 1) / gemm_blocks);
-    if (ksl > 8) ksl = 8;
-    if (ksl > ksteps_g / 4) ksl = ksteps_g / 4;
-    // the stats workspace has ceil(N/4) entries per sample; the sliced form uses T*ksl of them
-    const int max_ks = ((a->out_features + 3) / 4) / ((a->out_features + 15) / 16);
-    if (ksl > max_ks) ksl = max_ks;
-    const int fk = env_int("BNN_HIP_BBB_GEMM_KS", 0);
-    if (fk >= 1 && fk <= max_ks) ksl = fk;
-    if (ksl < 1) ksl = 1;
-    if (a->split_scratch_bytes < (size_t)ksl * part_bytes || (reinterpret_cast<uintptr_t>(a->split_scratch) & 15)) ksl = 1;
-  }
+  const dim3 grid((unsigned)(((pl.blocks + 7) / 8) * 8)), block(pl.nw * 64);
   if (a->w_sampled) {
-    // ---- matmul half only: same tile machinery, no generator work.  Two rebuilds of it measured slower and were
-    // dropped: every load of a wave issued in one round (10 waves x 2 steps of 64 k, 136 landing registers: 11.8
-    // against 8.7 us at 128 x 1200 x 1200), and a dedicated kernel whose blocks own 2 feature tiles x 4 batch tiles so
-    // that each fragment feeds more MFMAs (half the L2 -> L1 bytes: 6.1 against 5.2 us per two layers with four
-    // evaluations side by side).  What did help is below: 32-row batch blocks.
-    // Batch tiles per block: 2 (32 rows).  Without generator work a block's cost is the x it pulls through its CU's L1
-    // -- all of K for its rows -- so four times the blocks each ingest a quarter of it (BNN_HIP_PRE_MT=8: 128 rows).
-    const int mt = env_int("BNN_HIP_PRE_MT", 2) == 8 ? 8 : 2;
-    const int mbs_p = (a->batch + 16 * mt - 1) / (16 * mt);
-    Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, true, a->concurrency);
-    if (mt == 2 || pl.R > 2) {                           // enough blocks already: whole 16-feature tiles
-      pl.R = 1;
-      pl.tiles = (a->out_features + 15) / 16;
-    }
-    const int fr = env_int("BNN_HIP_PRE_R", 0), fw = env_int("BNN_HIP_PRE_WAVES", 0);
-    if (fr == 1 || fr == 2) {
-      pl.R = fr;
-      pl.tiles = (a->out_features + 16 / fr - 1) / (16 / fr);
-    }
-    if (fw >= 1 && fw <= 12) pl.nw = fw;
-    const long total = (long)pl.tiles * a->n_samples * mbs_p;
-    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-    const size_t lds = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
-#define BNN_PRE(XDT, RR, MTT)                                                                     \
+#define BNN_PRE(XDT)                                                                              \
   do {                                                                                            \
-    err = allow_big_lds(bbb_fwd_pre_kernel<XDT, RR, MTT>, lds);                                   \
+    err = allow_big_lds(bbb_fwd_pre_kernel<XDT, 1, 2>, pl.lds);                                   \
     if (err == hipSuccess)                                                                        \
-      hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, RR, MTT>), grid, block, lds, stream, k);        \
+      hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, 1, 2>), grid, block, pl.lds, stream, k);        \
   } while (0)
-#define BNN_PRE_R(XDT)                                               \
-  do {                                                               \
-    if (mt == 2) { if (pl.R == 1) BNN_PRE(XDT, 1, 2); else BNN_PRE(XDT, 2, 2); }  \
-    else { if (pl.R == 1) BNN_PRE(XDT, 1, 8); else BNN_PRE(XDT, 2, 8); }          \
-  } while (0)
-    if (xdt == BNN_F32) BNN_PRE_R(BNN_F32); else BNN_PRE_R(BNN_BF16);
+    if (xdt == BNN_F32) BNN_PRE(BNN_F32); else BNN_PRE(BNN_BF16);
 #undef BNN_PRE
-#undef BNN_PRE_R
     if (err != hipSuccess) return (int)err;
     err = hipGetLastError();
     return err == hipSuccess ? BNN_OK : (int)err;
   }
-  const bool gemm_ok = al && math == BNN_MATH_BF16 && xdt == BNN_BF16 && K >= 8;
-  const bool use_gemm = gemm_ok && (force == 1 || (force != 0 && (gemm_blocks >= 450 || (ksl > 1 && gemm_blocks * ksl >= 300))));
-  if (use_gemm) {
-    if (gemm_blocks >= 450 && !env_int("BNN_HIP_BBB_GEMM_KS", 0)) ksl = 1;
-    k.ksl = ksl;
+  if (pl.form != BNN_FORM_TILE) {
+    // Throughput form (block GEMM, x tile shared through LDS); K-range slices write fp32 partial tiles into the
+    // caller's split scratch and a tiny reduce kernel sums them in slice order (deterministic), applies ReLU and the
+    // down-conversion.
+    k.ksl = pl.ksl;
     k.ks_part = reinterpret_cast<float*>(a->split_scratch);
-    const long blocks = gemm_blocks * ksl;
-    const dim3 grid((unsigned)(((blocks + 7) / 8) * 8)), block(256);
     if (a->w_sigma)
       hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
     else
       hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
-    if (ksl > 1) {
+    if (pl.ksl > 1) {
       err = hipGetLastError();
       if (err != hipSuccess) return (int)err;
       const long cnt = (long)a->n_samples * a->batch * a->out_features;
       const int vec_ok = (cnt % 4 == 0) && !(reinterpret_cast<uintptr_t>(a->y) & 15);
       long nb = (cnt / 4 + 255) / 256;
       nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
-      hipLaunchKernelGGL(ks_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, k.ks_part, ksl, cnt, k.relu, a->y,
+      hipLaunchKernelGGL(ks_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, k.ks_part, pl.ksl, cnt, k.relu, a->y,
                          k.y_bf16, vec_ok);
     }
   } else {
-    const Plan pl = make_plan(a->n_samples, a->batch, K, a->out_features, al, a->concurrency);
-    const long total = (long)pl.tiles * a->n_samples * mbs;
-    const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-    const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
 #define BNN_GO(MATH, XDT, RR, AL)                                                              \
   do {                                                                                         \
-    err = allow_big_lds(bbb_fwd_kernel<MATH, XDT, RR, AL>, lds);                               \
+    err = allow_big_lds(bbb_fwd_kernel<MATH, XDT, RR, AL>, pl.lds);                            \
     if (err == hipSuccess)                                                                     \
-      hipLaunchKernelGGL((bbb_fwd_kernel<MATH, XDT, RR, AL>), grid, block, lds, stream, k);    \
+      hipLaunchKernelGGL((bbb_fwd_kernel<MATH, XDT, RR, AL>), grid, block, pl.lds, stream, k); \
   } while (0)
 #define BNN_GO_R(MATH, XDT)                                   \
   do {                                                        \
@@ -1340,67 +1299,7 @@ extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
 // Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
 // tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
 // the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
-// a plain layer that may ride in a combined launch: K1a tile form, bf16 math, vector path, nothing on the side
-static bool stage_ok(const bnn_bbb_fwd_args* l, bool al) {
-  const int mbs = (l->batch + 127) / 128;
-  const long gemm_blocks = (long)((l->out_features + 63) / 64) * l->n_samples * mbs;
-  return al && l->math == BNN_MATH_BF16 && !l->w_sampled && !l->split_scratch && !l->log_prior && !l->log_q &&
-         gemm_blocks < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1;
-}
-
-#define BNN_STAGE_LAUNCH(NEXT, PLR, GRID, BLOCK, LDS, ...)                                                     \
-  do {                                                                                                         \
-    if ((NEXT)->x_dtype == BNN_F32) {                                                                          \
-      if ((PLR) == 1) {                                                                                        \
-        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_F32, 1>, LDS);                                       \
-        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_F32, 1>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
-      } else {                                                                                                 \
-        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_F32, 2>, LDS);                                       \
-        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_F32, 2>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
-      }                                                                                                        \
-    } else {                                                                                                   \
-      if ((PLR) == 1) {                                                                                        \
-        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_BF16, 1>, LDS);                                      \
-        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_BF16, 1>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
-      } else {                                                                                                 \
-        err = allow_big_lds(bbb_fwd_final_next_kernel<BNN_BF16, 2>, LDS);                                      \
-        if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_final_next_kernel<BNN_BF16, 2>), GRID, BLOCK, LDS, stream, __VA_ARGS__); \
-      }                                                                                                        \
-    }                                                                                                          \
-  } while (0)
-
-// two independent plain layers (the hidden layer of one evaluation, the first layer of the next) in one launch
-static int stage_pair(const bnn_bbb_fwd_args* mid, const bnn_bbb_fwd_args* next, void* stream_) {
-  BbbK km, k1;
-  bool alm = false, al1 = false;
-  int rc = prepare(mid, km, alm);
-  if (rc != BNN_OK) return rc;
-  rc = prepare(next, k1, al1);
-  if (rc != BNN_OK) return rc;
-  const Plan plm = make_plan(mid->n_samples, mid->batch, mid->in_features, mid->out_features, true, mid->concurrency);
-  const Plan pl1 = make_plan(next->n_samples, next->batch, next->in_features, next->out_features, true, next->concurrency);
-  if (!(stage_ok(mid, alm) && stage_ok(next, al1) && mid->x_dtype == BNN_BF16 && plm.R == pl1.R && pl1.R <= 2 &&
-        env_int("BNN_HIP_FINAL_NEXT", 1) != 0)) {
-    rc = bnn_bbb_linear_fwd(mid, stream_);
-    return rc != BNN_OK ? rc : bnn_bbb_linear_fwd(next, stream_);
-  }
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const int nwc = plm.nw > pl1.nw ? plm.nw : pl1.nw;
-  const long totm = (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128);
-  const long tot1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
-  const dim3 grid((unsigned)(((totm + 7) & ~7L) + ((tot1 + 7) & ~7L))), block(nwc * 64);
-  const size_t lds = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc) * sizeof(float);
-  FinPack fp;
-  memset(&fp, 0, sizeof(fp));
-  hipError_t err = hipSuccess;
-  BNN_STAGE_LAUNCH(next, pl1.R, grid, block, lds, km, fp, km, k1, 0, (int)totm, (int)tot1, env_int("BNN_HIP_STAGE_PLAIN_ORDER", 1));
-  if (err != hipSuccess) return (int)err;
-  err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
-}
-
-static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* mid,
-                          const bnn_bbb_fwd_args* next, void* stream_) {
+extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
   BbbK k;
   bool al = false;
   int rc = prepare(a, k, al);
@@ -1413,15 +1312,11 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
                     f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
                     f->classes == a->out_features && f->batch == a->batch && a->y_dtype == BNN_F32 &&
                     (a->n_samples == 1 || a->n_samples > 16 || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
-                    env_int("BNN_HIP_FUSE_FINAL", 1) != 0;
+                    a->form == BNN_FORM_AUTO;
   if (!fuse) {
     rc = bnn_bbb_linear_fwd(a, stream_);
     if (rc != BNN_OK) return rc;
-    rc = bnn_elbo_finalize(f, stream_);
-    if (rc != BNN_OK) return rc;
-    if (mid && next) return stage_pair(mid, next, stream_);
-    if (mid) return bnn_bbb_linear_fwd(mid, stream_);
-    return next ? bnn_bbb_linear_fwd(next, stream_) : BNN_OK;
+    return bnn_elbo_finalize(f, stream_);
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   fp.sums = f->sums;
@@ -1444,8 +1339,6 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
     }
   }
   if ((long)a->n_samples * KS > 128) KS = 1;           // enough sample blocks already: skip the hand-off
-  const int forceKs = env_int("BNN_HIP_FINAL_KS", 0);
-  if (forceKs >= 1 && forceKs <= kFinalMaxSlices) KS = forceKs;
   if (KS > 1 && (!f->scratch || f->scratch_bytes < bnn_bbb_final_scratch_bytes(a->n_samples) ||
                  (reinterpret_cast<uintptr_t>(f->scratch) & 15)))
     KS = 1;
@@ -1464,48 +1357,6 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
   }
   const long total = (long)a->n_samples * KS;           // one tile, one batch block, KS slices
   hipError_t err = hipSuccess;
-  if (!next && mid) {                                  // one plain layer beside the output layer: same kernel, it rides as `next`
-    next = mid;
-    mid = nullptr;
-  }
-  if (next) {
-    // ---- combined launch with the next evaluation's first layer (and the hidden layer of the one between), when
-    // all take the plain tile forms
-    BbbK k1, km;
-    bool al1 = false, alm = false;
-    rc = prepare(next, k1, al1);
-    if (rc != BNN_OK) return rc;
-    if (mid) {
-      rc = prepare(mid, km, alm);
-      if (rc != BNN_OK) return rc;
-    }
-    const bool combine = !tail_kernel && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && stage_ok(next, al1) &&
-                         env_int("BNN_HIP_FINAL_NEXT", 1) != 0;
-    if (combine) {
-      const Plan pl1 = make_plan(next->n_samples, next->batch, next->in_features, next->out_features, true, next->concurrency);
-      Plan plm = pl1;
-      bool mid_in = false;
-      if (mid) {
-        plm = make_plan(mid->n_samples, mid->batch, mid->in_features, mid->out_features, true, mid->concurrency);
-        mid_in = stage_ok(mid, alm) && mid->x_dtype == BNN_BF16 && plm.R == pl1.R;
-      }
-      if (pl1.R <= 2) {
-        int nwc = pl1.nw > nw ? pl1.nw : nw;
-        if (mid_in && plm.nw > nwc) nwc = plm.nw;
-        const long total1 = (long)pl1.tiles * next->n_samples * ((next->batch + 127) / 128);
-        const long totalm = mid_in ? (long)plm.tiles * mid->n_samples * ((mid->batch + 127) / 128) : 0;
-        const dim3 gridc((unsigned)(((total + 7) & ~7L) + ((totalm + 7) & ~7L) + ((total1 + 7) & ~7L))), blockc(nwc * 64);
-        const size_t ldsc = ((size_t)nwc * 8 * 64 * 4 + 16 + 3 * nwc + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
-        if (!mid_in) km = k1;
-        BNN_STAGE_LAUNCH(next, pl1.R, gridc, blockc, ldsc, k, fp, km, k1, (int)total, (int)totalm, (int)total1,
-                         env_int("BNN_HIP_STAGE_PLAIN_ORDER", 1));
-        if (err != hipSuccess) return (int)err;
-        err = hipGetLastError();
-        if (err != hipSuccess) return (int)err;
-        return (mid && !mid_in) ? bnn_bbb_linear_fwd(mid, stream_) : BNN_OK;
-      }
-    }
-  }
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
   const size_t lds = ((size_t)nw * 8 * 64 * 4 + 16 + 3 * nw + 128 * 16 + kFinMaxWaves * kFinNV) * sizeof(float);
 #define BNN_FIN(MATH, XDT)                                                                     \
@@ -1523,99 +1374,7 @@ static int final_fwd_impl(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f,
   if (err != hipSuccess) return (int)err;
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  if (tail_kernel) {
-    rc = bnn_elbo_sums_(f, stream_);
-    if (rc != BNN_OK) return rc;
-  }
-  if (mid && next) return stage_pair(mid, next, stream_);
-  if (mid) return bnn_bbb_linear_fwd(mid, stream_);
-  return next ? bnn_bbb_linear_fwd(next, stream_) : BNN_OK;
-}
-
-extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
-  return final_fwd_impl(a, f, nullptr, nullptr, stream_);
-}
-
-// One stage of a software pipeline over independent evaluations: any of {output layer + finalize of evaluation j,
-// hidden layer of evaluation j+1, first layer of evaluation j+2} in ONE launch (see include/bnn_hip.h).
-extern "C" int bnn_bbb_stage_fwd(const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* mid,
-                                 const bnn_bbb_fwd_args* first, void* stream_) {
-  if ((last == nullptr) != (fin == nullptr)) return BNN_ERR_NULL;
-  if (last) return final_fwd_impl(last, fin, mid, first, stream_);
-  if (mid && first) return stage_pair(mid, first, stream_);
-  if (mid) return bnn_bbb_linear_fwd(mid, stream_);
-  if (first) return bnn_bbb_linear_fwd(first, stream_);
-  return BNN_ERR_NULL;
-}
-
-// bnn_bbb_final_fwd(last, fin) and bnn_bbb_linear_fwd(next_first) -- the first layer of the NEXT, independent
-// evaluation -- in one launch when both take their plain tile forms; the two calls otherwise.
-extern "C" int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, const bnn_bbb_fwd_args* next,
-                                      void* stream_) {
-  if (!next) return BNN_ERR_NULL;
-  return final_fwd_impl(a, f, nullptr, next, stream_);
-}
-
-// The last hidden layer + the output layer + finalize of a ONE-sample evaluation in one launch (K1d) when the
-// shapes allow it and BNN_HIP_FUSE_TAIL2=1; otherwise bnn_bbb_linear_fwd(hidden) followed by
-// bnn_bbb_final_fwd(last, fin).  OFF by default: measured on MI355X the single block that inherits the output
-// layer (38 k-steps over its 12 waves, all of the hidden activations through one CU's L1) takes longer than the
-// dependent launch of five K-slice blocks it replaces: 47.0 against 40.3 us per evaluation alone, 13.8 against
-// 11.7 us with four in flight.
-extern "C" int bnn_bbb_tail2_fwd(const bnn_bbb_fwd_args* hidden, const bnn_bbb_fwd_args* last, const bnn_finalize_args* f,
-                                 void* stream_) {
-  BbbK k2, k3;
-  bool al2 = false, al3 = false;
-  int rc = prepare(hidden, k2, al2);
-  if (rc != BNN_OK) return rc;
-  rc = prepare(last, k3, al3);
-  if (rc != BNN_OK) return rc;
-  FinPack fp;
-  rc = make_fin(f, fp.k, fp.c);
-  if (rc != BNN_OK) return rc;
-  const int nl = f->n_layers;
-  const long gemm_blocks = (long)((hidden->out_features + 63) / 64) * hidden->n_samples * ((hidden->batch + 127) / 128);
-  const bool fuse =
-      env_int("BNN_HIP_FUSE_TAIL2", 0) != 0 && f->ticket != nullptr && hidden->n_samples == 1 && last->n_samples == 1 &&
-      f->n_samples == 1 && nl >= 2 && al2 && al3 && hidden->math == BNN_MATH_BF16 && last->math == BNN_MATH_BF16 &&
-      hidden->x_dtype == BNN_BF16 && hidden->y_dtype == BNN_BF16 && last->x_dtype == BNN_BF16 && last->x == hidden->y &&
-      last->x_per_sample == 1 && last->in_features == hidden->out_features && last->batch == hidden->batch &&
-      hidden->batch <= 128 && last->out_features <= 16 && hidden->want_stats && last->want_stats && !f->local_reparam &&
-      f->layer_workspace[nl - 1] == last->workspace && f->layer_workspace[nl - 2] == hidden->workspace &&
-      f->classes == last->out_features && f->batch == last->batch && last->y_dtype == BNN_F32 &&
-      !(hidden->log_prior || hidden->log_q || last->log_prior || last->log_q) && !hidden->split_scratch &&
-      gemm_blocks < 450 && env_int("BNN_HIP_BBB_GEMM", -1) != 1;
-  if (!fuse) {
-    rc = bnn_bbb_linear_fwd(hidden, stream_);
-    if (rc != BNN_OK) return rc;
-    return bnn_bbb_final_fwd(last, f, stream_);
-  }
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  fp.sums = f->sums;
-  fp.ticket = nullptr;                                  // one sample: the finalising block writes the sums itself
-  fp.ks = 1;
-  fp.ks_ticket = nullptr;
-  fp.ks_stats = nullptr;
-  fp.ks_tiles = nullptr;
-  const Plan pl = make_plan(1, hidden->batch, hidden->in_features, hidden->out_features, true, hidden->concurrency);
-  const long total = (long)pl.tiles;                    // one sample, one batch block
-  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw + 128 * 16 + kFinMaxWaves * kFinNV + 2) * sizeof(float);
-  hipError_t err = hipSuccess;
-#define BNN_T2(RR)                                                                                                   \
-  do {                                                                                                               \
-    err = allow_big_lds(bbb_fwd_tail2_kernel<BNN_MATH_BF16, RR>, lds);                                               \
-    if (err == hipSuccess)                                                                                           \
-      hipLaunchKernelGGL((bbb_fwd_tail2_kernel<BNN_MATH_BF16, RR>), grid, block, lds, stream, k2, k3, fp, f->ticket, \
-                         (uint32_t)total);                                                                           \
-  } while (0)
-  if (pl.R == 1) BNN_T2(1);
-  else if (pl.R == 2) BNN_T2(2);
-  else BNN_T2(4);
-#undef BNN_T2
-  if (err != hipSuccess) return (int)err;
-  err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
+  return tail_kernel ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
 }
 
 // gx[S,B,K] = gz[S,B,N] . w_s with w regenerated (TRANS form of the K-split kernel).  Called by
@@ -1641,16 +1400,18 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = 0; k.relu = 0; k.y_bf16 = 0; k.spb = 1;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
+  k.xg = 1; k.sgrp = 0u; k.sgrp_stride = 0u;
   k.inv2var1 = k.inv2var2 = k.c1 = k.c2 = k.pi = 0.f;
 #ifdef BNN_STAMPS
   k.dbg = nullptr;
 #endif
   if ((a->in_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->g_x) & 15)) return BNN_ERR_ALIGN;
   const bool al = (k.K % 8 == 0) && aligned16(gz);
-  const Plan pl = make_plan(k.S, k.B, k.K, k.N, al);
-  const long total = (long)pl.tiles * k.S * ((k.B + 127) / 128);
+  BbbPlan pl{};
+  tile_plan(k.S, k.B, k.K, k.N, al, 8, pl);
+  const long total = pl.blocks;
   const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(pl.nw * 64);
-  const size_t lds = ((size_t)pl.nw * 8 * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
+  const size_t lds = pl.lds;
   hipError_t err = hipSuccess;
 #define BNN_IG(MATH, RR, AL)                                                                    \
   do {                                                                                          \
@@ -1675,12 +1436,10 @@ extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, v
     if (a->math != BNN_MATH_BF16) return BNN_ERR_ENUM;   // the sampled weights are the bf16 operands of that mode
     // 128-row batch blocks here: a lane's 8 reduction-consecutive weights are 8 strided 2-byte loads in this
     // direction, and 32-row blocks would repeat them four times (28.8 against 21.4 us at 2 x 128 x 1200 x 1200)
-    const int mt = env_int("BNN_HIP_PRE_MT_BWD", 8) == 2 ? 2 : 8;
-    const long totalp = (long)((k.N + 15) / 16) * k.S * ((k.B + 16 * mt - 1) / (16 * mt));
+    const long totalp = (long)((k.N + 15) / 16) * k.S * ((k.B + 127) / 128);
     const dim3 gridp((unsigned)(((totalp + 7) / 8) * 8));
-    const size_t ldsp = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
-    if (mt == 2) { if (!al) BNN_IGP(1, false, 2); else BNN_IGP(1, true, 2); }
-    else { if (!al) BNN_IGP(1, false, 8); else BNN_IGP(1, true, 8); }
+    const size_t ldsp = pl.lds;
+    if (!al) BNN_IGP(1, false, 8); else BNN_IGP(1, true, 8);
   } else if (a->math == BNN_MATH_BF16) BNN_IG_R(BNN_MATH_BF16); else BNN_IG_R(BNN_MATH_F32);
 #undef BNN_IGP
 #undef BNN_IG

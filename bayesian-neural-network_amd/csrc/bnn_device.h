@@ -129,19 +129,6 @@ __device__ __forceinline__ bool xcd_work_item(int total, int& item) {
   return (b >> 3) < chunk && item < total;
 }
 
-// The same order inside one block range of a grid that holds several independent pieces (pipeline-stage kernels):
-// `b_local` = block index relative to the range's start, which the launcher puts on a multiple of 8 and pads to a
-// multiple of 8 blocks, so b_local & 7 is still the XCD the block runs on.  False for the padding blocks.
-__device__ __forceinline__ bool xcd_piece_item(int b_local, int total, int& item, int plain = 0) {
-  if (plain) {                                            // diagnostic: block order = item order
-    item = b_local;
-    return b_local < total;
-  }
-  const int chunk = (total + 7) >> 3;
-  item = (b_local & 7) * chunk + (b_local >> 3);
-  return (b_local >> 3) < chunk && item < total;
-}
-
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
 // the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
 __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,
@@ -171,14 +158,5 @@ __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __
     }
   }
 }
-
-// An independent cast that rides on another launch as extra blocks (K4's finalize, K3e's pipeline stage): the NEXT evaluation's input batch.
-struct CastJob {
-  const float* src;
-  __bf16* dst;
-  __bf16* dsq;
-  long n;
-  int vec_ok;
-};
 
 }  // namespace bnn

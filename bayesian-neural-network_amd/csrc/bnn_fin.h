@@ -20,8 +20,8 @@ struct FinK {
   float *log_prior, *log_q, *kl, *nll;
   uint32_t* sample_counter;
   uint32_t sample_counter_inc;
-  uint32_t* ring_pos;            // optional slot cursor of the sums ring (bnn_finalize_args.sums_ring_pos)
-  uint32_t ring_len, ring_stride;
+  int group;                     // MC samples per minibatch when the launch holds several (0: one evaluation)
+  long tgt_stride;               // elements between the targets of consecutive minibatches (0: one target for all)
 };
 
 // All transcendental constants of the priors, precomputed on the host in fp64.
@@ -53,7 +53,8 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
     }
   }
   if (a->n_layers > 0 && !(a->prior.kind == BNN_PRIOR_MIXTURE) && !(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
-  if (a->sums_ring_pos && (!a->sums || a->sums_ring_len == 0 || a->sums_ring_stride < 4)) return BNN_ERR_SHAPE;
+  if (a->group_samples < 0 || (a->group_samples > 0 && a->n_samples % a->group_samples != 0)) return BNN_ERR_SHAPE;
+  if (a->target_per_group && a->group_samples <= 0) return BNN_ERR_SHAPE;
   if (a->nll) {
     if (!a->logits || !a->target) return BNN_ERR_NULL;
     if (a->batch <= 0 || a->classes <= 0) return BNN_ERR_SHAPE;
@@ -63,7 +64,9 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
   k.prior = a->prior; k.logits = a->logits; k.target = a->target; k.nll_mode = a->nll_mode;
   k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
   k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
-  k.ring_pos = a->sums_ring_pos; k.ring_len = a->sums_ring_len; k.ring_stride = a->sums_ring_stride;
+  k.group = a->group_samples;
+  k.tgt_stride = a->target_per_group
+                     ? (a->nll_mode == BNN_NLL_CLASSIFICATION ? (long)a->batch : (long)a->batch * a->classes) : 0;
   const double c0 = -0.91893853320467274178;
   const double sp = (a->prior.kind == BNN_PRIOR_MIXTURE) ? 1.0 : (double)a->prior.sigma_p;
   for (int l = 0; l < 8; ++l) cst.cnt_c0[l] = cst.lp_const[l] = cst.kl_const[l] = 0.0;
@@ -122,7 +125,7 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   if (p.nll && lg) {
     float acc = 0.f;
     if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
-      const long long* tgt = reinterpret_cast<const long long*>(p.target);
+      const long long* tgt = reinterpret_cast<const long long*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
       if (p.C <= 32) {                           // a thread per row
         for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
           const float* row = lg + (size_t)b * ldc;
@@ -157,7 +160,7 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
             for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
             se = logf(se);
           }
-          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
+          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
           acc += (mx + se) - picked;
         }
       } else {                                   // a wave per row, lanes stride over the classes
@@ -175,13 +178,13 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
           se = wave_sum(se);
           if (lane == 0) {
             const long long tc = tgt[b];
-            const float picked = (tc >= 0 && tc < p.C) ? row[tc] : 0.f;
+            const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
             acc += (mx + logf(se)) - picked;
           }
         }
       }
     } else {
-      const float* tgt = reinterpret_cast<const float*>(p.target);
+      const float* tgt = reinterpret_cast<const float*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
       if (p.C <= 8) {                            // a thread per row (the 1-output regression net)
         for (int b = threadIdx.x; b < p.B; b += blockDim.x)
           for (int cc = 0; cc < p.C; ++cc) {
@@ -282,12 +285,21 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   }
 }
 
-// Where this evaluation's 4-vector of sums goes; called by the ONE thread that writes it.
-__device__ __forceinline__ float* fin_sums_slot(const FinK& p, float* sums) {
-  if (!sums || !p.ring_pos) return sums;
-  const uint32_t k = *p.ring_pos;
-  *p.ring_pos = (k + 1u >= p.ring_len) ? 0u : k + 1u;
-  return sums + (size_t)k * p.ring_stride;
+// The 4-vector(s) of sums from the per-sample scalars, in sample order (one thread; the callers make the scalars
+// of all samples visible first): one vector, or one per minibatch of `group` samples.
+__device__ __forceinline__ void fin_fold_sums(const FinK& p, float* sums) {
+  const int g = p.group > 0 ? p.group : p.S;
+  const float* pa = p.local_reparam ? p.kl : p.log_prior;
+  for (int m = 0; m * g < p.S; ++m) {
+    double ta = 0, tb = 0, tn = 0;
+    for (int i = m * g; i < (m + 1) * g; ++i) {
+      if (pa) ta += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!p.local_reparam && p.log_q) tb += __hip_atomic_load(p.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.nll) tn += __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float* so = sums + 4 * m;
+    so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)g;
+  }
 }
 
 __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b, float nll) {
@@ -298,39 +310,6 @@ __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b
     if (p.log_q) p.log_q[s] = b;
   }
   if (p.nll) p.nll[s] = nll;
-}
-
-// The one-block form of K4 as a device function (a pipeline-stage kernel runs it beside the layers of later
-// evaluations): walks all samples, stores the per-sample scalars, then the 4-vector of sums, and advances the counter.
-// `part`: LDS scratch as for fin_sample.
-__device__ __forceinline__ void fin_single_block(const FinK& p, const FinC& cst, float* sums, float* part) {
-  int T[8];
-#pragma unroll
-  for (int l = 0; l < 8; ++l)
-    T[l] = (l < p.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(p.ws[l])[0].x) : 0;
-  double tot_a = 0, tot_b = 0, tot_n = 0;
-  for (int s = 0; s < p.S; ++s) {
-    float a = 0.f, b = 0.f, nll = 0.f;
-    const float* lg = p.logits ? p.logits + (size_t)s * p.B * p.C : nullptr;
-    fin_sample(p, cst, s, T, lg, p.C, -1, 0.f, 0.f, 0.f, part, a, b, nll);
-    if (threadIdx.x == 0) {
-      fin_store(p, s, a, b, nll);
-      tot_a += a;
-      tot_b += b;
-      tot_n += nll;
-    }
-    if (s + 1 < p.S) __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (sums) {
-      float* so = fin_sums_slot(p, sums);
-      so[0] = (float)tot_a;
-      so[1] = (float)tot_b;
-      so[2] = (float)tot_n;
-      so[3] = (float)p.S;
-    }
-    if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
-  }
 }
 
 }  // namespace bnn

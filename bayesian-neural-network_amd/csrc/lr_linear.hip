@@ -48,10 +48,20 @@ struct LrK {
   int eps_mode, want_kl, relu, y_bf16;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
+  int xg;                        // samples sharing one x (x index = s / xg)
+  uint32_t sgrp, sgrp_stride;    // sample groups (bnn_lr_fwd_args.sample_group): 0 = none
 #ifdef BNN_STAMPS
   unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
 #endif
 };
+
+// global MC sample index (Philox subsequence) of local sample s
+__device__ __forceinline__ uint32_t lr_global_sample(const LrK& p, int s) {
+  const uint32_t base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
+  if (p.sgrp == 0u) return base + (uint32_t)s;
+  const uint32_t g = (uint32_t)s / p.sgrp;
+  return base + g * p.sgrp_stride + ((uint32_t)s - g * p.sgrp);
+}
 
 #ifdef BNN_STAMPS
 #define LR_STAMP(i)                                                              \
@@ -70,10 +80,8 @@ struct LrK {
 // MT = batch tiles (of 16 rows) per block: 8, or 2 for a narrow layer (the 10-class output layer is
 // 3 feature tiles: with 128 rows per block three blocks would each ingest all of x; 32-row blocks
 // make 12 of them, each with a quarter of x, 8 accumulators and room for 12 waves).
-// `forced_item` >= 0 runs that work item whatever the block index is (the stage kernel below places several layers'
-// blocks in one grid).
 template <int MATH, int XDT, int R, int MT>
-__device__ __forceinline__ void lr_fwd_body(const LrK& p, int forced_item) {
+__device__ __forceinline__ void lr_fwd_body(const LrK& p) {
   constexpr int F = 16 / R, FG = F / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -81,8 +89,8 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p, int forced_item) {
   const int c = r / F, f = r % F;
   const int K = p.K, N = p.N, B = p.B;
   const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
-  int item = forced_item;
-  if (forced_item < 0 && !xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
+  int item;
+  if (!xcd_work_item(ntiles * p.S * mbs, item)) return;       // block-uniform
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
   const int n = nt * F + f;
   const bool n_ok = n < N;
@@ -90,10 +98,10 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p, int forced_item) {
   const int m0 = mb * 16 * MT;
   const int mtiles = min(MT, (B - m0 + 15) >> 4);
   const int ssteps = (K + 32 * R - 1) / (32 * R);
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const uint32_t gs = lr_global_sample(p, s);
   const bool do_kl = p.want_kl && mb == 0 && s == 0;
   const bool x_al = (K & 7) == 0;                             // 16-byte x fragments possible
-  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)s * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
 
   f32x4* slab = reinterpret_cast<f32x4*>(lds);
   float* lds_bias = lds + (size_t)nw * MT * 64 * 4;
@@ -408,46 +416,7 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p, int forced_item) {
 
 template <int MATH, int XDT, int R, int MT>
 __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p) {
-  lr_fwd_body<MATH, XDT, R, MT>(p, -1);
-}
-
-// K3e  one stage of the evaluation pipeline for the MNIST-shaped LR net (see K1e in bbb_linear.hip): the narrow output
-// layer of evaluation j (R = 4 feature classes, 32-row blocks), the hidden layer of evaluation j + 1 and the first
-// layer of evaluation j + 2 (whole 16-feature tiles, 128-row blocks) as three block ranges of ONE grid of 8-wave
-// blocks.  Independent pieces: the caller keeps their buffers apart and gives each a static sample offset.
-// Two more independent pieces may ride: the finalize of evaluation j - 1 (one block: K4's one-block form) and the input
-// cast of evaluation j + 3 -- then an LR evaluation is ONE launch in steady state.
-struct LrStageExtra {
-  FinK fk;
-  FinC fc;
-  float* sums;
-  CastJob cj;
-  int nfin;     // 0 or 1
-  int plain;    // diagnostic: block order = item order inside the layers' ranges
-};
-
-__global__ __launch_bounds__(512) void lr_stage_kernel(const LrK p2, const LrK p1, const LrK p0, int n2, int n1, int n0,
-                                                       const LrStageExtra ex) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int b = (int)blockIdx.x;
-  // every layer's block range starts on, and is padded to, a multiple of 8 blocks: the XCD-aware work order of the
-  // stand-alone launches holds inside each range (neighbouring feature tiles share the 128-byte lines of the gathered
-  // [in,out] weights: on one XCD's L2 they are fetched once, spread over the XCDs every tile fetched its own copy --
-  // 45 MB over the fabric per stage against 20.6 MB algorithmic)
-  const int e2 = (n2 + 7) & ~7, e1 = e2 + ((n1 + 7) & ~7), e0 = e1 + ((n0 + 7) & ~7);
-  int item;
-  if (b < e2) {
-    if (xcd_piece_item(b, n2, item, ex.plain)) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 4, 2>(p2, item);
-  } else if (b < e1) {
-    if (xcd_piece_item(b - e2, n1, item, ex.plain)) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p1, item);
-  } else if (b < e0) {
-    if (xcd_piece_item(b - e1, n0, item, ex.plain)) lr_fwd_body<BNN_MATH_BF16, BNN_BF16, 1, 8>(p0, item);
-  } else if (b < e0 + ex.nfin) fin_single_block(ex.fk, ex.fc, ex.sums, lds);
-  else {
-    const int first = e0 + ex.nfin;
-    cast_bf16_span(ex.cj.src, ex.cj.dst, ex.cj.dsq, ex.cj.n, ex.cj.vec_ok, (long)(b - first) * blockDim.x + threadIdx.x,
-                   (long)((int)gridDim.x - first) * blockDim.x);
-  }
+  lr_fwd_body<MATH, XDT, R, MT>(p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -541,10 +510,10 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
   const int nc = min(n, N - 1);
   const int m0 = mb * 128;
   const int ksteps = (K + 31) >> 5;
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
+  const uint32_t gs = lr_global_sample(p, s);
   const bool do_kl = !PREP && p.want_kl && mb == 0 && s == 0;   // PREP: the prepare pass owns the KL sums
-  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)s * (size_t)p.x_sstride;
-  const __bf16* xq = reinterpret_cast<const __bf16*>(p.x_sq) + (size_t)s * (size_t)p.x_sstride;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+  const __bf16* xq = reinterpret_cast<const __bf16*>(p.x_sq) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
   const int T = (N + 15) >> 4;
   if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
 
@@ -799,11 +768,6 @@ extern "C" size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features) {
   return (1 + (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
 }
 
-static int lr_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 extern "C" size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features) {
   if (in_features <= 0 || out_features <= 0) return 0;
   return (size_t)((out_features + 15) / 16) * (size_t)((in_features + 31) / 32) * 128 * 16;
@@ -850,6 +814,8 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   if ((a->in_features % 8 == 0) && (reinterpret_cast<uintptr_t>(a->x) & 15)) return BNN_ERR_ALIGN;
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
+  k.xg = a->x_per_sample > 0 ? a->x_per_sample : 1;
+  k.sgrp = a->sample_group; k.sgrp_stride = a->sample_group_stride;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
@@ -869,118 +835,99 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   return BNN_OK;
 }
 
-// tile plan of the K3a form: a function of the shape (and the concurrency hint) only
+// Launch geometry of K3: a pure function of the shape and of what the arguments allow (bnn_lr_plan exports it).
 struct LrPlan {
-  int R, MT, nw;
+  int form;         // BNN_FORM_TILE (K3a) or BNN_FORM_GEMM (K3b)
+  int R, MT, nw;    // K3a: k-range classes, 16-row batch tiles per block, waves;  K3b: nw = 4 or 8
   long total;       // blocks
-  bool gemm;        // the launch would take the K3b block-GEMM form instead
+  size_t lds;
 };
 
-static LrPlan lr_plan(const bnn_lr_fwd_args* a) {
-  LrPlan pl{};
+static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
   const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
-  const int force = lr_env_int("BNN_HIP_LR_GEMM", -1);
+  // K3b needs bf16 x AND x^2 streams; the saved variance (v_out) is a K3a epilogue
   const bool can = !a->v_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
-  pl.gemm = can && (force == 1 || (force != 0 && gemm_blocks >= 300));
-  int R = 1;
-  const long want_blocks = 120 / (a->concurrency > 1 ? a->concurrency : 1);
-  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < want_blocks) R *= 2;
-  const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
-  if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
-  const int F = 16 / R;
-  const int ssteps = (K + 32 * R - 1) / (32 * R);
-  int MT = ((long)((N + F - 1) / F) * a->n_samples * mbs < 64 && N <= 64 && a->batch > 32) ? 2 : 8;
-  const int forceMT = lr_env_int("BNN_HIP_LR_MT", 0);
-  if (forceMT == 2 || forceMT == 8) MT = forceMT;
-  const int max_nw = MT == 2 ? 12 : 8;
-  int spw = 1;
-  while ((ssteps + spw - 1) / spw > max_nw) ++spw;
-  int nw = (ssteps + spw - 1) / spw;
-  nw = nw < 1 ? 1 : nw;
-  if (ssteps >= 4 && lr_env_int("BNN_HIP_LR_WAVES4", 1)) nw = (ssteps >= max_nw ? max_nw : ssteps) & ~3;
-  const int mt = a->batch >= 16 * MT ? MT : (a->batch + 15) / 16;
-  const int need = (mt * 16 * (F / 4) + 127) / 128;
-  if (nw < need) nw = need;
-  pl.R = R; pl.MT = MT; pl.nw = nw;
-  pl.total = (long)((N + F - 1) / F) * a->n_samples * ((a->batch + 16 * MT - 1) / (16 * MT));
-  return pl;
-}
-
-extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
-  LrK k;
-  {
-    const int rc = lr_fill(a, k);
-    if (rc != BNN_OK) return rc;
-  }
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-
-  // launch geometry: a function of the shape only
-  const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
-  hipError_t err = hipSuccess;
-  {
-    const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
-    const int force = lr_env_int("BNN_HIP_LR_GEMM", -1);
-    const bool can = !a->v_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
-                     !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
-    if (can && (force == 1 || (force != 0 && gemm_blocks >= 300))) {
-      const dim3 grid((unsigned)(((gemm_blocks + 7) / 8) * 8)), block(256);
-      if (a->w_frag) {
-        if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
-        if (lr_env_int("BNN_HIP_LR_NW8", 1) && N >= 128) {
-          // 8 waves share each x / x^2 tile: twice the MFMA work per LDS-DMA round trip
-          const long blocks8 = (long)((N + 127) / 128) * a->n_samples * mbs;
-          hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true>), dim3((unsigned)(((blocks8 + 7) / 8) * 8)), dim3(512), 0, stream, k);
-        } else {
-          hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
-        }
-      } else {
-        hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
-      }
-      err = hipGetLastError();
-      if (err != hipSuccess) return (int)err;
-      if (a->kl_out) {
-        hipLaunchKernelGGL(lr_layer_kl_kernel, dim3(1), dim3(256), 0, stream, k.ws, K, N, a->sigma_p, a->b_mu, a->b_rho,
-                           a->kl_out);
-        err = hipGetLastError();
-        if (err != hipSuccess) return (int)err;
-      }
-      return BNN_OK;
-    }
+  // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
+  if (can && (a->form == BNN_FORM_GEMM || (a->form == BNN_FORM_AUTO && gemm_blocks >= 300))) {
+    pl.form = BNN_FORM_GEMM;
+    pl.R = 1; pl.MT = 8;
+    // prepared fragments, wide layer: 8 waves share each x / x^2 tile (twice the MFMA work per LDS-DMA round trip)
+    pl.nw = (a->w_frag && N >= 128) ? 8 : 4;
+    pl.total = (long)((N + 16 * pl.nw - 1) / (16 * pl.nw)) * a->n_samples * mbs;
+    pl.lds = 2 * 2 * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);
+    return BNN_OK;
   }
   int R = 1;
-  const long want_blocks = 120 / (a->concurrency > 1 ? a->concurrency : 1);   // a 1/n share of the chip, see make_plan (bbb_linear.hip)
-  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < want_blocks) R *= 2;
-  const int forceR = lr_env_int("BNN_HIP_LR_R", 0);
-  if (forceR == 1 || forceR == 2 || forceR == 4) R = forceR;
+  while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
   const int F = 16 / R;
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   // a narrow layer in few samples: 32-row blocks (MT = 2), so that more than a handful of blocks exist
   // and each ingests a quarter of x; its weights are small enough that re-reading them per block is free
-  int MT = ((long)((N + F - 1) / F) * a->n_samples * mbs < 64 && N <= 64 && a->batch > 32) ? 2 : 8;
-  const int forceMT = lr_env_int("BNN_HIP_LR_MT", 0);
-  if (forceMT == 2 || forceMT == 8) MT = forceMT;
+  const int MT = ((long)((N + F - 1) / F) * a->n_samples * mbs < 64 && N <= 64 && a->batch > 32) ? 2 : 8;
   const int max_nw = MT == 2 ? 12 : 8;
   int spw = 1;
   while ((ssteps + spw - 1) / spw > max_nw) ++spw;
   int nw = (ssteps + spw - 1) / spw;
   nw = nw < 1 ? 1 : nw;
   // a CU has 4 SIMDs: keep the waves of a block a multiple of 4 so no SIMD carries one more than the others
-  // (as many as there are k-steps, up to the limit) -- see make_plan in bbb_linear.hip
-  if (ssteps >= 4 && lr_env_int("BNN_HIP_LR_WAVES4", 1)) nw = (ssteps >= max_nw ? max_nw : ssteps) & ~3;
-  {
-    // the epilogue gives every thread at most 2 output items (batch row x 4 features): a short k range
-    // must not leave the block with fewer threads than that needs (extra waves own no k-step and
-    // contribute zero slabs)
-    const int mt = a->batch >= 16 * MT ? MT : (a->batch + 15) / 16;
-    const int need = (mt * 16 * (F / 4) + 127) / 128;
-    if (nw < need) nw = need;
-  }
-  const int mbs_t = (a->batch + 16 * MT - 1) / (16 * MT);
-  const long total = (long)((N + F - 1) / F) * a->n_samples * mbs_t;
-  const dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(nw * 64);
-  const size_t lds = ((size_t)nw * MT * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+  // (as many as there are k-steps, up to the limit) -- see tile_plan in bbb_linear.hip
+  if (ssteps >= 4) nw = (ssteps >= max_nw ? max_nw : ssteps) & ~3;
+  // the epilogue gives every thread at most 2 output items (batch row x 4 features): a short k range
+  // must not leave the block with fewer threads than that needs (extra waves own no k-step and
+  // contribute zero slabs)
+  const int mt = a->batch >= 16 * MT ? MT : (a->batch + 15) / 16;
+  const int need = (mt * 16 * (F / 4) + 127) / 128;
+  if (nw < need) nw = need;
+  pl.form = BNN_FORM_TILE;
+  pl.R = R; pl.MT = MT; pl.nw = nw;
+  pl.total = (long)((N + F - 1) / F) * a->n_samples * ((a->batch + 16 * MT - 1) / (16 * MT));
+  pl.lds = ((size_t)nw * MT * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+  return BNN_OK;
+}
+
+extern "C" int bnn_lr_plan(const bnn_lr_fwd_args* a, bnn_plan* out) {
+  if (!out) return BNN_ERR_NULL;
+  LrK k;
+  int rc = lr_fill(a, k);
+  if (rc != BNN_OK) return rc;
+  LrPlan pl{};
+  rc = lr_plan(a, pl);
+  if (rc != BNN_OK) return rc;
+  out->form = pl.form;
+  out->k_classes = pl.R;
+  out->waves = pl.nw;
+  out->batch_rows = 16 * pl.MT;
+  out->k_slices = 1;
+  out->blocks = (int32_t)pl.total;
+  out->lds_bytes = (int32_t)pl.lds;
+  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : 16 * pl.nw;
+  return BNN_OK;
+}
+
+extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
+  LrK k;
+  int rc = lr_fill(a, k);
+  if (rc != BNN_OK) return rc;
+  LrPlan pl{};
+  rc = lr_plan(a, pl);
+  if (rc != BNN_OK) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int K = a->in_features, N = a->out_features;
+  hipError_t err = hipSuccess;
+  const dim3 grid((unsigned)(((pl.total + 7) / 8) * 8)), block(pl.nw * 64);
+  if (pl.form == BNN_FORM_GEMM) {
+    if (a->w_frag) {
+      if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
+      if (pl.nw == 8) hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true>), grid, block, 0, stream, k);
+      else hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+    } else {
+      hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
+    }
+  } else {
+    const int R = pl.R, MT = pl.MT;
+    const size_t lds = pl.lds;
 #define BNN_LR(MATH, XDT, RR, MM)                                                                       \
   do {                                                                                                  \
     if (lds > 64 * 1024)                                                                                \
@@ -999,15 +946,16 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     else if (R == 2) BNN_LR_M(MATH, XDT, 2);     \
     else BNN_LR_M(MATH, XDT, 4);                 \
   } while (0)
-  if (a->math == BNN_MATH_BF16) {
-    if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_BF16, BNN_F32); else BNN_LR_R(BNN_MATH_BF16, BNN_BF16);
-  } else {
-    if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_F32, BNN_F32); else BNN_LR_R(BNN_MATH_F32, BNN_BF16);
-  }
+    if (a->math == BNN_MATH_BF16) {
+      if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_BF16, BNN_F32); else BNN_LR_R(BNN_MATH_BF16, BNN_BF16);
+    } else {
+      if (a->x_dtype == BNN_F32) BNN_LR_R(BNN_MATH_F32, BNN_F32); else BNN_LR_R(BNN_MATH_F32, BNN_BF16);
+    }
 #undef BNN_LR
 #undef BNN_LR_M
 #undef BNN_LR_R
-  if (err != hipSuccess) return (int)err;
+    if (err != hipSuccess) return (int)err;
+  }
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->kl_out) {
@@ -1017,81 +965,4 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     if (err != hipSuccess) return (int)err;
   }
   return BNN_OK;
-}
-
-// One stage of the evaluation pipeline (see include/bnn_hip.h): the independent pieces in one launch when they take the
-// tile plans lr_stage_kernel is built for, one after the other otherwise.
-extern "C" int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
-
-extern "C" int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first,
-                                const bnn_finalize_args* fin, void* stream_) {
-  const bnn_lr_fwd_args* parts[3] = {last, mid, first};
-  if (!last && !mid && !first && !fin) return BNN_ERR_NULL;
-  auto sequential = [&](bool with_fin) {
-    for (int i = 0; i < 3; ++i)
-      if (parts[i]) {
-        const int rc = bnn_lr_linear_fwd(parts[i], stream_);
-        if (rc != BNN_OK) return rc;
-      }
-    return (with_fin && fin) ? bnn_elbo_finalize(fin, stream_) : (int)BNN_OK;
-  };
-  if (lr_env_int("BNN_HIP_LR_STAGE", 1) == 0) return sequential(true);
-  LrK k[3];
-  long n[3] = {0, 0, 0};
-  int present = 0;
-  for (int i = 0; i < 3; ++i) {
-    if (!parts[i]) continue;
-    ++present;
-    const bnn_lr_fwd_args* a = parts[i];
-    const int rc = lr_fill(a, k[i]);
-    if (rc != BNN_OK) return rc;
-    const LrPlan pl = lr_plan(a);
-    const bool shape_ok = i == 0 ? (pl.R == 4 && pl.MT == 2) : (pl.R == 1 && pl.MT == 8);
-    if (pl.gemm || !shape_ok || pl.nw > 8 || a->math != BNN_MATH_BF16 || a->x_dtype != BNN_BF16 || a->kl_out ||
-        (a->in_features & 7))
-      return sequential(true);
-    n[i] = pl.total;
-  }
-  if (present == 0) return bnn_elbo_finalize(fin, stream_);
-  LrStageExtra ex;
-  memset(&ex, 0, sizeof(ex));
-  ex.plain = lr_env_int("BNN_HIP_STAGE_PLAIN_ORDER", 0);
-  bool fin_in = false;
-  int ncast = 0;
-  if (fin) {
-    // the one-block finalize (one sample per evaluation) and its cast rider join the launch
-    const int rc = make_fin(fin, ex.fk, ex.fc);
-    if (rc != BNN_OK) return rc;
-    fin_in = fin->n_samples == 1 && lr_env_int("BNN_HIP_LR_STAGE_FIN", 1) != 0;
-    if (fin_in) {
-      ex.sums = fin->sums;
-      ex.nfin = 1;
-      if (fin->cast_n > 0) {
-        if (!fin->cast_src || !fin->cast_dst) return BNN_ERR_NULL;
-        if ((reinterpret_cast<uintptr_t>(fin->cast_src) & 3) || (reinterpret_cast<uintptr_t>(fin->cast_dst) & 1)) return BNN_ERR_ALIGN;
-        ex.cj.src = fin->cast_src;
-        ex.cj.dst = reinterpret_cast<__bf16*>(fin->cast_dst);
-        ex.cj.dsq = reinterpret_cast<__bf16*>(fin->cast_dst_sq);
-        ex.cj.n = (long)fin->cast_n;
-        ex.cj.vec_ok = !((reinterpret_cast<uintptr_t>(fin->cast_src) | reinterpret_cast<uintptr_t>(fin->cast_dst) |
-                          reinterpret_cast<uintptr_t>(fin->cast_dst_sq)) & 15);
-        long nb = (ex.cj.n / 8 + 511) / 512;
-        ncast = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
-      }
-    }
-  }
-  if (present < 2 && !fin_in) return sequential(true);
-  for (int i = 0; i < 3; ++i)
-    if (!parts[i]) k[i] = k[parts[0] ? 0 : (parts[1] ? 1 : 2)];            // placeholder, its block range is empty
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const size_t lds = ((size_t)8 * 8 * 64 * 4 + 16 + 3 * 8) * sizeof(float);
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-  if (err != hipSuccess) return (int)err;
-  const long padded = ((n[0] + 7) & ~7L) + ((n[1] + 7) & ~7L) + ((n[2] + 7) & ~7L);
-  hipLaunchKernelGGL(lr_stage_kernel, dim3((unsigned)(padded + ex.nfin + ncast)), dim3(512), lds, stream, k[0], k[1], k[2],
-                     (int)n[0], (int)n[1], (int)n[2], ex);
-  err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
-  return (fin && !fin_in) ? bnn_elbo_finalize(fin, stream_) : (int)BNN_OK;
 }

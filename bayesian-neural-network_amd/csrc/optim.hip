@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
         if (i + j < n) { p[i + j] = pv[j]; m[i + j] = mv[j]; v[i + j] = vv[j]; }
     }
   }
+  // every wave of the block has read *step_dev (top of the kernel) before thread 0 announces the block's arrival:
+  // the last arriver overwrites the word, and a wave that had not loaded it yet would use step + 2
+  if (k.ticket) __syncthreads();
   if (k.ticket && threadIdx.x == 0) {
     // two-level arrival count: device-scope atomics on ONE word serialise at the memory side (1170 of them were a
     // ~4 us tail on this 24 us kernel); blocks count in 8 groups (word 1 + blockIdx % 8), each group's last arriver
@@ -127,7 +130,9 @@ __global__ void nll_bwd_kernel(const float* __restrict__ logits, const void* __r
       for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
       float se = 0.f;
       for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
-      const float inv = 1.0f / se;
+      // a label outside [0, C) poisons the row's gradient (and the forward's NLL) with NaN instead of training
+      // silently on a wrong loss (nn.CrossEntropyLoss, networks.py:186, raises there; ignore_index is not supported)
+      const float inv = (tc >= 0 && tc < C) ? 1.0f / se : __builtin_nanf("");
       for (int c = 0; c < C; ++c) out[c] = (expf(row[c] - mx) * inv - (c == tc ? 1.f : 0.f)) * gs;
     } else {
       const float* tg = reinterpret_cast<const float*>(target) + (size_t)b * C;

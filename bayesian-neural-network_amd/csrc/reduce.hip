@@ -103,22 +103,18 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 }
 
 // grid = n_samples blocks (one sample each), or ONE block looping over all samples when `single`: then the
-// block also writes the 4-vector of sums, in sample order.  With a `ticket` word the one-block-per-sample form
+// block also writes the 4-vector(s) of sums, in sample order.  With a `ticket` word the one-block-per-sample form
 // does that too: the last-arriving block folds the per-sample scalars (release / ticket / acquire, nobody
 // waits), so a handful of samples is finalized in parallel and still in one launch (8 samples: 31.7 us serially).
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const FinC cst, int single, float* sums,
-                                                            uint32_t* ticket, int nfin, const CastJob cj) {
+                                                            uint32_t* ticket) {
   __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
-  if ((int)blockIdx.x >= nfin) {                           // rider blocks: block-uniform, before any barrier
-    cast_bf16_span(cj.src, cj.dst, cj.dsq, cj.n, cj.vec_ok, (long)((int)blockIdx.x - nfin) * blockDim.x + threadIdx.x,
-                   (long)((int)gridDim.x - nfin) * blockDim.x);
-    return;
-  }
   int T[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l)
     T[l] = (l < p.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(p.ws[l])[0].x) : 0;
   const int s_begin = single ? 0 : blockIdx.x, s_end = single ? p.S : blockIdx.x + 1;
+  const int g = p.group > 0 ? p.group : p.S;
   double tot_a = 0, tot_b = 0, tot_n = 0;
   for (int s = s_begin; s < s_end; ++s) {
     float a = 0.f, b = 0.f, nll = 0.f;
@@ -129,20 +125,18 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
       tot_a += a;
       tot_b += b;
       tot_n += nll;
+      if (single && (s + 1) % g == 0) {                       // a minibatch (or the one evaluation) is complete
+        if (sums) {
+          float* so = sums + 4 * (s / g);
+          so[0] = (float)tot_a; so[1] = (float)tot_b; so[2] = (float)tot_n; so[3] = (float)g;
+        }
+        tot_a = tot_b = tot_n = 0;
+      }
     }
     if (s + 1 < s_end) __syncthreads();
   }
   if (single) {
-    if (threadIdx.x == 0) {
-      if (sums) {
-        sums = fin_sums_slot(p, sums);
-        sums[0] = (float)tot_a;
-        sums[1] = (float)tot_b;
-        sums[2] = (float)tot_n;
-        sums[3] = (float)p.S;
-      }
-      if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
-    }
+    if (threadIdx.x == 0 && p.sample_counter) *p.sample_counter += p.sample_counter_inc;
     return;
   }
   if (!ticket) {                                             // the sums (if any) come from a follow-up launch
@@ -156,29 +150,39 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
     if (tk == (uint32_t)p.S - 1u) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (sums) {
-        double ta = 0, tb = 0, tn = 0;
-        const float* pa = p.local_reparam ? p.kl : p.log_prior;
-        for (int i = 0; i < p.S; ++i) {                      // sample order: the sums do not depend on who arrived when
-          if (pa) ta += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!p.local_reparam && p.log_q) tb += __hip_atomic_load(p.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (p.nll) tn += __hip_atomic_load(p.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        float* so = fin_sums_slot(p, sums);
-        so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)p.S;
-      }
+      if (sums) fin_fold_sums(p, sums);                      // sample order: the sums do not depend on who arrived when
       *ticket = 0u;
       if (p.sample_counter) *p.sample_counter += p.sample_counter_inc;
     }
   }
 }
 
-// Sum of the per-sample scalars over the local samples, in index order per thread and a
-// fixed tree across threads: the 4-vector a sharded job all-reduces.
+// Sums of the per-sample scalars over the local samples: the 4-vector a sharded job all-reduces (one per minibatch
+// of `g` samples).  One evaluation: index order per thread and a fixed tree across threads; several minibatches: a
+// thread per minibatch, sample order.
 __global__ void sample_sums_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                   const float* __restrict__ c, int S, float* sums, uint32_t* counter,
-                                   uint32_t counter_inc, uint32_t* ring_pos, uint32_t ring_len, uint32_t ring_stride) {
+                                   const float* __restrict__ c, int S, int g, float* sums, uint32_t* counter,
+                                   uint32_t counter_inc) {
   __shared__ double scratch[16];
+  if (g > 0 && g < S) {
+    const int G = S / g;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < G; m += gridDim.x * blockDim.x) {
+      double x = 0, y = 0, z = 0;
+      for (int i = m * g; i < (m + 1) * g; ++i) {
+        if (a) x += a[i];
+        if (b) y += b[i];
+        if (c) z += c[i];
+      }
+      if (sums) {
+        sums[4 * m + 0] = (float)x;
+        sums[4 * m + 1] = (float)y;
+        sums[4 * m + 2] = (float)z;
+        sums[4 * m + 3] = (float)g;
+      }
+    }
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += counter_inc;
+    return;
+  }
   double x = 0, y = 0, z = 0;
   for (int i = threadIdx.x; i < S; i += blockDim.x) {
     if (a) x += a[i];
@@ -190,11 +194,6 @@ __global__ void sample_sums_kernel(const float* __restrict__ a, const float* __r
   z = block_sum(z, scratch);
   if (threadIdx.x == 0) {
     if (sums) {
-      if (ring_pos) {
-        const uint32_t k = *ring_pos;
-        *ring_pos = (k + 1u >= ring_len) ? 0u : k + 1u;
-        sums += (size_t)k * ring_stride;
-      }
       sums[0] = (float)x;
       sums[1] = (float)y;
       sums[2] = (float)z;
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(256) void elbo_loss_nll_bwd_kernel(
       for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
       float se = 0.f;
       for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
-      const float inv = 1.0f / se;
+      const float inv = (tc >= 0 && tc < C) ? 1.0f / se : __builtin_nanf("");   // bad label: NaN, as in nll_bwd_kernel
       for (int c = 0; c < C; ++c) out[c] = (expf(row[c] - mx) * inv - (c == tc ? 1.f : 0.f)) * gs;
     } else {
       const float* tg = reinterpret_cast<const float*>(target) + (size_t)brow * C;
@@ -470,30 +469,15 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   const bool small = (long)a->n_samples * a->batch * a->classes <= 65536;
   const bool ticketed = a->n_samples > 1 && a->n_samples <= 64 && a->ticket != nullptr;
   const int single = a->n_samples == 1 || (a->n_samples <= 16 && small && !ticketed);
-  const int nfin = single ? 1 : a->n_samples;
-  CastJob cj{nullptr, nullptr, nullptr, 0, 0};
-  int nrider = 0;
-  if (a->cast_n > 0) {                                      // the next evaluation's input cast rides on this launch
-    if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
-    if ((reinterpret_cast<uintptr_t>(a->cast_src) & 3) || (reinterpret_cast<uintptr_t>(a->cast_dst) & 1)) return BNN_ERR_ALIGN;
-    cj.src = a->cast_src; cj.dst = reinterpret_cast<__bf16*>(a->cast_dst); cj.dsq = reinterpret_cast<__bf16*>(a->cast_dst_sq);
-    cj.n = (long)a->cast_n;
-    cj.vec_ok = !((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst) |
-                   reinterpret_cast<uintptr_t>(a->cast_dst_sq)) & 15);
-    long nb = (cj.n / 8 + 255) / 256;
-    nrider = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-  } else if (a->cast_n < 0) {
-    return BNN_ERR_SHAPE;
-  }
-  hipLaunchKernelGGL(elbo_finalize_kernel, dim3((unsigned)(nfin + nrider)), dim3(256), 0, stream, k, cst, single, a->sums,
-                     (single || !ticketed) ? (uint32_t*)nullptr : a->ticket, nfin, cj);
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3((unsigned)(single ? 1 : a->n_samples)), dim3(256), 0, stream, k, cst, single,
+                     a->sums, (single || !ticketed) ? (uint32_t*)nullptr : a->ticket);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->sums && !single && !ticketed) {
     const float* first = a->local_reparam ? a->kl : a->log_prior;
     const float* second = a->local_reparam ? nullptr : a->log_q;
-    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples, a->sums,
-                       (uint32_t*)nullptr, 0u, a->sums_ring_pos, a->sums_ring_len, a->sums_ring_stride);
+    hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, stream, first, second, a->nll, a->n_samples,
+                       a->group_samples, a->sums, (uint32_t*)nullptr, 0u);
     err = hipGetLastError();
   }
   return err == hipSuccess ? BNN_OK : (int)err;
@@ -516,8 +500,7 @@ extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream_) {
   const float* first = f->local_reparam ? f->kl : f->log_prior;
   const float* second = f->local_reparam ? nullptr : f->log_q;
   hipLaunchKernelGGL(sample_sums_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), first, second,
-                     f->nll, f->n_samples, f->sums, f->sample_counter, f->sample_counter_inc, f->sums_ring_pos,
-                     f->sums_ring_len, f->sums_ring_stride);
+                     f->nll, f->n_samples, f->group_samples, f->sums, f->sample_counter, f->sample_counter_inc);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

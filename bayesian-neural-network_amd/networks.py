@@ -256,6 +256,16 @@ class BayesianNetwork(nn.Module):
         softmax(net(x, sample=True)).  Same eps order as that loop when eps is injected."""
         return _engine.mc_predict(self._specs(), self._flat(x), int(samples))
 
+    def elbo_many(self, inputs, targets, samples, sigma=1.):
+        """Extension (not in the reference): the forward-only ELBO terms of G independent minibatches -- inputs
+        [G, batch, ...], targets [G, batch] -- in one launch per layer instead of G sample_elbo calls under
+        no_grad (the reference walks minibatches one at a time, classification/class_task.py:89-103).  Returns
+        float32 [G, 4]: per minibatch (sum_s log p | sum_s KL, sum_s log q | 0, sum_s nll, samples); divide by
+        `samples` for the means sample_elbo / sample_elbo_lr return (networks.py:205-208, :222-224)."""
+        if self.mode not in ('regression', 'classification'):
+            raise Exception("Training mode must be either 'regression' or 'classification'")
+        return _engine.elbo_many(self, inputs, targets, int(samples), sigma=float(sigma))
+
     def log_prior(self):
         return self.l1.log_prior + self.l2.log_prior + self.l3.log_prior
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 1
+#define BNN_HIP_ABI_VERSION 2
 
 enum bnn_status {
   BNN_OK = 0,
@@ -76,6 +76,12 @@ enum bnn_prior_kind {
 
 enum bnn_nll_mode { BNN_NLL_REGRESSION = 0, BNN_NLL_CLASSIFICATION = 1 };
 
+/* Kernel forms of a layer launch.  TILE: one block per (feature tile, sample, batch block), the block's
+ * waves split the reduction and meet in LDS -- few samples in flight.  GEMM: block GEMM, the x tile shared
+ * through LDS by LDS-DMA, a wave owns 16 features for all of K -- many samples.  GEMM_KSLICE (BBB): the GEMM
+ * form with the reduction cut into slices whose fp32 partial tiles a second kernel sums in slice order. */
+enum bnn_form { BNN_FORM_AUTO = 0, BNN_FORM_TILE = 1, BNN_FORM_GEMM = 2, BNN_FORM_GEMM_KSLICE = 3 };
+
 typedef struct bnn_prior {
   int32_t kind;      /* bnn_prior_kind */
   float sigma_p;     /* Gaussian prior scale (prior_init[0])            */
@@ -85,15 +91,42 @@ typedef struct bnn_prior {
 } bnn_prior;
 
 /* ------------------------------------------------------------------------------------
+ * Launch plans.  The geometry of a forward layer launch is a pure function of the shape and of what the
+ * arguments allow -- never of pointers' values, streams or the environment -- so one shape always runs one
+ * summation order (bitwise reproducible), and the function is testable without a device.
+ * bnn_bbb_plan / bnn_lr_plan return what bnn_bbb_linear_fwd / bnn_lr_linear_fwd will launch for `a`
+ * (only the shape, dtype, math, form, alignment of the pointers and presence of the optional buffers are read).
+ * ---------------------------------------------------------------------------------- */
+typedef struct bnn_plan {
+  int32_t form;          /* bnn_form taken */
+  int32_t k_classes;     /* TILE: R k-range classes of the 16 MFMA rows; a tile holds 16 / R features */
+  int32_t waves;         /* waves per block */
+  int32_t batch_rows;    /* batch rows per block */
+  int32_t k_slices;      /* GEMM_KSLICE: reduction slices (1 otherwise) */
+  int32_t blocks;        /* work items (the grid is padded to a multiple of 8) */
+  int32_t lds_bytes;     /* LDS per block */
+  int32_t features_per_block;
+} bnn_plan;
+
+/* ------------------------------------------------------------------------------------
  * K1  bnn_bbb_linear_fwd — BayesianLinear.forward for n_samples MC samples in ONE launch.
  * Replaces networks.py:73-88 (+ :39-46 GaussianNode, :14-27 / :67-68 priors) and the
  * serial MC loop over it (networks.py:199-200) for one layer:
  *     w_s = mu + softplus(rho) * eps_s       (per weight and bias, never stored)
  *     y_s = x_s . w_s^T + b_s  [-> ReLU]     (networks.py:88, :169-171)
  *     stats partials for log p(w_s), log q(w_s)   (networks.py:82-83)
- * Shapes: x [x_samples, batch, in] (x_samples = n_samples if x_per_sample else 1);
+ * Shapes: x [x_rows, batch, in] (x_rows = 1 if x_per_sample == 0, else ceil(n_samples / x_per_sample));
  * w_mu,w_rho [out,in]; b_mu,b_rho [out]; eps_w [n_samples,out,in]; eps_b [n_samples,out];
  * y [n_samples, batch, out].
+ *
+ * Sample groups.  The n_samples of a launch may be G independent minibatches x S MC samples each
+ * (sample s = minibatch s / S, MC sample s % S): the reference evaluates minibatches one after the
+ * other (classification/class_task.py:66-79 trains, :89-103 evaluates), but given the parameters
+ * their forward passes are independent, so a stream of minibatches is batched into one launch per
+ * layer exactly like the MC samples of one minibatch.  x_per_sample = S then gives the first layer
+ * one x per minibatch, and (sample_group = S_local, sample_group_stride = S_global) keeps the Philox
+ * index of (minibatch m, global MC sample j) at sample_offset + m * S_global + j whatever share of
+ * the S_global samples this rank owns (results independent of the number of GPUs).
  *
  * Stats workspace (want_stats != 0): opaque to the caller, produced here and consumed only
  * by this library (the optional per-layer reduction below and bnn_elbo_finalize).  It holds,
@@ -110,7 +143,7 @@ typedef struct bnn_bbb_fwd_args {
   int32_t n_samples, batch, in_features, out_features;
   const void* x;
   int32_t x_dtype;          /* bnn_dtype */
-  int32_t x_per_sample;     /* 0: one x for all samples, 1: x[s] */
+  int32_t x_per_sample;     /* 0: one x for all samples; g >= 1: sample s reads x[s / g] (1: one x per sample) */
   const float* w_mu;
   const float* w_rho;
   const float* b_mu;
@@ -124,6 +157,8 @@ typedef struct bnn_bbb_fwd_args {
   uint32_t sample_offset;   /* global MC index of local sample 0 (multi-GPU shards) */
   const uint32_t* sample_counter; /* optional DEVICE word added to sample_offset at run time, so a
                                captured hipGraph draws fresh eps on every replay (see K4) */
+  uint32_t sample_group;    /* 0: global index of local sample s = sample_offset + counter + s.  g > 0: */
+  uint32_t sample_group_stride; /* sample_offset + counter + (s / g) * sample_group_stride + s % g      */
   float* eps_w_dump;        /* optional: the eps actually used, [n_samples,out,in] */
   float* eps_b_dump;        /* optional: [n_samples,out] */
   bnn_prior prior;
@@ -135,9 +170,10 @@ typedef struct bnn_bbb_fwd_args {
   float* log_q;             /* optional [n_samples] */
   void* y;
   int32_t y_dtype;          /* bnn_dtype */
-  int32_t concurrency;      /* 0 / 1: the launch has the chip to itself.  n > 1: about n independent launches
-                               like this one run side by side (one stream each): the launch is then sized for
-                               a 1/n share of the chip (fewer, larger tiles) */
+  int32_t form;             /* bnn_form preference: BNN_FORM_AUTO lets the plan choose; another value is taken when
+                               the arguments allow that form (bnn_bbb_plan tells), else the plan's own choice.
+                               Tests compare the forms with each other through it; bnn_bbb_final_fwd fuses the
+                               finalize only under BNN_FORM_AUTO */
   void* split_scratch;      /* optional, 16-byte aligned, >= 8 * n_samples*batch*out_features*4 bytes:
                                lets a mid-sized launch split its K range over several blocks
                                (fp32 partial tiles summed in a fixed order by a tiny second kernel) */
@@ -153,6 +189,7 @@ typedef struct bnn_bbb_fwd_args {
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
 int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
+int bnn_bbb_plan(const bnn_bbb_fwd_args* args, bnn_plan* plan);
 
 /* ------------------------------------------------------------------------------------
  * K1s  bnn_bbb_sample_weights — the sampling half of BayesianLinear.forward (networks.py:73-86) for up to
@@ -217,7 +254,7 @@ typedef struct bnn_lr_fwd_args {
   int32_t n_samples, batch, in_features, out_features;
   const void* x;
   int32_t x_dtype;
-  int32_t x_per_sample;
+  int32_t x_per_sample;     /* as in bnn_bbb_fwd_args */
   const float* w_mu;        /* [in,out] */
   const float* w_rho;
   const float* b_mu;
@@ -230,12 +267,14 @@ typedef struct bnn_lr_fwd_args {
   uint32_t layer_id;
   uint32_t sample_offset;
   const uint32_t* sample_counter; /* optional device word, as in bnn_bbb_fwd_args */
+  uint32_t sample_group;    /* as in bnn_bbb_fwd_args */
+  uint32_t sample_group_stride;
   float* eps_act_dump;
   float* eps_b_dump;
   float sigma_p;            /* prior_init[0]; prior mean is 0 (networks.py:103-104) */
   int32_t want_kl;
   int32_t relu;
-  int32_t concurrency;      /* as in bnn_bbb_fwd_args */
+  int32_t form;             /* bnn_form, as in bnn_bbb_fwd_args */
   void* workspace;
   size_t workspace_bytes;
   float* kl_out;
@@ -256,6 +295,7 @@ typedef struct bnn_lr_fwd_args {
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
 int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
+int bnn_lr_plan(const bnn_lr_fwd_args* args, bnn_plan* plan);
 
 
 /* bnn_lr_prepare — the eps-independent half of BayesianLinearLR.forward, once per ELBO
@@ -313,9 +353,9 @@ typedef struct bnn_finalize_args {
   uint32_t* sample_counter;         /* optional device word: += sample_counter_inc when done */
   uint32_t sample_counter_inc;      /* normally the GLOBAL number of MC samples of the evaluation */
   uint32_t reserved;
-  float* sums;                      /* optional float[4]: sums over the n_samples local samples of
-                                       {log p | KL, log q | 0, nll, n_samples}: the vector a sharded
-                                       job all-reduces (fixed summation order) */
+  float* sums;                      /* optional float[4] (float[G][4] with group_samples): sums over the local samples
+                                       (of each minibatch) of {log p | KL, log q | 0, nll, sample count}: the vector
+                                       a sharded job all-reduces (fixed summation order) */
   uint32_t* ticket;                 /* optional zero-initialised device word (left at zero again): lets 2..64 samples be
                                        finalized by one block each IN ONE launch, the last arriver folding `sums`
                                        (bnn_elbo_finalize and the fused last-layer form bnn_bbb_final_fwd) */
@@ -323,17 +363,10 @@ typedef struct bnn_finalize_args {
                                        aligned, ZEROED ONCE by the caller: lets the fused last layer
                                        split its K range over several blocks per sample */
   size_t scratch_bytes;
-  uint32_t* sums_ring_pos;          /* optional device word (zero-initialised by the caller): when set,
-                                       the 4-vector goes to sums + (*pos) * sums_ring_stride floats and
-                                       *pos advances modulo sums_ring_len.  Lets a captured hipGraph
-                                       deposit consecutive evaluations in consecutive slots of a slab
-                                       that a sharded job all-reduces once per many evaluations. */
-  uint32_t sums_ring_len;
-  uint32_t sums_ring_stride;        /* floats between consecutive slots (>= 4) */
-  const float* cast_src;            /* bnn_elbo_finalize only, optional rider on the same launch: an INDEPENDENT */
-  void* cast_dst;                   /* bnn_cast_bf16(cast_src, cast_dst, cast_dst_sq, cast_n) -- the next         */
-  void* cast_dst_sq;                /* evaluation's input batch, so that its cast costs the chain of dependent   */
-  int64_t cast_n;                   /* launches nothing; 0 = none                                                */
+  int32_t group_samples;            /* 0: the n_samples are one evaluation.  g > 0: n_samples = G * g, G independent
+                                       minibatches of g MC samples each (see bnn_bbb_fwd_args): `sums` is then
+                                       float[G][4], one 4-vector per minibatch */
+  int32_t target_per_group;         /* with group_samples: 0 = one target for all, 1 = target[G][batch(,classes)] */
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
@@ -346,47 +379,6 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
  * (networks.py:174-178).  Falls back to the two launches otherwise. */
 size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
-
-/* bnn_bbb_final_next_fwd — bnn_bbb_final_fwd(layer, fin) of one evaluation and bnn_bbb_linear_fwd(next_first), the
- * first layer of the NEXT evaluation, in ONE launch (the same results as the two calls).  The two are independent
- * work: the caller guarantees that next_first neither writes what layer / fin read (its statistics workspace must
- * not be one of fin->layer_workspace, its y not an input of layer) nor depends on what they write (give it a static
- * sample_offset rather than a sample counter that fin advances).  The output layer is a few latency-bound blocks;
- * beside the next evaluation's first layer it no longer holds its stream's chain of dependent launches. */
-int bnn_bbb_final_next_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* next_first,
-                           void* stream);
-
-/* bnn_bbb_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer net: any of
- *   last + fin : output layer + finalize of evaluation j      (as bnn_bbb_final_fwd; both NULL or both set)
- *   mid        : hidden layer of evaluation j + 1             (as bnn_bbb_linear_fwd; bf16 x)
- *   first      : first layer of evaluation j + 2              (as bnn_bbb_linear_fwd)
- * in ONE launch, so that in steady state an evaluation costs its stream one launch instead of three dependent
- * ones.  Same results as the separate calls.  The caller keeps the pieces independent: each evaluation in flight
- * has its own activation and statistics buffers and a static sample_offset (only the finalize that ends a batch of
- * evaluations advances a shared sample counter).  Pieces that cannot ride together (other tile plans, fp32 math, an
- * output layer wider than 16 ...) are launched one after the other. */
-int bnn_bbb_stage_fwd(const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin, const bnn_bbb_fwd_args* mid,
-                      const bnn_bbb_fwd_args* first, void* stream);
-
-/* bnn_lr_stage_fwd — one stage of a software pipeline over INDEPENDENT evaluations of a three-layer LR net (the LR
- * counterpart of bnn_bbb_stage_fwd): the output layer of evaluation j, the hidden layer of evaluation j + 1 and the
- * first layer of evaluation j + 2, any of them NULL, in ONE launch; the same results as bnn_lr_linear_fwd on each.
- * The caller keeps the pieces independent (own activation and KL workspaces per evaluation in flight, static
- * sample_offset).  `fin` (optional): the finalize of a still earlier evaluation, bnn_elbo_finalize(fin) with its cast
- * rider; with one sample per evaluation it joins the launch as two more independent pieces.  Pieces whose tile plan
- * the combined kernel is not built for run one after the other. */
-int bnn_lr_stage_fwd(const bnn_lr_fwd_args* last, const bnn_lr_fwd_args* mid, const bnn_lr_fwd_args* first,
-                     const bnn_finalize_args* fin, void* stream);
-
-/* bnn_bbb_tail2_fwd — the last HIDDEN layer, the output layer and the finalize of a ONE-sample evaluation in one
- * launch: the same results as bnn_bbb_linear_fwd(hidden) followed by bnn_bbb_final_fwd(last, fin) with
- * last->x == hidden->y (bf16) and fin's two last workspaces those of the two layers, but whichever block of the
- * hidden layer finishes last carries on with the output layer and the finalize (fin->ticket: one zero-initialised
- * device word).  Falls back to the two calls when the shapes or modes do not allow it (more than one sample,
- * fp32 math, an output layer wider than 16, ...) and, by default, always: the fused form measured slower on
- * MI355X (see the source); BNN_HIP_FUSE_TAIL2=1 enables it. */
-int bnn_bbb_tail2_fwd(const bnn_bbb_fwd_args* hidden, const bnn_bbb_fwd_args* last, const bnn_finalize_args* fin,
-                      void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bnn_bbb_linear_bwd — backward of BayesianLinear for n_samples MC samples (what autograd

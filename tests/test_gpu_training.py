@@ -249,6 +249,39 @@ def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
             assert float((got - want.detach()).abs().max()) <= 1e-5 * (float(want.detach().abs().max()) + 1e-6), idx
     for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), k
+    if not autograd:
+        # a SECOND step object on the trained optimiser (another minibatch shape, e.g. the 96-row last MNIST batch):
+        # its warm-up must leave the device step, the moments and the parameters where training left them, and a
+        # checkpoint of the optimiser must carry the real step count
+        before = {k: v.clone() for k, v in net_b.state_dict().items()}
+        m_before = [ob.state[p]["exp_avg"].clone() for p in net_b.parameters()]
+        graphed2 = GraphedTrainStep(net_b, ob, xs[0][:32], ys[0][:32], S)
+        assert ob.device_step() == M
+        for k, v in net_b.state_dict().items():
+            assert torch.equal(v, before[k]), k
+        for p, m in zip(net_b.parameters(), m_before):
+            assert torch.equal(ob.state[p]["exp_avg"], m)
+        sd = ob.state_dict()
+        assert all(int(st["step"]) == M for st in sd["state"].values())
+        graphed2.step(xs[1][:32], ys[1][:32], 0.1)
+        assert ob.device_step() == M + 1
+
+
+def test_out_of_range_label_poisons_loss_and_gradient():
+    """A label outside [0, classes) must not train silently on a wrong loss (nn.CrossEntropyLoss, reference
+    networks.py:186, raises): the NLL and the row's logit gradient come out NaN."""
+    from bnn_hip import ops
+    dev = torch.device("cuda:0")
+    S, B, Cc = 2, 8, 10
+    logits = torch.randn(S, B, Cc, device=dev)
+    good = torch.randint(0, Cc, (B,), device=dev)
+    bad = good.clone()
+    bad[3] = Cc
+    fin = lambda tg: ops.elbo_finalize(workspaces=[], layer_in=[], layer_out=[], local_reparam=False, prior=ops.PriorSpec(),
+                                       n_samples=S, logits=logits, target=tg, mode="classification")["nll"]
+    assert torch.isfinite(fin(good)).all() and torch.isnan(fin(bad)).all()
+    g = ops.nll_bwd(logits, bad, torch.ones(S, device=dev), "classification")
+    assert torch.isnan(g[:, 3]).all() and torch.isfinite(g[:, [0, 1, 2, 4, 5, 6, 7]]).all()
 
 
 def test_graphed_step_with_presampled_weights_equals_the_fused_step(monkeypatch):

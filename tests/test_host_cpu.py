@@ -173,6 +173,13 @@ WORKER = textwrap.dedent('''
         np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=2e-6)
     lo, n = engine.shard_range(S, rank, world)
     assert n in (2, 3) and bnn_hip.runtime.state.counter == S      # every rank advanced by the GLOBAL count
+    # the sharded ELBO is forward-only: nothing all-reduces parameter gradients, so a differentiable call is refused
+    # rather than leaving every rank with the gradient of its own samples only
+    try:
+        net.sample_elbo(torch.from_numpy(x).view(B, dims[0]), torch.from_numpy(y), 0.25, S)
+        raise SystemExit("sharded differentiable sample_elbo was not refused")
+    except bnn_hip.BnnHipError as e:
+        assert "forward-only" in str(e)
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 ''')
@@ -202,39 +209,41 @@ BENCH_WORKER = textwrap.dedent(r'''
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     class FakeEvaluator:
-        """Stands in for engine.GraphedElbo: a replay runs `per_replay` evaluations, each depositing its
-        4-vector {{evaluation index, rank, 0, 1}} at the device-side ring cursor (here a Python int)."""
-        def __init__(self, slab, j, n, per_replay):
-            self.slab, self.j, self.n, self.per_replay, self.stream, self.pos, self.count = slab, j, n, per_replay, None, 0, 0
+        # Stands in for engine.GraphedElbo: a replay evaluates G minibatches and leaves their 4-vectors
+        # (replay index * G + minibatch, rank, 0, 1) in the static `sums` tensor.
+        def __init__(self, G):
+            self.G, self.count, self.sums = G, 0, torch.zeros((G, 4)) if G > 1 else torch.zeros(4)
         def replay(self):
-            for _ in range(self.per_replay):
-                self.slab[self.pos, self.j] = torch.tensor([float(self.count * self.n + self.j), float(rank), 0.0, 1.0])
-                self.pos = (self.pos + 1) % self.slab.shape[0]
-                self.count += 1
+            v = self.sums.view(self.G, 4)
+            for m in range(self.G):
+                v[m] = torch.tensor([float(self.count * self.G + m), float(rank), 0.0, 1.0])
+            self.count += 1
+            return self.sums
 
-    for (nstr, E, ar_every, warmup, steps) in ((3, 4, 16, 24, 120), (4, 2, 8, 10, 46), (1, 1, 4, 3, 9)):
-        slab = torch.zeros((2 * ar_every, nstr, 4))
-        evs = [FakeEvaluator(slab, j, nstr, E) for j in range(nstr)]
-        dt = bench.run_steps(evs, steps, warmup, dist, slab, ar_every)
-        assert dt > 0
-        h = bench.run_steps.last_flushed_half
-        if h is not None:                                   # every row of the last fully reduced half: summed over the ranks
-            rows = slab[h * ar_every:(h + 1) * ar_every]
-            assert bool((rows[:, :, 3] == float(world)).all()), rows[:, :, 3]
-            assert bool((rows[:, :, 1] == sum(range(world))).all())
-            idx = rows[:, :, 0] / world                     # the same evaluation index on every rank
-            assert bool((idx == idx.round()).all())
-        total = sum(e.count for e in evs)
-        assert total == warmup + steps, (total, warmup, steps)
+    for (steps, warmup, group, every) in ((120, 24, 16, False), (46, 10, 8, False), (9, 3, 4, False), (20, 5, 256, False),
+                                          (12, 4, 1, True)):
+        G, full, rem, warm = bench.plan_groups(steps, warmup, group)
+        main, tail = FakeEvaluator(G), (FakeEvaluator(rem) if rem else None)
+        dt = bench.run_groups(main, full, warm, tail, dist, every)
+        assert dt > 0 and main.count == warm + full and (tail is None or tail.count == 1)
+        assert (main.count - warm) * G + (rem if tail else 0) == steps
+        if every:                                           # reduced in place, evaluation by evaluation
+            assert bool((main.sums.view(G, 4)[:, 3] == float(world)).all())
+        else:
+            slot = bench.run_groups.last_reduced[(full + warm - 1) & 1].view(G, 4)   # the last launch group's collective
+            assert bool((slot[:, 3] == float(world)).all()) and bool((slot[:, 1] == sum(range(world))).all())
+            assert bool((slot[:, 0] == world * (torch.arange(G) + (warm + full - 1) * G)).all()), slot[:, 0]
+            if tail is not None:
+                assert bool((tail.sums.view(rem, 4)[:, 3] == float(world)).all())
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 ''')
 
 
-def test_bench_ring_allreduce_bookkeeping_two_ranks(tmp_path):
-    """bench.run_steps' N>1 bookkeeping (ring halves, one all-reduce per half, partial flush at the barriers,
-    matching collective counts on every rank) on 2 ranks over gloo with stand-in evaluators: no hang, every
-    fully flushed row is the sum over the ranks, exactly warmup + steps evaluations ran."""
+def test_bench_group_allreduce_bookkeeping_two_ranks(tmp_path):
+    '''bench.run_groups' N>1 bookkeeping (two slab slots, one asynchronous all-reduce per launch group, the remainder
+    group's own collective, the per-evaluation collective of the C4 mode) on 2 ranks over gloo with stand-in
+    evaluators: no hang, every reduced row is the sum over the ranks, exactly K steps are timed.'''
     script = tmp_path / "bench_worker.py"
     script.write_text(BENCH_WORKER.format(repo=REPO))
     port = str(30500 + (os.getpid() % 2000))
@@ -247,15 +256,99 @@ def test_bench_ring_allreduce_bookkeeping_two_ranks(tmp_path):
 
 
 def test_bench_times_any_step_count_exactly():
-    """bench.plan_steps: whole graph launches plus one tail launch always add up to the K the caller asked for, the
-    warm-up is never shorter than asked, E divides the all-reduce period in the N>1 path."""
+    '''bench.plan_groups: whole launch groups plus one remainder launch always add up to the K the caller asked for and
+    the warm-up is never shorter than asked.'''
     import bench
-    for steps in (1, 2, 3, 5, 7, 20, 50, 97, 100, 1001, 3000):
-        for warmup in (0, 1, 5, 33, 300):
-            for nstr in (1, 3, 4):
-                for ar in (None, 16, 64):
-                    E, main, tail, wrun = bench.plan_steps(steps, warmup, 4, nstr, ar)
-                    assert E >= 1 and main % E == 0 and 0 <= tail < E and main + tail == steps
-                    assert wrun >= warmup and wrun % E == 0 and wrun - warmup < E
-                    assert ar is None or ar % E == 0
-    assert bench.plan_steps(3000, 300, 4, 4)[0] == 4 and bench.plan_steps(20, 5, 4, 4)[0] == 5
+    for steps in (1, 2, 3, 5, 7, 20, 50, 97, 100, 1001, 3000, 8192):
+        for warmup in (0, 1, 5, 33, 300, 512):
+            for group in (1, 4, 16, 256):
+                G, full, rem, warm = bench.plan_groups(steps, warmup, group)
+                assert 1 <= G <= min(group, steps) and full * G + rem == steps and 0 <= rem < G
+                assert warm * G >= warmup and warm * G - warmup < G
+    assert bench.plan_groups(20, 5, 256) == (20, 1, 0, 1) and bench.plan_groups(8192, 512, 256) == (256, 32, 0, 2)
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    '''`bench.py --gpus N` never reports a run of another size: under a launcher whose WORLD_SIZE disagrees it exits 2
+    before touching a device, and without a launcher it starts N rank processes itself (here, with no GPU, every
+    rank refuses for want of devices and the parent relays that: exit 2, no JSON line).'''
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 2 and r.stderr.count("2 ranks need 2 GPUs") == 2 and not r.stdout.strip()
+
+
+def _plan_args(cls, **kw):
+    a = cls()
+    a.struct_bytes = C.sizeof(cls)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_launch_plans_are_a_function_of_the_shape():
+    '''bnn_bbb_plan / bnn_lr_plan (no device needed: they read shapes, dtypes and pointer alignment only): the forms,
+    tile widths and wave counts the BASELINE shapes launch with, and the invariants every plan must keep -- whole
+    waves in fours where there is enough work, LDS within 160 KiB, the requested form honoured when it applies.'''
+    from bnn_hip import _lib as L
+    lib = L.load()
+    P = 0x10000                                             # any 16-byte aligned non-null address: plans never dereference
+
+    def bbb(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, scratch=False):
+        a = _plan_args(L.BbbFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
+                       b_mu=P, b_rho=P, math=math, y=P, form=form, split_scratch=P if scratch else None,
+                       split_scratch_bytes=(8 * S * B * N * 4) if scratch else 0)
+        a.prior.sigma_p = 1.0
+        pl = L.Plan()
+        assert lib.bnn_bbb_plan(C.byref(a), C.byref(pl)) == 0
+        return pl
+
+    def lr(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, sq=False, frag=False):
+        a = _plan_args(L.LrFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
+                       b_mu=P, b_rho=P, math=math, y=P, form=form, x_sq=P if sq else None, w_frag=P if frag else None)
+        pl = L.Plan()
+        assert lib.bnn_lr_plan(C.byref(a), C.byref(pl)) == 0
+        return pl
+
+    # C2, one sample: 150 tiles of 8 features cover the chip, 12 waves split the 19 super-steps
+    pl = bbb(1, 128, 1200, 1200)
+    assert (pl.form, pl.k_classes, pl.waves, pl.blocks, pl.features_per_block) == (L.FORM_TILE, 2, 12, 150, 8)
+    pl = bbb(1, 128, 784, 1200, xdt=L.F32)
+    assert (pl.form, pl.k_classes, pl.blocks) == (L.FORM_TILE, 2, 150)
+    # C4's per-GPU share (8 samples): whole 16-feature tiles, 4-wave blocks, three to a CU
+    pl = bbb(8, 128, 1200, 1200)
+    assert (pl.form, pl.k_classes, pl.waves, pl.blocks) == (L.FORM_TILE, 1, 4, 600)
+    # the throughput regime: block GEMM from 450 (64-feature group x sample) items
+    assert bbb(24, 128, 1200, 1200).form == L.FORM_GEMM and bbb(23, 128, 1200, 1200).form == L.FORM_TILE
+    pl = bbb(256, 128, 1200, 1200)
+    assert (pl.form, pl.waves, pl.blocks, pl.features_per_block) == (L.FORM_GEMM, 4, 19 * 256, 64)
+    assert bbb(256, 128, 1200, 1200, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE      # fp32 math has no GEMM form
+    # C5's per-GPU share: K-sliced GEMM for the 16.8 M-weight layer when a scratch is there, the tile form without
+    pl = bbb(4, 128, 4096, 4096, scratch=True)
+    assert pl.form == L.FORM_GEMM_KSLICE and pl.k_slices >= 2 and pl.blocks == 64 * 4 * pl.k_slices
+    assert bbb(4, 128, 4096, 4096).form == L.FORM_TILE and bbb(4, 128, 1200, 1200, scratch=True).form == L.FORM_TILE
+    # a form preference is honoured when the arguments allow it, ignored otherwise
+    assert bbb(2, 128, 1200, 1200, form=L.FORM_GEMM).form == L.FORM_GEMM
+    assert bbb(2, 128, 1200, 1200, math=L.MATH_F32, xdt=L.F32, form=L.FORM_GEMM).form == L.FORM_TILE
+    assert bbb(256, 128, 1200, 1200, form=L.FORM_TILE).form == L.FORM_TILE
+    # LR: K3a until 300 block-GEMM items AND the bf16 x / x^2 pair; the output layer in 32-row blocks
+    assert lr(1, 128, 1200, 1200).form == L.FORM_TILE and lr(64, 128, 1200, 1200).form == L.FORM_TILE
+    pl = lr(64, 128, 1200, 1200, sq=True)
+    assert (pl.form, pl.waves) == (L.FORM_GEMM, 4)
+    assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 8
+    pl = lr(1, 128, 1200, 10)
+    assert (pl.form, pl.batch_rows, pl.k_classes) == (L.FORM_TILE, 32, 4)
+    # invariants over a sweep of shapes
+    for S in (1, 2, 3, 8, 31, 64):
+        for B in (1, 16, 100, 128, 300):
+            for K in (1, 8, 50, 784, 1200, 4096):
+                for N in (1, 10, 50, 1200, 4096):
+                    for pl in (bbb(S, B, K, N), lr(S, B, K, N), bbb(S, B, K, N, math=L.MATH_F32, xdt=L.F32)):
+                        assert 1 <= pl.waves <= 16 and pl.lds_bytes <= 160 * 1024 and pl.blocks >= 1
+                        assert pl.form in (L.FORM_TILE, L.FORM_GEMM, L.FORM_GEMM_KSLICE)
+                        assert pl.k_classes in (1, 2, 4) and pl.batch_rows in (32, 128)
