@@ -246,6 +246,17 @@ def g6():
                 tup = net.sample_elbo_lr(xt, yt, 0.5, S) if lr else net.sample_elbo(xt, yt, 0.5, S)
             for i, t in enumerate(tup):
                 rec[f"t{i}"] = f64(t)
+            if S == 2:
+                # gradient evidence at full C2 size (the reference's loss.backward(), class_task.py:78): every 997th
+                # element (997 is prime: the stride walks all rows and columns) and the L2 norm of all 12 .grad tensors
+                install_eps(net, B, S, lr)
+                net.zero_grad()
+                tup = net.sample_elbo_lr(xt, yt, 0.5, S) if lr else net.sample_elbo(xt, yt, 0.5, S)
+                tup[0].backward()
+                for n, p_ in net.named_parameters():
+                    g = p_.grad.detach().double().flatten()
+                    rec[f"grad_sub/{n}"] = g[::997].numpy().astype(np.float64)
+                    rec[f"grad_l2/{n}"] = np.float64(float(g.pow(2).sum().sqrt()))
             flatten(f"G6/{name}/S{S}", rec, out)
     torch.set_num_threads(1)
     np.savez_compressed(os.path.join(OUT, "net_c2.npz"), **out)

@@ -1,8 +1,8 @@
 """GPU parity: the HIP path (through the drop-in networks.py and the C ABI) against
 (i) the golden vectors recorded from the real reference and (ii) the CPU oracle on
 identical epsilon.  Tolerances (fp32 path): outputs and scalars rtol 2e-5 — the target
-the north star states is rtol 1e-4 for KL/ELBO.  bf16-operand math: logits 3e-2 of the
-output scale, NLL 1e-3, complexity scalars (always fp32) 2e-5."""
+the north star states is rtol 1e-4 for KL/ELBO.  bf16-operand math: logits and NLL to 3x the error
+measured at C2 (BF16_LOGIT_TOL, BF16_NLL_RTOL below), complexity scalars (always fp32) 2e-5."""
 import math
 
 import numpy as np
@@ -17,6 +17,13 @@ from bnn_hip import ops, synth
 from oracle import bnn_oracle as O
 
 F32_RTOL = 2e-5
+# bf16-operand error of the C2 network, MEASURED on MI355X by test_timed_path_against_oracle_on_philox_eps (printed with
+# -s; round 2, 16 configurations): the NLL of one (minibatch, MC sample) pair moves by 1.4e-4 .. 1.9e-3 relative to the
+# fp32 oracle, the logits by 4.3e-3 .. 6.0e-3 of their scale.  That is ~30x what SURVEY 7.3 priced for bf16 MFMA
+# OPERANDS alone (5.5e-5): this path also ROUNDS the two hidden activations to bf16 between layers (2-byte activation
+# traffic), and the summed cross-entropy of 128 rows amplifies logit noise.  Tolerances = 3x the largest error seen.
+BF16_NLL_RTOL = 5.5e-3
+BF16_LOGIT_TOL = 1.8e-2
 
 
 @pytest.fixture(scope="module")
@@ -314,7 +321,7 @@ def test_c2_mnist_shape_elbo(g_c2, dev, variant, math_mode):
         nll0 = net.get_nll(logits, yd)
     scale = float(c1["logits_s0_absmax"])
     close(logits[:2], c1["logits_s0_rows01"], rtol=0, atol=(2e-5 if f32 else 3e-2) * scale)
-    close(nll0, c1["nll_s0"], rtol=2e-5 if f32 else 2e-3)
+    close(nll0, c1["nll_s0"], rtol=2e-5 if f32 else BF16_NLL_RTOL)
     for li, l in enumerate((net.l1, net.l2, net.l3)):
         if lr:
             close(l.kl_cost, c1[f"l{li+1}/kl"])
@@ -326,10 +333,32 @@ def test_c2_mnist_shape_elbo(g_c2, dev, variant, math_mode):
         install_eps(net, 128, S, lr)
         with torch.no_grad():
             tup = (net.sample_elbo_lr if lr else net.sample_elbo)(xd, yd, 0.5, S)
-        nll_tol = 2e-5 if f32 else 2e-3
+        nll_tol = 2e-5 if f32 else BF16_NLL_RTOL
         tols = [1e-4, F32_RTOL, nll_tol] if lr else [1e-4, F32_RTOL, F32_RTOL, nll_tol]   # ELBO: rtol 1e-4 (north star)
         for i, v in enumerate(tup):
             close(v, c[f"t{i}"], rtol=tols[i])
+
+
+@pytest.mark.parametrize("variant", ["bbb", "mix", "lr"])
+def test_c2_gradients_through_the_hip_backward(g_c2, dev, variant):
+    """loss.backward() at full C2 size (S = 2, beta = 0.5) through the HIP backward kernels, fp32 math, on the
+    reference's epsilon, against gradient vectors recorded from the REAL reference (golden G6: every 997th element
+    and the L2 norm of all 12 .grad tensors, classification/class_task.py:78)."""
+    lr = variant == "lr"
+    net, _ = build_net(dev, lr, (784, 1200, 10), "classification",
+                       (0.5, 0.0, -6.0) if variant == "mix" else (1.0,), variant == "mix")
+    x, y = synth.synth_batch("classification", 128, 784, 10)
+    c = g_c2.case(f"G6/{variant}/S2")
+    install_eps(net, 128, 2, lr)
+    net.zero_grad()
+    tup = (net.sample_elbo_lr if lr else net.sample_elbo)(t(x).to(dev), t(y).to(dev), 0.5, 2)
+    close(tup[0], c["t0"], rtol=1e-4)
+    tup[0].backward()
+    for n, p_ in net.named_parameters():
+        g = p_.grad.double().flatten().cpu()
+        sub = c[f"grad_sub/{n}"]
+        np.testing.assert_allclose(g[::997].numpy(), sub, rtol=2e-4, atol=2e-5 * float(np.abs(sub).max()), err_msg=n)
+        close(float(g.pow(2).sum().sqrt()), c[f"grad_l2/{n}"], rtol=2e-5)
 
 
 # ------------------------------------------------------------------ size-independent properties
@@ -446,7 +475,7 @@ def test_lr_throughput_path_against_oracle(dev, monkeypatch, force_gemm, S):
     with torch.no_grad():
         got = net.sample_elbo_lr(t(x).to(dev), t(y).to(dev), 0.5, S)
     close(got[1], ref[1].numpy())                       # KL: fp32 statistics
-    close(got[2], ref[2].numpy(), rtol=3e-3)            # NLL follows bf16 logits
+    close(got[2], ref[2].numpy(), rtol=BF16_NLL_RTOL)   # NLL follows bf16 logits
     close(got[0], ref[0].numpy(), rtol=1e-4)            # ELBO
 
 
@@ -541,7 +570,7 @@ def test_bbb_throughput_forms_agree(dev, monkeypatch):
         assert ctr == rctr == 300 + S
         close(out["log_prior"], ref["log_prior"].cpu().numpy(), rtol=2e-6)      # statistics are fp32 in every form
         close(out["log_q"], ref["log_q"].cpu().numpy(), rtol=2e-6)
-        close(out["nll"], ref["nll"].cpu().numpy(), rtol=5e-3)                  # bf16 logits
+        close(out["nll"], ref["nll"].cpu().numpy(), rtol=BF16_NLL_RTOL)         # bf16 logits
         close(sums[:2], rsums[:2].cpu().numpy(), rtol=2e-6)
         close(sums[2], float(out["nll"].double().sum()), rtol=1e-6)
         assert float(sums[3]) == S
@@ -761,12 +790,6 @@ def _oracle_pairs(p, xs, ys, seed, base, S):
     return np.asarray(rows, np.float64), np.stack(logits)
 
 
-# bf16-operand error of the C2 network, measured on MI355X by this very test (printed with -s): the NLL of one
-# evaluation moves by 1.3e-4 .. 6e-4 relative to the fp32 oracle (the hidden activations are ROUNDED to bf16 between
-# layers, on top of the bf16 MFMA operands SURVEY 7.3 priced at 5.5e-5), the logits by <= 1.2e-2 of their scale.
-# Tolerances = 3x the largest error seen.
-BF16_NLL_RTOL = 2e-3
-BF16_LOGIT_TOL = 3e-2
 
 
 @pytest.mark.parametrize("G,S", [(1, 1), (1, 8), (4, 2), (16, 1)])

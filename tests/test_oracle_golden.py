@@ -169,6 +169,20 @@ def test_g6_c2_full_size(g_c2, variant):
             tup = fn(p, xt, yt, 0.5, S, eps=eps[:S])
             for i, v in enumerate(tup):
                 close(v.numpy(), c[f"t{i}"], rtol=3e-6)
+        # gradients at full C2 size (S = 2): the oracle's autograd against the reference's, on every 997th element
+        # and the L2 norm of all 12 tensors
+        c = g_c2.case(f"G6/{variant}/S2")
+        for lay in p.layers:
+            for q in lay:
+                q.requires_grad_(True)
+        tup = (O.sample_elbo_lr if lr else O.sample_elbo)(p, xt, yt, 0.5, 2, eps=eps[:2])
+        tup[0].backward()
+        names = [f"l{li+1}.{n}" for li in range(3) for n in synth.PARAM_NAMES]
+        for n, q in zip(names, [q for lay in p.layers for q in lay]):
+            g = q.grad.double().flatten()
+            sub = c[f"grad_sub/{n}"]
+            np.testing.assert_allclose(g[::997].numpy(), sub, rtol=2e-5, atol=2e-6 * float(np.abs(sub).max()))
+            close(float(g.pow(2).sum().sqrt()), c[f"grad_l2/{n}"], rtol=1e-5)
     finally:
         torch.set_num_threads(1)
 

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     if "bnn::" in r["Kernel_Name"]:
         agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out_path = os.path.join(REPO, "profiles", "pmc.json")
+out_path = os.path.join(os.environ.get("BNN_PROFILES_DIR") or os.path.join(REPO, "profiles"), "pmc.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for kern, cs in agg.items():
     m = {c: sum(v) / len(v) for c, v in cs.items()}

@@ -19,7 +19,7 @@ fetch_dir, write_dir, key, kern = sys.argv[1:5]
 fetch_kib, nf = mean_counter(fetch_dir, "FETCH_SIZE", kern)
 write_kib, nw = mean_counter(write_dir, "WRITE_SIZE", kern)
 hbm = 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0
-out_path = os.path.join(REPO, "profiles", "traffic.json")
+out_path = os.path.join(os.environ.get("BNN_PROFILES_DIR") or os.path.join(REPO, "profiles"), "traffic.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 data[key] = {"kernel": kern, "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
              "hbm_bytes_per_launch": hbm, "dispatches_averaged": [nf, nw], "source_hash": source_hash(),
