@@ -25,6 +25,7 @@ EXPORTS = (
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
+    "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
 )
 
 
@@ -256,6 +257,15 @@ def load():
     lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int
     lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.bnn_ece_workspace_bytes.restype = C.c_size_t
+    lib.bnn_ece_workspace_bytes.argtypes = []
+    lib.bnn_ece.restype = C.c_int
+    lib.bnn_ece.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void_p,
+                            C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.bnn_snr_db.restype = C.c_int
+    lib.bnn_snr_db.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.bnn_snr_prune.restype = C.c_int
+    lib.bnn_snr_prune.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]
     v = lib.bnn_version()
     if v != ABI_VERSION:
         raise BnnHipError(f"libbnn_hip.so ABI version {v} != binding version {ABI_VERSION}")

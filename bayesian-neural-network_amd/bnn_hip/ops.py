@@ -737,3 +737,44 @@ def softplus(rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
         out = torch.empty_like(rho)
     L.check(lib.bnn_softplus(rho.data_ptr(), out.data_ptr(), rho.numel(), _stream()), "bnn_softplus")
     return out
+
+
+def ece_bins(probs: torch.Tensor, labels: torch.Tensor, bin_edges) -> torch.Tensor:
+    """F3: bnn_ece.  probs fp32 [n, classes], labels int64[n] on the device, bin_edges a host float64 sequence.
+    Returns float32 [1 + 3 * nbins] = (ece, then per bin count, corrects, confidence sum)."""
+    lib = L.load()
+    require_device(probs, labels)
+    pr = _f32c(probs, "probs")
+    if pr.dim() != 2 or labels.numel() != pr.shape[0]:
+        raise BnnHipError("ece: probs must be [n, classes] and labels [n]")
+    lb = labels.to(torch.int64).contiguous()
+    edges = (C.c_double * len(bin_edges))(*[float(e) for e in bin_edges])
+    ws = torch.empty(lib.bnn_ece_workspace_bytes() // 8, dtype=torch.float64, device=pr.device)
+    out = torch.empty(1 + 3 * (len(bin_edges) - 1), dtype=torch.float32, device=pr.device)
+    L.check(lib.bnn_ece(pr.data_ptr(), lb.data_ptr(), pr.shape[0], pr.shape[1], edges, len(bin_edges), ws.data_ptr(),
+                        ws.numel() * 8, out.data_ptr(), _stream()), "bnn_ece")
+    return out
+
+
+def snr_db(mu: torch.Tensor, rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F4: bnn_snr_db.  10 log10(|mu| / softplus(rho)) elementwise (fp32), shaped like mu."""
+    lib = L.load()
+    require_device(mu, rho)
+    mu, rho = _f32c(mu, "mu"), _f32c(rho, "rho")
+    if mu.numel() != rho.numel():
+        raise BnnHipError("snr_db: mu and rho must have the same number of elements")
+    if out is None:
+        out = torch.empty_like(mu)
+    L.check(lib.bnn_snr_db(mu.data_ptr(), rho.data_ptr(), mu.numel(), out.data_ptr(), _stream()), "bnn_snr_db")
+    return out
+
+
+def snr_prune_(mu: torch.Tensor, rho: torch.Tensor, threshold: float, kept: Optional[torch.Tensor] = None):
+    """F4: bnn_snr_prune, IN PLACE on contiguous fp32 tensors: mu, rho *= (snr_db > threshold)."""
+    lib = L.load()
+    require_device(mu, rho)
+    if mu.dtype != torch.float32 or rho.dtype != torch.float32 or not mu.is_contiguous() or not rho.is_contiguous() or \
+            mu.numel() != rho.numel():
+        raise BnnHipError("snr_prune_: contiguous float32 mu and rho of one size")
+    L.check(lib.bnn_snr_prune(mu.data_ptr(), rho.data_ptr(), mu.numel(), float(threshold), _ptr(kept), _stream()),
+            "bnn_snr_prune")

@@ -567,6 +567,31 @@ int bnn_mc_softmax_mean(const float* logits, int32_t n_samples, int32_t batch, i
                         float* probs, long long* preds, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * F3  bnn_ece — ECELoss.forward of compute_ece.py:14-57 over the MC-averaged class probabilities the predict path
+ * produces (classification/class_task.py:81-87 -> compute_ece.py:62-78): every one of the n x classes probabilities
+ * is binned (np.digitize(p, bin_edges, right=True) - 1), a probability is "correct" when it is its row's argmax and
+ * that argmax is the label; ece = sum_b |mean confidence_b - accuracy_b| * count_b / sum_b count_b.
+ * probs fp32 [n, classes]; labels int64[n]; bin_edges: HOST float64 array of n_edges <= 65 increasing values
+ * (np.arange(0, 1.1, bin_step) for the reference's bins);  out fp32 [1 + 3 * (n_edges - 1)] = {ece, then per bin
+ * count, corrects, confidence sum}.  Bins without data contribute nothing (the reference's loop breaks there).
+ * Integer counts by LDS atomics, fp64 confidence sums in a fixed order: bitwise reproducible.
+ * ---------------------------------------------------------------------------------- */
+size_t bnn_ece_workspace_bytes(void);
+int bnn_ece(const float* probs, const long long* labels, int64_t n, int32_t classes, const double* bin_edges,
+            int32_t n_edges, void* workspace, size_t workspace_bytes, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * F4  signal-to-noise pruning of weight_pruning.py:85-115 over n contiguous fp32 (mu, rho) pairs:
+ *   bnn_snr_db     out[i] = 10 log10(|mu[i]| / log1p(exp(rho[i])))           (:85-87 compute_snr, :100, :109)
+ *   bnn_snr_prune  in place mu[i] *= m, rho[i] *= m with m = (snr_db > threshold)   (:101-105, :110-114);
+ *                  a pruned weight is left at rho = 0 (sigma = log 2), as the reference leaves it.
+ *                  kept (optional device uint64, caller-zeroed): += number of survivors.
+ * The threshold is the caller's np.percentile(snrs, 100 * drop_percentage) (:92).
+ * ---------------------------------------------------------------------------------- */
+int bnn_snr_db(const float* mu, const float* rho, int64_t n, float* out, void* stream);
+int bnn_snr_prune(float* mu, float* rho, int64_t n, float threshold, unsigned long long* kept, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * bnn_philox_normal — materialise the on-chip epsilon stream (map at the top) into
  * eps[n_samples, rows, cols]: used by the backward pass to regenerate eps instead of
  * storing it, and by tests to check the frozen counter->element map.

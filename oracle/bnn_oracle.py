@@ -383,3 +383,66 @@ def philox_eps_for_network(p: NetParams, batch: int, seed: int, sample: int) -> 
             out.append(torch.from_numpy(philox_normal(seed, tensor_id(li, 0), sample, wm.shape[0], wm.shape[1])))
         out.append(torch.from_numpy(philox_normal(seed, tensor_id(li, 1), sample, 1, bm.shape[0]))[0])
     return out
+
+
+# --------------------------------------------------------------------------------------
+# F3 / F4 restatements.  compute_ece.py and weight_pruning.py cannot be imported in the build container (both
+# import seaborn at module scope; nothing can be installed), so these follow the SOURCE TEXT line by line and are
+# NOT pinned by reference-recorded vectors: parity UNPINNED for these two rows.
+# --------------------------------------------------------------------------------------
+def get_one_hot(targets: np.ndarray, nb_classes: int) -> np.ndarray:
+    """compute_ece.py:59-61."""
+    res = np.eye(nb_classes)[np.array(targets).reshape(-1)]
+    return res.reshape(list(targets.shape) + [nb_classes])
+
+
+def ece_reference(probs: np.ndarray, labels: np.ndarray, bin_step: float = 0.1, num_classes: int = 10):
+    """ECELoss.forward, compute_ece.py:22-57, statement by statement.  Returns (ece, bin_centers[have_data], bin_acc).
+    Like the reference it is only meaningful when every bin holds data (an empty bin makes np.mean NaN and the
+    compressed bin_acc array misaligned with the loop index)."""
+    pred_class = np.argmax(probs, axis=1)                                          # :23
+    expanded_preds = np.reshape(probs, -1)                                         # :26
+    pred_class_OH = np.reshape(get_one_hot(pred_class, num_classes), -1)           # :27
+    target_class_OH = np.reshape(get_one_hot(labels, num_classes), -1)             # :28
+    correct_vec = (target_class_OH * (pred_class_OH == target_class_OH)).astype(int)   # :29
+    bins = np.arange(0, 1.1, bin_step)                                             # :32
+    bin_idxs = np.digitize(expanded_preds, bins, right=True)                       # :33
+    bin_idxs = bin_idxs - 1                                                        # :34
+    bin_centers = bins[1:] - bin_step / 2                                          # :36
+    bin_counts = np.ones(len(bin_centers))                                         # :37
+    bin_corrects = np.zeros(len(bin_centers))                                      # :38
+    bin_confidence = np.zeros(len(bin_centers))                                    # :39
+    for nbin in range(len(bin_centers)):                                           # :45-48
+        bin_counts[nbin] = np.sum((bin_idxs == nbin).astype(int))
+        bin_corrects[nbin] = np.sum(correct_vec[bin_idxs == nbin])
+        with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")
+            bin_confidence[nbin] = np.mean(expanded_preds[bin_idxs == nbin])
+    have_data = bin_counts > 0                                                     # :50
+    bin_acc = bin_corrects[have_data] / bin_counts[have_data]                      # :51
+    ece = 0                                                                        # :53-55
+    for i in range(len(bin_confidence)):
+        ece += np.absolute(bin_confidence[i] - bin_acc[i]) * bin_counts[i] / np.sum(bin_counts)
+    return ece, bin_centers[have_data], bin_acc, (bin_counts, bin_corrects, bin_confidence)
+
+
+def compute_snr(mu, sigma):
+    """weight_pruning.py:85-87: signal-to-noise ratio in decibels."""
+    return 10 * np.log10(abs(mu) / sigma)
+
+
+def prune_weights(layers: Sequence[Sequence[torch.Tensor]], snrs, drop_percentage: float = 0.5):
+    """weight_pruning.py:89-115 on a list of (weight_mu, weight_rho, bias_mu, bias_rho) fp32 tensors: returns the
+    pruned copies and the threshold.  Same torch ops, same order."""
+    snr_threshold = np.percentile(snrs, 100 * drop_percentage)                     # :92
+    out = []
+    for weight_mus, weight_rhos, bias_mus, bias_rhos in layers:
+        weight_sigmas = torch.log1p(torch.exp(weight_rhos))                        # :98
+        bias_sigmas = torch.log1p(torch.exp(bias_rhos))                            # :99
+        s = 10 * torch.log10(torch.abs(weight_mus) / weight_sigmas)                # :102
+        mask = (s > snr_threshold).long()                                          # :104-105
+        wm, wr = weight_mus * mask, weight_rhos * mask                             # :106-107
+        s = 10 * torch.log10(torch.abs(bias_mus) / bias_sigmas)                    # :110
+        mask = (s > snr_threshold).long()
+        out.append((wm, wr, bias_mus * mask, bias_rhos * mask))                    # :113-114
+    return out, float(snr_threshold)

@@ -217,3 +217,32 @@ def test_philox_normal_moments():
     assert abs(float(np.corrcoef(e.ravel(), e2.ravel())[0, 1])) < 5e-3
     sub = O.philox_normal(2026, O.tensor_id(1, 0), 3, 7, 1201)
     np.testing.assert_array_equal(sub, e[:7])
+
+
+def test_ece_restatement_known_answer():
+    """F3 oracle (parity UNPINNED: compute_ece.py needs seaborn to import): a hand-computed case.  Two classes, bins of
+    width 0.5: rows (0.9, 0.1) label 0, (0.6, 0.4) label 1, (0.2, 0.8) label 1.  Bin (0, 0.5] holds {0.1, 0.4, 0.2}
+    with no "correct" entry; bin (0.5, 1] holds {0.9, 0.6, 0.8} of which 0.9 and 0.8 are correct argmax entries.
+    ECE = |0.7/3 - 0| * 3/6 + |2.3/3 - 2/3| * 3/6 = 0.11666.. + 0.05 = 0.16666.."""
+    probs = np.asarray([[0.9, 0.1], [0.6, 0.4], [0.2, 0.8]], np.float32)
+    labels = np.asarray([0, 1, 1], np.int64)
+    ece, centers, acc, (cnt, cor, conf) = O.ece_reference(probs, labels, bin_step=0.5, num_classes=2)
+    assert list(cnt) == [3, 3] and list(cor) == [0, 2]
+    close(conf, [np.float32(0.1) / 3 + np.float32(0.4) / 3 + np.float32(0.2) / 3, (0.9 + 0.6 + 0.8) / 3], rtol=1e-6)
+    close(ece, (0.7 / 3) * 0.5 + abs(2.3 / 3 - 2 / 3) * 0.5, rtol=1e-6)
+    close(centers, [0.25, 0.75]); close(acc, [0.0, 2 / 3])
+
+
+def test_snr_pruning_restatement():
+    """F4 oracle (parity UNPINNED): half of the weights go, the survivors are exactly those above the median SNR, a
+    pruned weight is left at rho = 0 (weight_pruning.py:106-107 multiplies rho by the mask too)."""
+    rs = np.random.RandomState(3)
+    layers = [tuple(t(rs.uniform(lo, hi, sh).astype(np.float32)) for lo, hi, sh in
+                    ((-0.2, 0.2, (6, 5)), (-5, -4, (6, 5)), (-0.2, 0.2, (6,)), (-5, -4, (6,))))]
+    mus = np.concatenate([layers[0][0].numpy().ravel(), layers[0][2].numpy().ravel()]).astype(np.float64)
+    sig = np.log(1 + np.exp(np.concatenate([layers[0][1].numpy().ravel(), layers[0][3].numpy().ravel()]).astype(np.float64)))
+    snrs = O.compute_snr(mus, sig)
+    (wm, wr, bm, br), thr = O.prune_weights(layers, snrs, 0.5)[0][0], O.prune_weights(layers, snrs, 0.5)[1]
+    kept = int((wm != 0).sum() + (bm != 0).sum())
+    assert kept == 18 and thr == float(np.percentile(snrs, 50))
+    assert bool(((wm == 0) == (wr == 0)).all()) and bool(((bm == 0) == (br == 0)).all())

@@ -7,7 +7,8 @@ import torch
 from bnn_hip import ops
 dev = torch.device("cuda:0")
 rows = []
-for n in (1200 * 1200, 4096 * 4096, 16 * 4096 * 4096):
+sizes = [int(a) for a in sys.argv[1:]] or [1200 * 1200, 4096 * 4096, 16 * 4096 * 4096]   # 268 M elements = 2.1 GB: above the Infinity Cache
+for n in sizes:
     mu = torch.empty(n, device=dev).uniform_(-0.2, 0.2); rho = torch.empty(n, device=dev).uniform_(-5, -4)
     for _ in range(5): ops.gauss_kl(mu, rho, 1.0)
     torch.cuda.synchronize()
