@@ -51,7 +51,7 @@ class BbbFwdArgs(C.Structure):
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("form", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
-        ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p),
+        ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p), ("rider", C.c_void_p),
     ]
 
 
@@ -70,7 +70,7 @@ class SampleLayer(C.Structure):
 class SampleArgs(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_uint32), ("n_layers", C.c_int32), ("n_samples", C.c_int32), ("sample_offset", C.c_uint32),
-        ("seed", C.c_uint64), ("sample_counter", C.c_void_p),
+        ("seed", C.c_uint64), ("sample_counter", C.c_void_p), ("sample_group", C.c_uint32), ("sample_group_stride", C.c_uint32),
         ("layer", SampleLayer * SAMPLE_MAX_LAYERS),
         ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_n", C.c_int64),
     ]

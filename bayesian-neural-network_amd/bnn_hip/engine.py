@@ -33,6 +33,32 @@ SPLIT_MIN_WEIGHTS = 4_000_000
 FUSED_ELBO_NODE = True
 
 
+# BBB, bf16 math: evaluations of at most this many (minibatch, MC sample) pairs draw the OUTPUT layer's weights beside the
+# layer before it (a sampling job riding on that launch, bnn_bbb_fwd_args.rider) and run the output layer + finalize in
+# the row-split matmul-only form (K1r): the tail of the dependent chain is then ~5 us instead of ~13
+FINAL_ROWS_MAX_SAMPLES = 16
+
+
+def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
+    """The output layer of this evaluation can take the pre-sampled row-split form."""
+    if len(specs) < 2 or any(sp.lr for sp in specs) or hidden_dtype != torch.bfloat16 or state.form != L.FORM_AUTO:
+        return False
+    k_last, n_last = specs[-1].in_out
+    return 0 < n_samples <= FINAL_ROWS_MAX_SAMPLES and n_last <= 16 and batch <= 128 and k_last % 8 == 0
+
+
+# BBB, bf16 math, forward-only: layers fed with at least this many batch rows sample their weights once per launch
+# (bnn_bbb_sample_weights: 8 B read + 2 B written per weight and sample, statistics included) and run the matmul as a
+# plain library GEMM (ops.bbb_library_matmul): 2 * batch flops per sampled weight make the matrix cores the bound, and
+# the fused kernels would redo the sampling for every 128-row batch block
+LIB_GEMM_MIN_BATCH = 512
+
+
+def use_library_gemm(sp, batch: int, hidden_dtype) -> bool:
+    return (not sp.lr) and hidden_dtype == torch.bfloat16 and batch >= LIB_GEMM_MIN_BATCH and sp.in_out[0] % 8 == 0 and \
+        state.form == L.FORM_AUTO
+
+
 def use_split(fin: int, fout: int, n_samples: int) -> bool:
     return fout > 16 and fin * fout >= SPLIT_MIN_WEIGHTS and SPLIT_MIN_SAMPLES <= n_samples < SPLIT_MAX_SAMPLES
 SIGMA_HOIST_MIN_SAMPLES = 24  # BBB: precompute sigma = softplus(rho) once per evaluation from here on
@@ -102,6 +128,10 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
         else:
             h = ops.cast_bf16(x)
     stats = []
+    # forward-only ELBO with on-chip eps: the output layer may take the pre-sampled row-split form (final_rows_ok)
+    rows_final = (not differentiable and fin_kw is not None and want_stats and sample and injected is None and
+                  final_rows_ok(layers, n_local, x.shape[-2], hidden_dtype))
+    presampled = None
     for i, sp in enumerate(layers):
         last = i == len(layers) - 1
         if not sample:
@@ -140,6 +170,15 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
                           sample_offset=first_sample, want_stats=want_stats, form=state.form)
+                if eps_mode == L.EPS_PHILOX and use_library_gemm(sp, h.shape[-2], hidden_dtype):
+                    if h.dtype != torch.bfloat16:
+                        h = ops.cast_bf16(h)
+                    sm = ops.bbb_sample_weights([dict(w_mu=pd[0], w_rho=pd[1], b_mu=pd[2], b_rho=pd[3], prior=call.prior,
+                                                       layer_id=sp.layer_id)], n_samples=n_local, seed=state.seed,
+                                                sample_offset=first_sample)[0]
+                    h = ops.bbb_library_matmul(h, sm["w"], sm["b"], n_samples=n_local, relu=sp.relu, y_dtype=call.y_dtype)
+                    stats.append(sm["workspace"])
+                    continue
                 if h.dtype == torch.bfloat16 and n_local >= SIGMA_HOIST_MIN_SAMPLES and eps_mode != L.EPS_ZERO and \
                         ((sp.in_out[1] + 63) // 64) * n_local >= 450:
                     kw["w_sigma"] = ops.softplus(pd[1])        # consumed by the throughput (GEMM) form only
@@ -147,8 +186,23 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                     kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
-                    out, fin = ops.bbb_final_fwd((h,) + pd, kw, dict(workspaces=stats, **fin_kw))
+                    if presampled is not None:
+                        out, fin = ops.bbb_final_fwd((h, None, None, None, None),
+                                                     dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu,
+                                                          y_dtype=call.y_dtype, eps_mode=L.EPS_ZERO, want_stats=False,
+                                                          w_sampled=presampled["w"], b_sampled=presampled["b"]),
+                                                     dict(workspaces=stats + [presampled["workspace"]], **fin_kw))
+                    else:
+                        out, fin = ops.bbb_final_fwd((h,) + pd, kw, dict(workspaces=stats, **fin_kw))
                     return out["y"], fin
+                if i == len(layers) - 2 and rows_final:
+                    # the output layer's weights are drawn beside this layer (a sampling job riding on its launch)
+                    spl = layers[-1]
+                    kw["rider"] = ops.build_sample_job(
+                        [dict(w_mu=spl.m.weight_mu.detach(), w_rho=spl.m.weight_rho.detach(), b_mu=spl.m.bias_mu.detach(),
+                              b_rho=spl.m.bias_rho.detach(), prior=spl.m._prior_spec, layer_id=spl.layer_id)],
+                        n_samples=n_local, seed=state.seed, sample_offset=first_sample)
+                    presampled = kw["rider"][1][0]
                 out = ops.bbb_linear_fwd(h, *pd, **kw)
             h = out["y"]
             stats.append(out["workspace"])
@@ -354,9 +408,18 @@ class GraphedElbo:
         self.sums = self._sums if self.G > 1 else self._sums.view(4)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = None if self.lr else ops.final_scratch(S, dev)
+        # large batches: sample once per launch, then a plain library GEMM (use_library_gemm)
+        self.lib = [use_library_gemm(sp, B, hid) for sp in self.specs]
+        self.lib_w = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) if lb else None
+                      for sp, lb in zip(self.specs, self.lib)]
+        self.lib_b = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) if lb else None
+                      for sp, lb in zip(self.specs, self.lib)]
+        for i, (sp, lb) in enumerate(zip(self.specs, self.lib)):
+            if lb:
+                self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
-                        S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) else None)
+                        (self.lib[0] or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES))) else None)
         self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
@@ -371,6 +434,12 @@ class GraphedElbo:
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
                           if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
+        self.rows = final_rows_ok(self.specs, S, B, hid)
+        if self.rows:
+            k_last, n_last = self.specs[-1].in_out
+            self.w_last = torch.empty((S, n_last, k_last), dtype=torch.bfloat16, device=dev)
+            self.b_last = torch.empty((S, n_last), dtype=torch.float32, device=dev)
+            self.ws[-1] = ops.sample_workspace(S, k_last, n_last, dev)
         self.graph = None
         if capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
@@ -413,13 +482,34 @@ class GraphedElbo:
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]
+            elif self.lib[i]:
+                ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,
+                                             workspace=self.ws[i], w_out=self.lib_w[i], b_out=self.lib_b[i])],
+                                       n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
+                ops.bbb_library_matmul(h, self.lib_w[i], self.lib_b[i], n_samples=self.n_local, relu=sp.relu,
+                                       y_dtype=self.bufs[i].dtype, out=self.bufs[i])
+                if i == last:
+                    ops.elbo_finalize(workspaces=self.ws, logits=self.bufs[i], **fin_kw)
             else:
                 if self.wsigma[i] is not None:
                     ops.softplus(p[1], out=self.wsigma[i])
                 kw = dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], w_sigma=self.wsigma[i], **common)
-                if i == last:
+                if i == last and self.rows:
+                    ops.bbb_final_fwd((h, None, None, None, None),
+                                      dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
+                                           y_dtype=self.bufs[i].dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=self.bufs[i],
+                                           w_sampled=self.w_last, b_sampled=self.b_last),
+                                      dict(workspaces=self.ws, **fin_kw))
+                elif i == last:
                     ops.bbb_final_fwd((h,) + p, kw, dict(workspaces=self.ws[:last], **fin_kw))
                 else:
+                    if i == last - 1 and self.rows:          # the output layer's weights are drawn beside this layer
+                        spl = self.specs[last]
+                        kw["rider"] = ops.build_sample_job(
+                            [dict(w_mu=spl.m.weight_mu.detach(), w_rho=spl.m.weight_rho.detach(), b_mu=spl.m.bias_mu.detach(),
+                                  b_rho=spl.m.bias_rho.detach(), prior=spl.m._prior_spec, layer_id=spl.layer_id,
+                                  workspace=self.ws[last], w_out=self.w_last, b_out=self.b_last)],
+                            n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
                     ops.bbb_linear_fwd(h, *p, **kw)
             h = self.bufs[i]
         if self.lr:

@@ -111,9 +111,32 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
                out=None, split_scratch=None, w_sigma=None, form: int = 0, sample_group: int = 0,
-               sample_group_stride: int = 0):
-    """Argument block of K1 + the tensors it points at (kept alive by the caller)."""
-    require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b)
+               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None):
+    """Argument block of K1 + the tensors it points at (kept alive by the caller).  `w_sampled` / `b_sampled` (bf16
+    [S,out,in] / fp32 [S,out] from bbb_sample_weights): the matmul-only form, the parameter tensors may then be None.
+    `rider` = the (args, results, keep) of build_sample_job: an independent sampling job carried by the launch."""
+    require_device(x, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, w_sampled, b_sampled)
+    if w_sampled is not None:
+        if w_sampled.dtype != torch.bfloat16 or b_sampled is None or b_sampled.dtype != torch.float32 or \
+                not w_sampled.is_contiguous() or not b_sampled.is_contiguous() or w_sampled.dim() != 3:
+            raise BnnHipError("w_sampled must be contiguous bf16 [S,out,in], b_sampled contiguous fp32 [S,out]")
+        if w_sampled.shape[0] != n_samples or b_sampled.numel() != n_samples * w_sampled.shape[1]:
+            raise BnnHipError("w_sampled / b_sampled do not match n_samples")
+        N, K = w_sampled.shape[1], w_sampled.shape[2]
+        xs, B, Kx, per_sample = _x3(x, n_samples)
+        if Kx != K:
+            raise BnnHipError(f"shape mismatch: x[...,{Kx}] sampled weight {tuple(w_sampled.shape)}")
+        y = out if out is not None else torch.empty((n_samples, B, N), dtype=y_dtype, device=xs.device)
+        a = L.BbbFwdArgs()
+        a.struct_bytes = C.sizeof(L.BbbFwdArgs)
+        a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
+        a.x, a.x_dtype, a.x_per_sample = xs.data_ptr(), _dt(xs), per_sample
+        a.eps_mode, a.math = L.EPS_ZERO, L.MATH_BF16
+        a.want_stats, a.relu = 0, int(relu)
+        a.y, a.y_dtype = y.data_ptr(), _dt(y)
+        a.w_sampled, a.b_sampled = w_sampled.data_ptr(), b_sampled.data_ptr()
+        a.form = int(form)
+        return a, dict(y=y, workspace=None, log_prior=None, log_q=None, eps_w=None, eps_b=None), (xs, w_sampled, b_sampled, y)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     N, K = w_mu.shape
@@ -155,8 +178,10 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     if split_scratch is not None:
         a.split_scratch = split_scratch.data_ptr()
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
+    if rider is not None:
+        a.rider = C.addressof(rider[0])
     res = dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma, rider)
     return a, res, keep
 
 
@@ -187,11 +212,12 @@ def sample_workspace(n_samples: int, fin: int, fout: int, device) -> torch.Tenso
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: int = 0, sample_counter=None, cast=None):
-    """K1s (bnn_bbb_sample_weights): `layers` = list of dicts(w_mu [out,in], w_rho, b_mu, b_rho, prior, layer_id,
-    workspace=None, w_out=None, b_out=None).  One launch samples them all; returns a list of dicts(w [S,out,in] bf16,
+def build_sample_job(layers, *, n_samples: int, seed: int = 0, sample_offset: int = 0, sample_counter=None, cast=None,
+                     sample_group: int = 0, sample_group_stride: int = 0):
+    """Argument block of K1s (bnn_bbb_sample_weights) + its results + the tensors it points at: launched by
+    bbb_sample_weights, or handed to a layer launch as its `rider`.  `layers` = list of dicts(w_mu [out,in], w_rho,
+    b_mu, b_rho, prior, layer_id, workspace=None, w_out=None, b_out=None); results = list of dicts(w [S,out,in] bf16,
     b [S,out] fp32, workspace).  `cast` = (fp32 tensor, bf16 tensor): also converts the input batch in that launch."""
-    lib = L.load()
     if not 1 <= len(layers) <= L.SAMPLE_MAX_LAYERS:
         raise BnnHipError(f"bbb_sample_weights: 1..{L.SAMPLE_MAX_LAYERS} layers per launch")
     a = L.SampleArgs()
@@ -199,7 +225,8 @@ def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: 
     a.n_layers, a.n_samples = len(layers), int(n_samples)
     a.seed, a.sample_offset = seed & 0xFFFFFFFFFFFFFFFF, sample_offset & 0xFFFFFFFF
     a.sample_counter = _ptr(sample_counter)
-    res, keep = [], []
+    a.sample_group, a.sample_group_stride = int(sample_group), int(sample_group_stride)
+    res, keep = [], [sample_counter]
     for i, ly in enumerate(layers):
         w_mu, w_rho = _f32c(ly["w_mu"], "weight_mu"), _f32c(ly["w_rho"], "weight_rho")
         b_mu, b_rho = _f32c(ly["b_mu"], "bias_mu"), _f32c(ly["b_rho"], "bias_rho")
@@ -228,7 +255,7 @@ def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: 
         e.workspace, e.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         e.prior = ly["prior"].c()
         res.append(dict(w=w, b=b, workspace=ws))
-        keep.append((w_mu, w_rho, b_mu, b_rho))
+        keep.append((w_mu, w_rho, b_mu, b_rho, w, b, ws))
     if cast is not None:                      # (fp32 src, bf16 dst): the input batch cast rides on the launch
         src, dst = cast
         require_device(src, dst)
@@ -236,30 +263,64 @@ def bbb_sample_weights(layers, *, n_samples: int, seed: int = 0, sample_offset: 
                 not src.is_contiguous() or not dst.is_contiguous():
             raise BnnHipError("bbb_sample_weights: cast = (contiguous fp32 source, contiguous bf16 destination) of one size")
         a.cast_src, a.cast_dst, a.cast_n = src.data_ptr(), dst.data_ptr(), src.numel()
-    L.check(lib.bnn_bbb_sample_weights(C.byref(a), _stream()), "bnn_bbb_sample_weights")
+        keep.append((src, dst))
+    return a, res, keep
+
+
+def bbb_sample_weights(layers, **kw):
+    """K1s (bnn_bbb_sample_weights): one launch samples every layer of `layers`; see build_sample_job."""
+    a, res, keep = build_sample_job(layers, **kw)
+    L.check(L.load().bnn_bbb_sample_weights(C.byref(a), _stream()), "bnn_bbb_sample_weights")
     return res
 
 
 def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):
     """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s])."""
-    lib = L.load()
+    a, res, keep = _bbb_build(x, None, None, None, None, n_samples=n_samples, prior=PriorSpec(), math_mode=L.MATH_BF16, relu=relu,
+                              y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=out, w_sampled=w, b_sampled=b)
+    L.check(L.load().bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
+    return res["y"]
+
+
+def bbb_library_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):
+    """y[s] = act(x[s] . w[s]^T + b[s]) through the BLAS library (hipBLASLt / rocBLAS behind torch): what is left of a
+    BayesianLinear layer (networks.py:88) once bbb_sample_weights has drawn its weights is a plain bf16 GEMM, and for
+    batches of >= 512 rows the matrix cores, not the sampling, bound the layer (a 1024 x 4096 x 4096 sample is 34 GFLOP
+    against 168 MB of parameters).  x [B,K] (shared) or [rows,B,K] bf16 with rows | n_samples, w bf16 [S,out,in], b
+    fp32 [S,out]; y [S,B,out] in `y_dtype`.  Only the most ordinary library call is used, F.linear (an NT GEMM): one over
+    all samples' weights stacked along the output dimension when they share x, one per sample otherwise; the product
+    leaves the library in bf16 (fp32 accumulation inside), then bias, ReLU and the conversion to `y_dtype` are
+    elementwise passes over y."""
     require_device(x, w, b)
-    if w.dtype != torch.bfloat16 or b.dtype != torch.float32 or not w.is_contiguous() or not b.is_contiguous():
-        raise BnnHipError("bbb_sampled_matmul: w must be contiguous bf16, b contiguous fp32")
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or b.dtype != torch.float32:
+        raise BnnHipError("bbb_library_matmul: bf16 x and w, fp32 b")
     S, N, K = w.shape
-    xs, B, Kx, per_sample = _x3(x, n_samples)
-    if S != n_samples or Kx != K or b.numel() != S * N:
-        raise BnnHipError("bbb_sampled_matmul: shape mismatch")
-    y = out if out is not None else torch.empty((n_samples, B, N), dtype=y_dtype, device=xs.device)
-    a = L.BbbFwdArgs()
-    a.struct_bytes = C.sizeof(L.BbbFwdArgs)
-    a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
-    a.x, a.x_dtype, a.x_per_sample = xs.data_ptr(), _dt(xs), per_sample
-    a.eps_mode, a.math = L.EPS_ZERO, L.MATH_BF16
-    a.want_stats, a.relu = 0, int(relu)
-    a.y, a.y_dtype = y.data_ptr(), _dt(y)
-    a.w_sampled, a.b_sampled = w.data_ptr(), b.data_ptr()
-    L.check(lib.bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
+    if S != n_samples or x.shape[-1] != K or b.numel() != S * N:
+        raise BnnHipError("bbb_library_matmul: shape mismatch")
+    B = x.shape[-2]
+    rows = x.shape[0] if x.dim() == 3 else 1
+    if S % rows:
+        raise BnnHipError("bbb_library_matmul: x row blocks must divide n_samples")
+    g = S // rows
+    y = out if (out is not None and out.dtype == y_dtype) else torch.empty((S, B, N), dtype=y_dtype, device=x.device)
+    if g == 1:
+        # one NT GEMM per sample (each is >= 2 * 512 * out * in flops: large enough alone).  torch.bmm is avoided on
+        # purpose: on this image (torch 2.10 + rocm 7.0 wheels on a ROCm 7.2 gfx950 box) a bf16 bmm of
+        # [4,1024,4096] x [4,4096,4096]^T raises a GPU memory access fault inside the library, mm does not
+        x3 = x.view(S, B, K)
+        for s_ in range(S):
+            y[s_].copy_(torch.nn.functional.linear(x3[s_], w[s_]))
+    else:
+        x3 = x.view(rows, B, K)
+        for r in range(rows):                                                            # one NT GEMM per minibatch
+            prod = torch.nn.functional.linear(x3[r], w[r * g:(r + 1) * g].view(g * N, K))   # [B, g * N]
+            y[r * g:(r + 1) * g].copy_(prod.view(B, g, N).transpose(0, 1))
+    y.add_(b.view(S, 1, N).to(y.dtype))
+    if relu:
+        y.relu_()
+    if out is not None and y is not out:
+        out.copy_(y)
+        return out
     return y
 
 
@@ -434,7 +495,8 @@ def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
     lib = L.load()
     a, res, keep1 = _bbb_build(*layer_args, **layer_kw)
     fin_kw = dict(fin_kw)
-    fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]
+    if layer_kw.get("w_sampled") is None:              # (a pre-sampled layer: its statistics workspace, the sampler's, is
+        fin_kw["workspaces"] = list(fin_kw["workspaces"]) + [res["workspace"]]     # already the last of fin_kw's)
     fin_kw["logits"] = res["y"]
     f, out, keep2 = _fin_build(**fin_kw)
     L.check(lib.bnn_bbb_final_fwd(C.byref(a), C.byref(f), _stream()), "bnn_bbb_final_fwd")

@@ -32,6 +32,7 @@
 // sum log sigma (s = 0 only), 0} for the features of tile t.
 #include "bnn_device.h"
 #include "bnn_fin.h"
+#include "bbb_sample_body.h"
 #include "../../include/bnn_hip.h"
 #include <string.h>
 
@@ -689,6 +690,170 @@ __global__ __launch_bounds__(768) void bbb_fwd_final_kernel(const BbbK p, const 
   bbb_fwd_body<MATH, XDT, 1, true, true>(p, &fp);
 }
 
+// K1a carrying an independent sampling job (bnn_bbb_fwd_args.rider) as extra blocks behind its own (whose count the
+// launcher pads to a multiple of 8, so the XCD-aware work order of the layer's blocks is unchanged).
+template <int XDT, int R>
+__global__ __launch_bounds__(768) void bbb_fwd_rider_kernel(const BbbK p, const SampleK sk, int n_main) {
+  if ((int)blockIdx.x >= n_main) {                         // block-uniform
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    sample_block(sk, (int)blockIdx.x - n_main, lds);
+    return;
+  }
+  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false>(p, nullptr);
+}
+
+// K1r  the output layer of a few-sample evaluation over PRE-SAMPLED weights, split by batch rows, with the finalize.
+// Grid: per sample RB = ceil(B / 16) row blocks + 1 statistics block, 256 threads each.
+//   row block : logits of its 16 batch rows = bf16 x . w^T (4 waves split the k-steps, every load of a wave issued
+//               before its MFMAs; one LDS round to add the waves up), + bias, stored; the rows' NLL (networks.py:183-190).
+//   stats     : the layers' log p / log q partial sums (networks.py:174-178), as K4 forms them.
+// Hand-off (placement-independent, nobody waits): each block's thread 0 stores its scalar(s) write-through (agent-scope
+// relaxed atomic store = sc1), drains (vmcnt(0)) and takes a ticket; the block whose ticket is last reads the RB + 2
+// scalars back with agent-scope loads, in a fixed order, and writes the sample's outputs.  Samples meet the same way.
+struct FinRows {
+  const __bf16* x;      // [S | shared, B, K]
+  long x_sstride;
+  int xg;
+  const __bf16* w;      // [S, N, K]
+  const float* b;       // [S, N]
+  float* y;             // [S, B, N]
+  int S, B, K, N, relu;
+  uint32_t* tickets;    // [S], zero between launches
+  float* parts;         // [S][16]: 0..7 the row blocks' NLL, 8 / 9 log p (KL) / log q
+};
+
+__global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, const FinPack fp) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4][64];
+  __shared__ float lg[16][17];
+  __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
+  const FinK& fk = fp.k;
+  const int RB = (p.B + 15) >> 4;
+  const int s = (int)blockIdx.x / (RB + 1), rb = (int)blockIdx.x - s * (RB + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pub0 = 0.f, pub1 = 0.f;
+  int slot = rb;                                            // where thread 0 publishes
+  if (rb == RB) {
+    // ---- statistics block: every layer's partial sums of sample s (no logits: nll stays 0)
+    int T[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) T[l] = (l < fk.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
+    float a = 0.f, b = 0.f, nll = 0.f;
+    fin_sample(fk, fp.c, s, T, nullptr, 0, -1, 0.f, 0.f, 0.f, part, a, b, nll);
+    pub0 = a;
+    pub1 = b;
+    slot = 8;
+  } else {
+    const int r = lane & 15, q = lane >> 4;
+    const int K = p.K, N = p.N, B = p.B;
+    const int row = min(rb * 16 + r, B - 1);
+    const __bf16* xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
+    const __bf16* wr = p.w + ((size_t)s * N + min(r, N - 1)) * K;
+    const int ksteps = (K + 31) >> 5;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 10;                                   // k-steps in flight per wave: 38 steps of the 1200-wide layer = one round
+    for (int base = wave; base < ksteps; base += 4 * U) {
+      float4 xa[U], wa[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (base + 4 * u) * 32 + q * 8;
+        const int kk = min(k, K - 8);
+        xa[u] = *reinterpret_cast<const float4*>(xr + kk);
+        wa[u] = *reinterpret_cast<const float4*>(wr + kk);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (base + 4 * u) * 32 + q * 8;
+        const bool ok = (base + 4 * u) < ksteps && k < K && r < N;    // past the reduction / a padding feature: zero weights
+        const float4 wz = ok ? wa[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wz), __builtin_bit_cast(bf16x8, xa[u]), acc, 0, 0, 0);
+      }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      // lane (r = batch row of the block, q): features 4q .. 4q+3
+      f32x4 v = red[0][lane];
+#pragma unroll
+      for (int wv = 1; wv < 4; ++wv) v += red[wv][lane];
+      const int brow = rb * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = q * 4 + i;
+        float o = v[i] + (n < N ? p.b[(size_t)s * N + n] : 0.f);
+        if (p.relu) o = fmaxf(o, 0.f);
+        v[i] = o;
+        lg[r][n] = o;
+      }
+      if (brow < B) {
+        float* yp = p.y + ((size_t)s * B + brow) * N + q * 4;
+        if ((N & 3) == 0 && q * 4 < N) {
+          *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < N) yp[i] = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // ---- NLL of the block's rows: lane r < 16 takes row r (the arithmetic of fin_sample's thread-per-row forms)
+      float acc_n = 0.f;
+      const int brow = rb * 16 + lane;
+      if (lane < 16 && brow < B && fk.nll) {
+        const int C = fk.C;
+        if (fk.nll_mode == BNN_NLL_CLASSIFICATION) {
+          const long long* tgt = reinterpret_cast<const long long*>(fk.target) + (fk.group > 0 ? (s / fk.group) * fk.tgt_stride : 0);
+          const long long tc = tgt[brow];
+          float mx = -3.0e38f, se = 0.f;
+          for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[lane][c]);
+          for (int c = 0; c < C; ++c) se += __expf(lg[lane][c] - mx);
+          const float picked = (tc >= 0 && tc < C) ? lg[lane][(int)tc] : __builtin_nanf("");
+          acc_n = (mx + __logf(se)) - picked;
+        } else {
+          const float* tgt = reinterpret_cast<const float*>(fk.target) + (fk.group > 0 ? (s / fk.group) * fk.tgt_stride : 0);
+          for (int c = 0; c < C; ++c) {
+            const float d = tgt[(size_t)brow * C + c] - lg[lane][c];
+            acc_n += (float)((double)(d * d) * fp.c.reg_inv2var + fp.c.reg_const);
+          }
+        }
+      }
+      pub0 = wave_sum(acc_n);
+    }
+  }
+  if (threadIdx.x != 0) return;
+  float* mine = p.parts + (size_t)s * 16;
+  __hip_atomic_store(mine + slot, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (rb == RB) __hip_atomic_store(mine + 9, pub1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t tk = __hip_atomic_fetch_add(p.tickets + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tk != (uint32_t)RB) return;                           // RB + 1 blocks per sample
+  // ---- last block of the sample: fold (row-block order), store the sample's scalars
+  double tn = 0;
+  for (int i = 0; i < RB; ++i) tn += __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float a = __hip_atomic_load(mine + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float b = __hip_atomic_load(mine + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float nll = (float)tn;
+  __hip_atomic_store(p.tickets + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  if (fk.log_prior) __hip_atomic_store(fk.log_prior + s, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.log_q) __hip_atomic_store(fk.log_q + s, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.nll) __hip_atomic_store(fk.nll + s, nll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.S == 1) {
+    if (fp.sums) {
+      fp.sums[0] = a; fp.sums[1] = b; fp.sums[2] = nll; fp.sums[3] = 1.f;
+    }
+    if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+    return;
+  }
+  // ---- samples meet: the sample whose ticket is last folds the 4-vector(s) and advances the Philox counter
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t2 = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t2 != (uint32_t)fk.S - 1u) return;
+  if (fp.sums) fin_fold_sums(fk, fp.sums);
+  __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+}
+
 // matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
 template <int XDT, int R, int MT>
 __global__ __launch_bounds__(768) void bbb_fwd_pre_kernel(const BbbK p) {
@@ -1216,6 +1381,20 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   const int xdt = a->x_dtype, math = a->math;
   hipError_t err = hipSuccess;
   const dim3 grid((unsigned)(((pl.blocks + 7) / 8) * 8)), block(pl.nw * 64);
+  // an independent sampling job rides on a tile-form launch as extra blocks (whole 256-thread sampling blocks);
+  // otherwise it is a launch of its own ahead of the layer
+  SampleK sk;
+  long rider_blocks = 0;
+  bool ride = false;
+  if (a->rider) {
+    rc = fill_sample(a->rider, sk, rider_blocks);
+    if (rc != BNN_OK) return rc;
+    ride = pl.form == BNN_FORM_TILE && !a->w_sampled && al && math == BNN_MATH_BF16 && pl.nw * 64 >= kSampleThreads;
+    if (!ride) {
+      rc = bnn_bbb_sample_weights(a->rider, stream_);
+      if (rc != BNN_OK) return rc;
+    }
+  }
   if (a->w_sampled) {
 #define BNN_PRE(XDT)                                                                              \
   do {                                                                                            \
@@ -1249,6 +1428,26 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
       hipLaunchKernelGGL(ks_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, k.ks_part, pl.ksl, cnt, k.relu, a->y,
                          k.y_bf16, vec_ok);
     }
+  } else if (ride) {
+    const unsigned n_main = (unsigned)(((pl.blocks + 7) / 8) * 8);
+    const dim3 grid_r(n_main + (unsigned)rider_blocks);
+    const size_t lds_r = pl.lds > (size_t)pl.nw * 3 * sizeof(float) ? pl.lds : (size_t)pl.nw * 3 * sizeof(float);
+#define BNN_RIDE(XDT, RR)                                                                                    \
+  do {                                                                                                       \
+    err = allow_big_lds(bbb_fwd_rider_kernel<XDT, RR>, lds_r);                                               \
+    if (err == hipSuccess)                                                                                   \
+      hipLaunchKernelGGL((bbb_fwd_rider_kernel<XDT, RR>), grid_r, block, lds_r, stream, k, sk, (int)n_main); \
+  } while (0)
+#define BNN_RIDE_R(XDT)                          \
+  do {                                           \
+    if (pl.R == 1) BNN_RIDE(XDT, 1);             \
+    else if (pl.R == 2) BNN_RIDE(XDT, 2);        \
+    else BNN_RIDE(XDT, 4);                       \
+  } while (0)
+    if (xdt == BNN_F32) BNN_RIDE_R(BNN_F32); else BNN_RIDE_R(BNN_BF16);
+#undef BNN_RIDE
+#undef BNN_RIDE_R
+    if (err != hipSuccess) return (int)err;
   } else {
 #define BNN_GO(MATH, XDT, RR, AL)                                                              \
   do {                                                                                         \
@@ -1308,6 +1507,36 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   rc = make_fin(f, fp.k, fp.c);
   if (rc != BNN_OK) return rc;
   const int nl = f->n_layers;
+  if (a->w_sampled) {
+    // ---- pre-sampled output layer: the row-split form (K1r) when the shapes allow it, else matmul-only K1 + K4
+    const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features;
+    const bool rows = a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 64 && !f->local_reparam &&
+                      nl >= 1 && f->n_samples == S && f->classes == N && f->batch == B && f->logits == a->y && f->nll &&
+                      f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
+                      !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) && !a->rider &&
+                      (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(a->y) & 15));
+    if (!rows) {
+      rc = bnn_bbb_linear_fwd(a, stream_);
+      return rc != BNN_OK ? rc : bnn_elbo_finalize(f, stream_);
+    }
+    FinRows fr;
+    fr.x = reinterpret_cast<const __bf16*>(a->x);
+    fr.x_sstride = k.x_sstride; fr.xg = k.xg;
+    fr.w = k.w_pre; fr.b = k.b_pre;
+    fr.y = reinterpret_cast<float*>(a->y);
+    fr.S = S; fr.B = B; fr.K = K; fr.N = N; fr.relu = a->relu ? 1 : 0;
+    char* base = reinterpret_cast<char*>(f->scratch);
+    fr.tickets = reinterpret_cast<uint32_t*>(base);
+    fr.parts = reinterpret_cast<float*>(base + (((size_t)S * 4 + 255) / 256) * 256);      // the K-slice statistics' region
+    fp.sums = f->sums;
+    fp.ticket = f->ticket;
+    fp.ks = 1; fp.ks_ticket = nullptr; fp.ks_stats = nullptr; fp.ks_tiles = nullptr;
+    const int RB = (B + 15) / 16;
+    hipLaunchKernelGGL(bbb_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       fr, fp);
+    const hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? BNN_OK : (int)e2;
+  }
   const bool fuse = al && a->out_features <= 16 && a->batch <= 128 && a->want_stats && !f->local_reparam && nl >= 1 &&
                     f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
                     f->classes == a->out_features && f->batch == a->batch && a->y_dtype == BNN_F32 &&

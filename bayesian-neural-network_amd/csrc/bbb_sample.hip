@@ -18,176 +18,18 @@
 // in_features % 8 == 0 and 16-byte aligned bases.  Statistics: one float4 {sum eps^2, sum w^2 | sum log p_mix,
 // sum log sigma (sample 0 only), 0} per block, in the layer's K1 workspace format (entry count in word 0), so
 // bnn_elbo_finalize / bnn_bbb_final_fwd read them exactly as they read K1a's tile partials.
-#include "bnn_device.h"
-#include "../../include/bnn_hip.h"
-#include <math.h>
+#include "bbb_sample_body.h"
 
 namespace bnn {
 
-constexpr int kSampleThreads = 256;
-constexpr int kSampleOctets = 2 * kSampleThreads;     // octets per block
-
-struct SampleL {
-  const float* w_mu;
-  const float* w_rho;
-  const float* b_mu;
-  const float* b_rho;
-  __bf16* w_out;
-  float* b_out;
-  float4* ws;
-  int K, N;
-  uint32_t layer_id;
-  int first_block;      // of the layer
-  int T;                // blocks (= statistics entries) per sample
-  int bias_per_block;   // block `chunk` also samples biases [chunk * bpb, (chunk + 1) * bpb)
-  int prior_kind;
-  float inv2var1, c1, inv2var2, c2, pi;
-};
-
-struct SampleK {
-  SampleL L[BNN_SAMPLE_MAX_LAYERS];
-  int n_layers, S;
-  uint32_t k0, k1, sample_offset;
-  const uint32_t* sample_counter;
-  const float* cast_src;   // optional rider: cast_dst[i] = bf16(cast_src[i]), the evaluation's input batch
-  __bf16* cast_dst;
-  long cast_n;
-  int cast_first;          // first block of the cast job (after every layer's blocks)
-};
-
-// the mixture density (argument of the log; accumulated with add_log: explicit contraction, see bnn_device.h)
-__device__ __forceinline__ float sample_mix_p(const SampleL& L, float w) {
-  const float w2 = w * w;
-  const float p1 = fast_exp(__builtin_fmaf(-w2, L.inv2var1, L.c1));
-  const float p2 = fast_exp(__builtin_fmaf(-w2, L.inv2var2, L.c2));
-  return __builtin_fmaf(L.pi, p1, (1.0f - L.pi) * p2);
-}
-
 __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const SampleK p) {
-  __shared__ float red[kSampleThreads / 64][3];
-  if ((int)blockIdx.x >= p.cast_first) {                   // rider: fp32 -> bf16 of the input batch, 8 per thread
-    const long i = ((long)((int)blockIdx.x - p.cast_first) * kSampleThreads + threadIdx.x) * 8;
-    if (i + 7 < p.cast_n && (p.cast_n & 7) == 0) {
-      const float4 a = *reinterpret_cast<const float4*>(p.cast_src + i), b = *reinterpret_cast<const float4*>(p.cast_src + i + 4);
-      bf16x8 o;
-      o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-      o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
-      *reinterpret_cast<bf16x8*>(p.cast_dst + i) = o;
-    } else {
-      for (long j = i; j < i + 8 && j < p.cast_n; ++j) p.cast_dst[j] = (__bf16)p.cast_src[j];
-    }
-    return;
-  }
-  int l = 0;
-#pragma unroll 1
-  while (l + 1 < p.n_layers && (int)blockIdx.x >= p.L[l + 1].first_block) ++l;
-  const SampleL& L = p.L[l];
-  const int local = (int)blockIdx.x - L.first_block;
-  const int s = local / L.T, chunk = local - s * L.T;
-  const int K = L.K, N = L.N;
-  const int opr = K >> 3;                                  // octets per row
-  const long total = (long)N * opr;
-  const uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u) + (uint32_t)s;
-  const uint32_t gpr = (uint32_t)(K >> 2);
-  const uint32_t wid = L.layer_id * 4u;
-  const bool do_ls = s == 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-  // ---- all parameter loads of the thread's two octets first (clamped addresses: no load under a branch)
-  long o[2];
-  int n[2], k[2];
-  float4 m[2][2], r[2][2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    o[u] = (long)chunk * kSampleOctets + u * kSampleThreads + threadIdx.x;
-    const long oc = o[u] < total ? o[u] : total - 1;
-    n[u] = (int)(oc / opr);
-    k[u] = (int)(oc - (long)n[u] * opr) << 3;
-    const size_t off = (size_t)n[u] * K + k[u];
-    m[u][0] = *reinterpret_cast<const float4*>(L.w_mu + off);
-    m[u][1] = *reinterpret_cast<const float4*>(L.w_mu + off + 4);
-    r[u][0] = *reinterpret_cast<const float4*>(L.w_rho + off);
-    r[u][1] = *reinterpret_cast<const float4*>(L.w_rho + off + 4);
-  }
-  // this block's share of the biases: one per thread of the first few threads
-  const int bn = chunk * L.bias_per_block + (int)threadIdx.x;
-  const bool has_bias = (int)threadIdx.x < L.bias_per_block && bn < N;
-  float bmu = 0.f, brho = 0.f;
-  if (has_bias) {
-    bmu = L.b_mu[bn];
-    brho = L.b_rho[bn];
-  }
-  __builtin_amdgcn_sched_barrier(0);                      // the loads stay one batch ahead of the generator work
-
-  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const bool ok = o[u] < total;
-    const uint32_t g = (uint32_t)n[u] * gpr + (uint32_t)(k[u] >> 2);
-    float e[8];
-    philox_normal4(g, gs, wid, p.k0, p.k1, e);
-    philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
-    const float mu[8] = {m[u][0].x, m[u][0].y, m[u][0].z, m[u][0].w, m[u][1].x, m[u][1].y, m[u][1].z, m[u][1].w};
-    const float rh[8] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y, r[u][1].z, r[u][1].w};
-    float w[8], e2 = 0.f, a = 0.f, ls = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float sg = softplus(rh[j]);
-      w[j] = __builtin_fmaf(sg, e[j], mu[j]);
-      e2 = __builtin_fmaf(e[j], e[j], e2);
-      if (L.prior_kind == BNN_PRIOR_GAUSS) a = __builtin_fmaf(w[j], w[j], a);
-      else a = add_log(a, sample_mix_p(L, w[j]));
-      if (do_ls) ls = add_log(ls, sg);
-    }
-    s_e2 += ok ? e2 : 0.f;
-    s_a += ok ? a : 0.f;
-    s_ls += ok ? ls : 0.f;
-    if (ok) {
-      bf16x8 wb;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wb[j] = (__bf16)w[j];
-      *reinterpret_cast<bf16x8*>(L.w_out + ((size_t)s * N + n[u]) * K + k[u]) = wb;
-    }
-  }
-  if (has_bias) {
-    float e4[4];
-    philox_normal4((uint32_t)(bn >> 2), gs, wid + 1u, p.k0, p.k1, e4);
-    const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
-    const float sg = softplus(brho);
-    const float b = __builtin_fmaf(sg, e, bmu);
-    L.b_out[(size_t)s * N + bn] = b;
-    s_e2 = __builtin_fmaf(e, e, s_e2);
-    s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
-    if (do_ls) s_ls = add_log(s_ls, sg);
-  }
-  const float a0 = wave_sum(s_e2), a1 = wave_sum(s_a), a2 = wave_sum(s_ls);
-  if (lane == 0) {
-    red[wave][0] = a0;
-    red[wave][1] = a1;
-    red[wave][2] = a2;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < kSampleThreads / 64; ++wv) {
-      t0 += red[wv][0];
-      t1 += red[wv][1];
-      t2 += red[wv][2];
-    }
-    L.ws[1 + (size_t)s * L.T + chunk] = make_float4(t0, t1, t2, 0.f);
-    if (local == 0) L.ws[0] = make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f);
-  }
+  __shared__ float red[(kSampleThreads / 64) * 3];
+  sample_block(p, (int)blockIdx.x, red);
 }
 
 }  // namespace bnn
 
 using namespace bnn;
-
-static inline int sample_chunks(int K, int N) {
-  const long octets = (long)N * (K >> 3);
-  return (int)((octets + kSampleOctets - 1) / kSampleOctets);
-}
 
 extern "C" size_t bnn_bbb_sample_workspace_bytes(int32_t n_samples, int32_t in_features, int32_t out_features) {
   if (n_samples <= 0 || in_features <= 0 || out_features <= 0 || (in_features & 7)) return 0;
@@ -198,62 +40,10 @@ extern "C" size_t bnn_bbb_sample_workspace_bytes(int32_t n_samples, int32_t in_f
 }
 
 extern "C" int bnn_bbb_sample_weights(const bnn_bbb_sample_args* a, void* stream_) {
-  if (!a) return BNN_ERR_NULL;
-  if (a->struct_bytes != sizeof(bnn_bbb_sample_args)) return BNN_ERR_ABI;
-  if (a->n_layers <= 0 || a->n_layers > BNN_SAMPLE_MAX_LAYERS || a->n_samples <= 0) return BNN_ERR_SHAPE;
   SampleK k;
   long blocks = 0;
-  const double c0 = -0.91893853320467274178;
-  for (int i = 0; i < a->n_layers; ++i) {
-    const bnn_bbb_sample_layer& l = a->layer[i];
-    if (l.in_features <= 0 || l.out_features <= 0 || (l.in_features & 7)) return BNN_ERR_SHAPE;
-    if (!l.w_mu || !l.w_rho || !l.b_mu || !l.b_rho || !l.w_out || !l.b_out || !l.workspace) return BNN_ERR_NULL;
-    if ((unsigned)l.prior.kind > 1u) return BNN_ERR_ENUM;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(l.w_mu) | reinterpret_cast<uintptr_t>(l.w_rho) |
-                         reinterpret_cast<uintptr_t>(l.w_out) | reinterpret_cast<uintptr_t>(l.workspace);
-    if (al & 15) return BNN_ERR_ALIGN;
-    if (l.workspace_bytes < bnn_bbb_sample_workspace_bytes(a->n_samples, l.in_features, l.out_features))
-      return BNN_ERR_WORKSPACE;
-    SampleL& o = k.L[i];
-    o.w_mu = l.w_mu; o.w_rho = l.w_rho; o.b_mu = l.b_mu; o.b_rho = l.b_rho;
-    o.w_out = reinterpret_cast<__bf16*>(l.w_out); o.b_out = l.b_out; o.ws = reinterpret_cast<float4*>(l.workspace);
-    o.K = l.in_features; o.N = l.out_features; o.layer_id = l.layer_id;
-    o.first_block = (int)blocks;
-    o.T = sample_chunks(l.in_features, l.out_features);
-    o.bias_per_block = (l.out_features + o.T - 1) / o.T;
-    if (o.bias_per_block > kSampleThreads) return BNN_ERR_SHAPE;     // in_features < 8 per 256 outputs: not a layer shape
-    o.prior_kind = l.prior.kind;
-    o.pi = l.prior.pi;
-    if (l.prior.kind == BNN_PRIOR_MIXTURE) {
-      if (!(l.prior.sigma1 > 0.f) || !(l.prior.sigma2 > 0.f)) return BNN_ERR_SHAPE;
-      o.inv2var1 = (float)(1.0 / (2.0 * (double)l.prior.sigma1 * l.prior.sigma1));
-      o.inv2var2 = (float)(1.0 / (2.0 * (double)l.prior.sigma2 * l.prior.sigma2));
-      o.c1 = (float)(c0 - log((double)l.prior.sigma1));
-      o.c2 = (float)(c0 - log((double)l.prior.sigma2));
-    } else {
-      if (!(l.prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
-      o.inv2var1 = o.inv2var2 = o.c1 = o.c2 = 0.f;
-    }
-    blocks += (long)o.T * a->n_samples;
-    if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
-  }
-  for (int i = a->n_layers; i < BNN_SAMPLE_MAX_LAYERS; ++i) {
-    k.L[i] = k.L[0];
-    k.L[i].first_block = (int)blocks;
-  }
-  k.n_layers = a->n_layers; k.S = a->n_samples;
-  k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
-  k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
-  k.cast_src = a->cast_src; k.cast_dst = reinterpret_cast<__bf16*>(a->cast_dst); k.cast_n = (long)a->cast_n;
-  k.cast_first = (int)blocks;
-  if (a->cast_n > 0) {
-    if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
-    if ((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst)) & 15) return BNN_ERR_ALIGN;
-    blocks += (a->cast_n + kSampleThreads * 8 - 1) / (kSampleThreads * 8);
-    if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
-  } else if (a->cast_n < 0) {
-    return BNN_ERR_SHAPE;
-  }
+  const int rc = fill_sample(a, k, blocks);
+  if (rc != BNN_OK) return rc;
   hipLaunchKernelGGL(bbb_sample_kernel, dim3((unsigned)blocks), dim3(kSampleThreads), 0, reinterpret_cast<hipStream_t>(stream_),
                      k);
   const hipError_t err = hipGetLastError();

@@ -138,6 +138,8 @@ typedef struct bnn_plan {
  * layer's per-sample scalars float[n_samples] (the values BayesianLinear stores in
  * self.log_prior / self.log_variational_posterior).
  * ---------------------------------------------------------------------------------- */
+struct bnn_bbb_sample_args;
+
 typedef struct bnn_bbb_fwd_args {
   uint32_t struct_bytes;
   int32_t n_samples, batch, in_features, out_features;
@@ -185,6 +187,11 @@ typedef struct bnn_bbb_fwd_args {
                                (want_stats must be 0; w_mu .. eps_* are ignored and may be NULL).  bf16 math,
                                in_features % 8 == 0, 16-byte aligned x and w_sampled */
   const float* b_sampled;   /* with w_sampled: fp32 [n_samples,out] */
+  const struct bnn_bbb_sample_args* rider; /* optional: an INDEPENDENT bnn_bbb_sample_weights(rider) job, carried by this
+                               launch as extra blocks when it takes the tile form in bf16 math (launched on its own
+                               ahead of the layer otherwise: same results).  Sampling depends on no activation: the
+                               output layer's weights are drawn beside the layer before it, and the output layer of a
+                               few-sample evaluation becomes a matmul-only launch (bnn_bbb_final_fwd, w_sampled) */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
@@ -226,6 +233,8 @@ typedef struct bnn_bbb_sample_args {
   uint32_t sample_offset;
   uint64_t seed;
   const uint32_t* sample_counter;   /* optional device word, as in bnn_bbb_fwd_args */
+  uint32_t sample_group;            /* sample groups, as in bnn_bbb_fwd_args; 0 = none */
+  uint32_t sample_group_stride;
   bnn_bbb_sample_layer layer[BNN_SAMPLE_MAX_LAYERS];
   const float* cast_src;            /* optional rider on the same launch: cast_dst[i] = bf16(cast_src[i]), */
   void* cast_dst;                   /* i < cast_n -- the evaluation's input batch for the bf16 matmuls      */
@@ -376,7 +385,12 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
  * fin->logits == layer->y and fin->layer_workspace[n_layers-1] == layer->workspace, but in ONE
  * launch when the layer is a single feature tile (out_features <= 16, batch <= 128): the block
  * that produced a sample's logits also forms its NLL (networks.py:183-190) and log p / log q
- * (networks.py:174-178).  Falls back to the two launches otherwise. */
+ * (networks.py:174-178).  Falls back to the two launches otherwise.
+ * With layer->w_sampled / b_sampled (the layer's weights drawn earlier by bnn_bbb_sample_weights, its statistics in
+ * fin->layer_workspace[n_layers-1]; bf16 math, <= 64 samples, fin->scratch given): the row-split form -- every
+ * 16-row batch block of a sample is a block of its own (plain bf16 matmul + the rows' NLL), one more block sums the
+ * layers' statistics, and the last block of the sample to finish folds the handful of scalars (write-through
+ * stores + one arrival counter: no block waits, no fence). */
 size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);
 int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* layer, const bnn_finalize_args* fin, void* stream);
 

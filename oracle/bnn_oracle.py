@@ -398,8 +398,8 @@ def get_one_hot(targets: np.ndarray, nb_classes: int) -> np.ndarray:
 
 def ece_reference(probs: np.ndarray, labels: np.ndarray, bin_step: float = 0.1, num_classes: int = 10):
     """ECELoss.forward, compute_ece.py:22-57, statement by statement.  Returns (ece, bin_centers[have_data], bin_acc).
-    Like the reference it is only meaningful when every bin holds data (an empty bin makes np.mean NaN and the
-    compressed bin_acc array misaligned with the loop index)."""
+    Like the reference it is only meaningful when every bin holds data: an empty bin makes np.mean NaN and the
+    compressed bin_acc array misaligned with the loop index (IndexError in the reference; NaN here)."""
     pred_class = np.argmax(probs, axis=1)                                          # :23
     expanded_preds = np.reshape(probs, -1)                                         # :26
     pred_class_OH = np.reshape(get_one_hot(pred_class, num_classes), -1)           # :27
@@ -421,8 +421,11 @@ def ece_reference(probs: np.ndarray, labels: np.ndarray, bin_step: float = 0.1, 
     have_data = bin_counts > 0                                                     # :50
     bin_acc = bin_corrects[have_data] / bin_counts[have_data]                      # :51
     ece = 0                                                                        # :53-55
-    for i in range(len(bin_confidence)):
-        ece += np.absolute(bin_confidence[i] - bin_acc[i]) * bin_counts[i] / np.sum(bin_counts)
+    try:
+        for i in range(len(bin_confidence)):
+            ece += np.absolute(bin_confidence[i] - bin_acc[i]) * bin_counts[i] / np.sum(bin_counts)
+    except IndexError:               # an empty bin: the reference's loop walks off the compressed bin_acc array here
+        ece = float("nan")
     return ece, bin_centers[have_data], bin_acc, (bin_counts, bin_corrects, bin_confidence)
 
 

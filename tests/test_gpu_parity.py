@@ -945,3 +945,107 @@ def test_c5_wide_lr_layer_against_oracle(dev, form):
             scale = float(np.abs(ref[s][0]).max())
             err = float(np.abs(out["y"][s].double().cpu().numpy() - ref[s][0]).max())
             assert err <= (2e-5 if mm == L.MATH_F32 else 2e-2) * scale, (name, form, s, err, scale)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 1200, 1200), (3, 128, 784, 1200), (2, 20, 72, 40), (24, 128, 1200, 1200)])
+def test_sampling_job_riding_on_a_layer_launch(dev, shape):
+    """bnn_bbb_fwd_args.rider: another layer's sampling (K1s) carried by a layer launch as extra blocks -- or, when the
+    launch cannot carry it (block-GEMM form), launched ahead of it -- leaves the layer's own results bitwise unchanged
+    and produces bitwise the weights, biases and statistics of a stand-alone bnn_bbb_sample_weights call."""
+    S, B, K, N = shape
+    rs = np.random.RandomState(33)
+    mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+    x = mk(B, K, lo=0, hi=1).to(torch.bfloat16)
+    w = [mk(N, K), mk(N, K, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4)]
+    w3 = [mk(10, N), mk(10, N, lo=-5, hi=-4), mk(10), mk(10, lo=-5, hi=-4)]
+    prior = ops.PriorSpec(False, 1.0)
+    kw = dict(n_samples=S, prior=prior, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.bfloat16, eps_mode=L.EPS_PHILOX, seed=5,
+              layer_id=1, sample_offset=17, want_stats=True)
+    job = lambda: ops.build_sample_job([dict(w_mu=w3[0], w_rho=w3[1], b_mu=w3[2], b_rho=w3[3], prior=prior, layer_id=2)],
+                                       n_samples=S, seed=5, sample_offset=17)
+    plain = ops.bbb_linear_fwd(x, *w, **kw)
+    alone = ops.bbb_sample_weights([dict(w_mu=w3[0], w_rho=w3[1], b_mu=w3[2], b_rho=w3[3], prior=prior, layer_id=2)],
+                                   n_samples=S, seed=5, sample_offset=17)[0]
+    j = job()
+    ridden = ops.bbb_linear_fwd(x, *w, rider=j, **kw)
+    torch.cuda.synchronize()
+    Tm = int(plain["workspace"][:1].view(torch.int32)[0])                 # the layer's own statistics entries in use
+    assert torch.equal(ridden["y"], plain["y"])
+    assert torch.equal(ridden["workspace"][:4 * (1 + S * Tm)], plain["workspace"][:4 * (1 + S * Tm)])
+    r = j[1][0]
+    assert torch.equal(r["w"], alone["w"]) and torch.equal(r["b"], alone["b"])
+    T = int(alone["workspace"][:1].view(torch.int32)[0])
+    assert torch.equal(r["workspace"][:4 * (1 + S * T)], alone["workspace"][:4 * (1 + S * T)])
+
+
+@pytest.mark.parametrize("dims,mode,B,G,S", [((784, 1200, 10), "classification", 128, 1, 1), ((784, 1200, 10), "classification", 128, 1, 16),
+                                             ((784, 1200, 10), "classification", 100, 3, 2), ((16, 64, 1), "regression", 128, 1, 5),
+                                             ((40, 72, 16), "classification", 37, 2, 3)])
+def test_row_split_output_layer_equals_the_two_launch_form(dev, monkeypatch, dims, mode, B, G, S):
+    """K1r (output layer over weights drawn by the rider, split by batch rows, finalize by the last block to arrive)
+    against the plain sequence (sampling fused into the output layer's launch + bnn_elbo_finalize): the same Philox
+    elements, so log p / log q agree to fp32 summation order and the logits / NLL to the bf16 rounding of w (the
+    pre-sampled form rounds w to bf16 once, the fused form feeds the same rounded value to the matrix core), replay
+    after replay (tickets back at zero, device counter advanced)."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    net, _ = build_net(dev, False, dims, mode, B=B)
+    xs, ys = zip(*[synth.synth_batch(mode, B, dims[0], dims[2], seed=70 + m) for m in range(G)])
+    xd, yd = torch.from_numpy(np.stack(xs)).to(dev), torch.from_numpy(np.stack(ys)).to(dev)
+    res = []
+    for form in (L.FORM_AUTO, L.FORM_TILE):
+        monkeypatch.setattr(bnn_hip.runtime.state, "form", form)
+        bnn_hip.manual_seed(8, counter=40)
+        ev = engine.GraphedElbo(net, xd if G > 1 else xd[0], yd if G > 1 else yd[0], S, sigma=0.3, stacked=G > 1)
+        assert ev.rows == (form == L.FORM_AUTO)
+        a = ev.replay().clone()
+        b = ev.replay().clone()
+        res.append((a, b, {k: v.clone() for k, v in ev.out.items()}, ev.logits.clone(), int(ev.counter.item())))
+        if ev.rows:
+            assert int(ev.scratch.view(torch.int32)[:G * S].abs().sum()) == 0 and int(ev.ticket.item()) == 0
+    (a1, b1, o1, lg1, c1), (a2, b2, o2, lg2, c2) = res
+    assert c1 == c2 == 40 + 3 * G * S and not torch.equal(a1, b1)
+    scale = float(lg2.abs().max()) + 1e-6
+    assert float((lg1 - lg2).abs().max()) <= 2e-5 * scale
+    for k in o1:
+        close(o1[k], o2[k].cpu().numpy(), rtol=2e-5 if k == "nll" else 2e-6)
+    close(a1, a2.cpu().numpy(), rtol=2e-5)
+    close(b1, b2.cpu().numpy(), rtol=2e-5)
+
+
+def test_large_batch_layers_take_the_library_gemm(dev, monkeypatch):
+    """Batches of >= 512 rows: every BBB layer is one sampling launch (K1s) + a plain library GEMM over the sampled
+    weights (ops.bbb_library_matmul) instead of the fused kernels; same Philox elements, so the evaluation agrees
+    with the fused path to bf16 rounding (the library rounds each layer's product to bf16 before bias and ReLU), and
+    with the fp32 oracle within the bf16 tolerances."""
+    from bnn_hip import engine
+    bnn_hip.set_math("bf16")
+    B, dims, S = 512, (64, 96, 8), 3
+    net, sd = build_net(dev, False, dims, "classification", B=B)
+    x, y = synth.synth_batch("classification", B, dims[0], dims[2], seed=9)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    res = []
+    for form in (L.FORM_AUTO, L.FORM_TILE):
+        monkeypatch.setattr(bnn_hip.runtime.state, "form", form)
+        bnn_hip.manual_seed(4, counter=10)
+        ev = engine.GraphedElbo(net, xd, yd, S)
+        assert all(ev.lib) == (form == L.FORM_AUTO)
+        sums = ev.replay().clone()
+        res.append((sums, {k: v.clone() for k, v in ev.out.items()}, ev.logits.clone()))
+        if form == L.FORM_AUTO:                                  # the eager product path takes the same route
+            bnn_hip.manual_seed(4, counter=10 + S)
+            with torch.no_grad():
+                tup = net.sample_elbo(xd, yd, 0.5, S)
+            close(tup[1] * S, float(sums[0]), rtol=1e-6)
+            close(tup[2] * S, float(sums[1]), rtol=1e-6)
+            close(tup[3] * S, float(sums[2]), rtol=1e-5)
+    (s1, o1, lg1), (s2, o2, lg2) = res
+    close(o1["log_prior"], o2["log_prior"].cpu().numpy(), rtol=2e-6)
+    close(o1["log_q"], o2["log_q"].cpu().numpy(), rtol=2e-6)
+    assert float((lg1 - lg2).abs().max()) <= BF16_LOGIT_TOL * float(lg2.abs().max())
+    close(o1["nll"], o2["nll"].cpu().numpy(), rtol=BF16_NLL_RTOL)
+    p = O.NetParams.from_state_dict(sd, "classification", dims[0], False, O.Prior.from_init([1.0], False))
+    want, _ = _oracle_pairs(p, [x], [y], 4, 10 + S, S)           # the captured graph's replay followed the warm-up
+    close(o1["log_prior"], want[:, 0], rtol=1e-5)
+    close(o1["log_q"], want[:, 1], rtol=1e-5)
+    close(o1["nll"], want[:, 2], rtol=BF16_NLL_RTOL)

@@ -1,0 +1,18 @@
+"""A few lines out of a bench.py JSON line (development loop)."""
+import json, sys
+d = json.load(open(sys.argv[1]))
+r = d["roofline"]
+print("value %.0f samples/s  %.2f us/step | roof %s %.1f us frac %.3f" % (d["value"], d["ms_per_step"] * 1e3, r["kernel"], r["avg_launch_us"], r["frac"]))
+if "single_evaluation_in_flight" in d:
+    s = d["single_evaluation_in_flight"]; print("single eval %.1f us, layer2 %.1f us" % (s["us_per_evaluation"], s["layer2"]["avg_launch_us"]))
+e = d.get("extras", {})
+for m in e.get("mc_batched_one_minibatch", []):
+    print("  S=%d one minibatch: %.0f samples/s %.1f us/eval, layer2 %.1f us frac %.3f" % (m["mc_samples_per_evaluation"], m["samples_per_s"], m["us_per_evaluation"], m["layer2_us_per_launch"], m["layer2_hbm_frac"]))
+if "lr_variant" in e:
+    l = e["lr_variant"]; s1 = l["single_evaluation_in_flight"]
+    print("  LR: %.0f samples/s, layer2 %s %.1f us frac %.3f | single %.1f us, layer2 %.1f us frac %.3f" % (l["samples_per_s"], l["roofline"]["kernel"], l["roofline"]["avg_launch_us"], l["roofline"]["frac"], s1["us_per_evaluation"], s1["layer2_us_per_launch"], s1["layer2_hbm_frac"]))
+for w in e.get("wide_4096", []):
+    r = w["roofline"]
+    print("  wide B=%d S=4: %.0f samples/s %.0f us/eval, [%s] %s %.1f us frac %.3f %s" % (w["batch"], w["samples_per_s"], w["us_per_evaluation"], r["bound"], r["kernel"][:40], r["avg_launch_us"], r["frac"], ("sampling %.1f us hbm %.3f" % (r["sampling"]["avg_launch_us"], r["sampling"]["hbm_frac"])) if "sampling" in r else ""))
+for c in e.get("c4", []):
+    print("  c4 S=%d: %.0f samples/s %.1f us/eval" % (c["mc_samples_per_evaluation"], c["samples_per_s"], c["us_per_evaluation"]))
