@@ -37,6 +37,11 @@ FUSED_ELBO_NODE = True
 # layer before it (a sampling job riding on that launch, bnn_bbb_fwd_args.rider) and run the output layer + finalize in
 # the row-split matmul-only form (K1r): the tail of the dependent chain is then ~5 us instead of ~13
 FINAL_ROWS_MAX_SAMPLES = 16
+# (Letting the FIRST layer's launch carry the sampling of every later layer -- hidden layers matmul-only too -- was
+# built and measured slower at every size: one evaluation 36.8 against 35.4 us at one sample, 58.8 against 43.6 at three:
+# the rider blocks inherit the layer's 768-thread / 98 KB-LDS block shape, one per CU, and queue behind the layer's own.
+# PRESAMPLE_HIDDEN_MAX_SAMPLES = 0 keeps that form off; tools/few_sample_sweep.py re-measures it.)
+PRESAMPLE_HIDDEN_MAX_SAMPLES = 0
 
 
 def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
@@ -57,6 +62,17 @@ LIB_GEMM_MIN_BATCH = 512
 def use_library_gemm(sp, batch: int, hidden_dtype) -> bool:
     return (not sp.lr) and hidden_dtype == torch.bfloat16 and batch >= LIB_GEMM_MIN_BATCH and sp.in_out[0] % 8 == 0 and \
         state.form == L.FORM_AUTO
+
+
+def presample_from(specs, n_samples: int, batch: int, hidden_dtype) -> int:
+    """Index of the layer whose launch carries the sampling job of all layers after it (they run matmul-only), or -1:
+    the layer before the output layer, or the first layer for very few (minibatch, sample) pairs."""
+    if not final_rows_ok(specs, n_samples, batch, hidden_dtype):
+        return -1
+    last = len(specs) - 1
+    if n_samples <= PRESAMPLE_HIDDEN_MAX_SAMPLES and all(sp.in_out[0] % 8 == 0 for sp in specs[1:]):
+        return 0
+    return last - 1
 
 
 def use_split(fin: int, fout: int, n_samples: int) -> bool:
@@ -129,9 +145,9 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
             h = ops.cast_bf16(x)
     stats = []
     # forward-only ELBO with on-chip eps: the output layer may take the pre-sampled row-split form (final_rows_ok)
-    rows_final = (not differentiable and fin_kw is not None and want_stats and sample and injected is None and
-                  final_rows_ok(layers, n_local, x.shape[-2], hidden_dtype))
-    presampled = None
+    pre_from = presample_from(layers, n_local, x.shape[-2], hidden_dtype) \
+        if (not differentiable and fin_kw is not None and want_stats and sample and injected is None) else -1
+    presampled = {}                                   # layer index -> dict(w, b, workspace) drawn by an earlier launch
     for i, sp in enumerate(layers):
         last = i == len(layers) - 1
         if not sample:
@@ -186,23 +202,28 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                     kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
-                    if presampled is not None:
+                    if i in presampled:
+                        ps = presampled[i]
                         out, fin = ops.bbb_final_fwd((h, None, None, None, None),
                                                      dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu,
                                                           y_dtype=call.y_dtype, eps_mode=L.EPS_ZERO, want_stats=False,
-                                                          w_sampled=presampled["w"], b_sampled=presampled["b"]),
-                                                     dict(workspaces=stats + [presampled["workspace"]], **fin_kw))
+                                                          w_sampled=ps["w"], b_sampled=ps["b"]),
+                                                     dict(workspaces=stats + [ps["workspace"]], **fin_kw))
                     else:
                         out, fin = ops.bbb_final_fwd((h,) + pd, kw, dict(workspaces=stats, **fin_kw))
                     return out["y"], fin
-                if i == len(layers) - 2 and rows_final:
-                    # the output layer's weights are drawn beside this layer (a sampling job riding on its launch)
-                    spl = layers[-1]
+                if i in presampled:                   # a hidden layer whose weights an earlier launch has drawn
+                    ps = presampled[i]
+                    h = ops.bbb_sampled_matmul(h, ps["w"], ps["b"], n_samples=n_local, relu=sp.relu, y_dtype=call.y_dtype)
+                    stats.append(ps["workspace"])
+                    continue
+                if i == pre_from:
+                    # the later layers' weights are drawn beside this layer (a sampling job riding on its launch)
                     kw["rider"] = ops.build_sample_job(
-                        [dict(w_mu=spl.m.weight_mu.detach(), w_rho=spl.m.weight_rho.detach(), b_mu=spl.m.bias_mu.detach(),
-                              b_rho=spl.m.bias_rho.detach(), prior=spl.m._prior_spec, layer_id=spl.layer_id)],
-                        n_samples=n_local, seed=state.seed, sample_offset=first_sample)
-                    presampled = kw["rider"][1][0]
+                        [dict(w_mu=q.m.weight_mu.detach(), w_rho=q.m.weight_rho.detach(), b_mu=q.m.bias_mu.detach(),
+                              b_rho=q.m.bias_rho.detach(), prior=q.m._prior_spec, layer_id=q.layer_id)
+                         for q in layers[i + 1:]], n_samples=n_local, seed=state.seed, sample_offset=first_sample)
+                    presampled = {i + 1 + j: r for j, r in enumerate(kw["rider"][1])}
                 out = ops.bbb_linear_fwd(h, *pd, **kw)
             h = out["y"]
             stats.append(out["workspace"])
@@ -434,12 +455,15 @@ class GraphedElbo:
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
                           if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
-        self.rows = final_rows_ok(self.specs, S, B, hid)
+        self.pre_from = presample_from(self.specs, S, B, hid)      # the layer whose launch samples all layers after it
+        self.rows = self.pre_from >= 0
+        self.w_pre, self.b_pre = [None] * len(self.specs), [None] * len(self.specs)
         if self.rows:
-            k_last, n_last = self.specs[-1].in_out
-            self.w_last = torch.empty((S, n_last, k_last), dtype=torch.bfloat16, device=dev)
-            self.b_last = torch.empty((S, n_last), dtype=torch.float32, device=dev)
-            self.ws[-1] = ops.sample_workspace(S, k_last, n_last, dev)
+            for i in range(self.pre_from + 1, len(self.specs)):
+                k_i, n_i = self.specs[i].in_out
+                self.w_pre[i] = torch.empty((S, n_i, k_i), dtype=torch.bfloat16, device=dev)
+                self.b_pre[i] = torch.empty((S, n_i), dtype=torch.float32, device=dev)
+                self.ws[i] = ops.sample_workspace(S, k_i, n_i, dev)
         self.graph = None
         if capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
@@ -498,17 +522,20 @@ class GraphedElbo:
                     ops.bbb_final_fwd((h, None, None, None, None),
                                       dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
                                            y_dtype=self.bufs[i].dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=self.bufs[i],
-                                           w_sampled=self.w_last, b_sampled=self.b_last),
+                                           w_sampled=self.w_pre[i], b_sampled=self.b_pre[i]),
                                       dict(workspaces=self.ws, **fin_kw))
                 elif i == last:
                     ops.bbb_final_fwd((h,) + p, kw, dict(workspaces=self.ws[:last], **fin_kw))
+                elif self.w_pre[i] is not None:              # a hidden layer whose weights an earlier launch has drawn
+                    ops.bbb_sampled_matmul(h, self.w_pre[i], self.b_pre[i], n_samples=self.n_local, relu=sp.relu,
+                                           y_dtype=self.bufs[i].dtype, out=self.bufs[i])
                 else:
-                    if i == last - 1 and self.rows:          # the output layer's weights are drawn beside this layer
-                        spl = self.specs[last]
+                    if i == self.pre_from:                   # the later layers' weights are drawn beside this layer
                         kw["rider"] = ops.build_sample_job(
-                            [dict(w_mu=spl.m.weight_mu.detach(), w_rho=spl.m.weight_rho.detach(), b_mu=spl.m.bias_mu.detach(),
-                                  b_rho=spl.m.bias_rho.detach(), prior=spl.m._prior_spec, layer_id=spl.layer_id,
-                                  workspace=self.ws[last], w_out=self.w_last, b_out=self.b_last)],
+                            [dict(w_mu=q.m.weight_mu.detach(), w_rho=q.m.weight_rho.detach(), b_mu=q.m.bias_mu.detach(),
+                                  b_rho=q.m.bias_rho.detach(), prior=q.m._prior_spec, layer_id=q.layer_id,
+                                  workspace=self.ws[j], w_out=self.w_pre[j], b_out=self.b_pre[j])
+                             for j, q in enumerate(self.specs) if j > i],
                             n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
                     ops.bbb_linear_fwd(h, *p, **kw)
             h = self.bufs[i]

@@ -83,6 +83,11 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
   const bool do_ls = s == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
   const bool active = (int)threadIdx.x < kSampleThreads;
+  if (!active) {                                          // whole waves (kSampleThreads is a multiple of 64): a wider block's
+    if (lane == 0) red[wave * 3 + 0] = red[wave * 3 + 1] = red[wave * 3 + 2] = 0.f;   // extra waves only meet the barrier
+    __syncthreads();
+    return;
+  }
 
   // ---- all parameter loads of the thread's two octets first (clamped addresses: no load under a branch)
   long o[2];

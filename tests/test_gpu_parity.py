@@ -1006,11 +1006,17 @@ def test_row_split_output_layer_equals_the_two_launch_form(dev, monkeypatch, dim
     (a1, b1, o1, lg1, c1), (a2, b2, o2, lg2, c2) = res
     assert c1 == c2 == 40 + 3 * G * S and not torch.equal(a1, b1)
     scale = float(lg2.abs().max()) + 1e-6
-    assert float((lg1 - lg2).abs().max()) <= 2e-5 * scale
+    # the output layer alone pre-sampled: same bf16 operands, fp32 summation order only.  Hidden layers pre-sampled too
+    # (n <= engine.PRESAMPLE_HIDDEN_MAX_SAMPLES): their matmul-only launches sum in another order, and a hidden
+    # activation that lands on the other side of a bf16 rounding boundary moves by 2^-8 of its value
+    hidden_pre = G * S <= engine.PRESAMPLE_HIDDEN_MAX_SAMPLES and len(dims) == 3
+    lg_tol, nll_tol = (2e-3, 1e-3) if hidden_pre else (2e-5, 2e-5)
+    err = float((lg1 - lg2).abs().max())
+    assert err <= lg_tol * scale, (err, scale)
     for k in o1:
-        close(o1[k], o2[k].cpu().numpy(), rtol=2e-5 if k == "nll" else 2e-6)
-    close(a1, a2.cpu().numpy(), rtol=2e-5)
-    close(b1, b2.cpu().numpy(), rtol=2e-5)
+        close(o1[k], o2[k].cpu().numpy(), rtol=nll_tol if k == "nll" else 2e-6)
+    close(a1, a2.cpu().numpy(), rtol=nll_tol)
+    close(b1, b2.cpu().numpy(), rtol=nll_tol)
 
 
 def test_large_batch_layers_take_the_library_gemm(dev, monkeypatch):
