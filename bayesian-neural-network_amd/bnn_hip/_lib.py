@@ -19,12 +19,13 @@ FORM_AUTO, FORM_TILE, FORM_GEMM, FORM_GEMM_KSLICE = 0, 1, 2, 3
 
 EXPORTS = (
     "bnn_version", "bnn_status_string",
-    "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_linear_fwd", "bnn_bbb_linear_bwd_workspace_bytes",
+    "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_split_scratch_bytes", "bnn_bbb_split_scratch_zero_bytes", "bnn_bbb_linear_fwd",
+    "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
 )
 
@@ -169,6 +170,15 @@ class Plan(C.Structure):
                 ("k_slices", C.c_int32), ("blocks", C.c_int32), ("lds_bytes", C.c_int32), ("features_per_block", C.c_int32)]
 
 
+PREPARE_MAX = 8
+
+
+class PrepareArgs(C.Structure):
+    _fields_ = [("struct_bytes", C.c_uint32), ("n_softplus", C.c_int32),
+                ("rho", C.c_void_p * PREPARE_MAX), ("sigma", C.c_void_p * PREPARE_MAX), ("n", C.c_int64 * PREPARE_MAX),
+                ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_dst_sq", C.c_void_p), ("cast_n", C.c_int64)]
+
+
 class BnnHipError(RuntimeError):
     pass
 
@@ -195,6 +205,9 @@ def load():
     lib.bnn_status_string.argtypes = [C.c_int]
     lib.bnn_bbb_linear_fwd_workspace_bytes.restype = C.c_size_t
     lib.bnn_bbb_linear_fwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    for fn in (lib.bnn_bbb_split_scratch_bytes, lib.bnn_bbb_split_scratch_zero_bytes):
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.bnn_bbb_linear_fwd.restype = C.c_int
     lib.bnn_bbb_linear_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.c_void_p]
     lib.bnn_bbb_plan.restype = C.c_int
@@ -255,6 +268,8 @@ def load():
                                       C.c_int32, C.c_void_p]
     lib.bnn_softplus.restype = C.c_int
     lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.bnn_eval_prepare.restype = C.c_int
+    lib.bnn_eval_prepare.argtypes = [C.POINTER(PrepareArgs), C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int
     lib.bnn_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.bnn_ece_workspace_bytes.restype = C.c_size_t

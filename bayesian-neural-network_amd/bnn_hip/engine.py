@@ -17,16 +17,18 @@ from .functional import AllReduceSumFn, BBBLinearFn, ElboFn, LayerCall, LRLinear
 from .runtime import state, take_samples
 
 
-CAST_INPUT_MIN_SAMPLES = 8    # BBB: below this the extra launch costs more than it saves
+CAST_INPUT_MIN_SAMPLES = 4    # BBB: from here on the first layer can take a block-GEMM form (bf16 x through LDS-DMA);
+                              # below, the extra launch costs more than it saves
 # LR: from one sample on.  Its first layer squares every x fragment it loads, and fp32 x doubles the bytes each block
 # pulls through its CU's L1 (21.5 us for that layer against 14.7 us for the wider second one): casting first wins
 # even with the extra launch in the chain (one-sample evaluation 59.4 -> 55.3 us)
 CAST_INPUT_MIN_SAMPLES_LR = 1
 LR_SQUARES_MIN_SAMPLES = 8    # LR: carry x^2 (bf16) between layers from here on (the block-GEMM form streams it)
-# BBB: the K-sliced GEMM form needs a scratch for its fp32 partial tiles; the library's plan (bnn_bbb_plan) takes
-# that form for layers of >= 4 M weights in this range of samples per launch (4096x4096, 4 samples: 126 vs 175 us)
-SPLIT_MIN_SAMPLES, SPLIT_MAX_SAMPLES = 4, 24
-SPLIT_MIN_WEIGHTS = 4_000_000
+# BBB: the K-sliced GEMM form needs a scratch for its fp32 partial tiles; the library's plan (bnn_bbb_plan) decides
+# whether and how finely to slice (bbb_linear.hip: kslices) -- here only the cases it can never take are left without
+SPLIT_MIN_SAMPLES = 4
+SPLIT_MIN_WEIGHTS = 250_000
+SPLIT_MAX_UNITS = 1024        # (64-feature group x sample x batch block) units: 256 KiB of scratch each
 
 # differentiable sample_elbo*: the whole network as one autograd node (functional.ElboFn) when eps is drawn on
 # chip; the identical-eps parity path keeps one node per layer
@@ -75,9 +77,27 @@ def presample_from(specs, n_samples: int, batch: int, hidden_dtype) -> int:
     return last - 1
 
 
-def use_split(fin: int, fout: int, n_samples: int) -> bool:
-    return fout > 16 and fin * fout >= SPLIT_MIN_WEIGHTS and SPLIT_MIN_SAMPLES <= n_samples < SPLIT_MAX_SAMPLES
-SIGMA_HOIST_MIN_SAMPLES = 24  # BBB: precompute sigma = softplus(rho) once per evaluation from here on
+def use_split(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
+    units = ((fout + 63) // 64) * n_samples * ((batch + 127) // 128)
+    return fout > 16 and fin % 8 == 0 and fin * fout >= SPLIT_MIN_WEIGHTS and n_samples >= SPLIT_MIN_SAMPLES and \
+        units <= SPLIT_MAX_UNITS
+
+
+def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
+    """sigma = softplus(rho) once per evaluation (part of the one prepare launch, ops.eval_prepare) instead of per
+    sampled weight: pays when the layer runs in a block-GEMM form (K-sliced from SPLIT_MIN_SAMPLES, plain from 450
+    units) and enough samples share it -- a quarter of the generator work of every sample against one 8 B/weight pass."""
+    units = ((fout + 63) // 64) * n_samples * ((batch + 127) // 128)
+    enough = n_samples >= (SIGMA_HOIST_MIN_SAMPLES if fin * fout < SIGMA_HOIST_BIG_LAYER else SIGMA_HOIST_MIN_SAMPLES_BIG)
+    return fout > 16 and fin % 8 == 0 and fin * fout >= SPLIT_MIN_WEIGHTS and enough and \
+        (units >= 450 or n_samples >= SPLIT_MIN_SAMPLES)
+
+
+# measured: the pass costs ~1.6 us per million weights; what it saves per sample shrinks as more waves per SIMD cover the
+# softplus (1200 x 1200, 8 samples: 31.5 -> 27.6 us; 4096 x 4096, 4 samples: 113.7 -> 107.5 us against a 25 us pass)
+SIGMA_HOIST_BIG_LAYER = 4_000_000
+SIGMA_HOIST_MIN_SAMPLES_BIG = 24
+SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per evaluation from here on
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
 
@@ -136,13 +156,20 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     h, h_sq = x, None
     any_lr = any(sp.lr for sp in layers)
     lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= LR_SQUARES_MIN_SAMPLES and any_lr
-    if hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES:   # (eager calls
-        # are host-bound: the one-sample LR cast of GraphedElbo would only add a launch here)
-        # once per evaluation: every layer then streams 2-byte x (LR: and its elementwise square)
-        if lr_sq:
-            h, h_sq = ops.cast_bf16(x, want_sq=True)
-        else:
-            h = ops.cast_bf16(x)
+    # everything that depends on no activation, in one launch: the input batch in bf16 (every layer then streams 2-byte x;
+    # LR: and its elementwise square) and sigma = softplus(rho) of the layers that will run a block-GEMM form
+    want_cast = hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES  # (eager
+    # calls are host-bound: the one-sample LR cast of GraphedElbo would only add a launch here)
+    hoisted = {}
+    if hidden_dtype == torch.bfloat16 and sample and not differentiable and (x.dtype == torch.bfloat16 or want_cast):
+        hoisted = {i: None for i, sp in enumerate(layers)
+                   if not sp.lr and hoist_sigma(*sp.in_out, n_local, x.shape[-2]) and not use_library_gemm(sp, x.shape[-2], hidden_dtype)}
+    if want_cast or hoisted:
+        sig, c16, c16sq = ops.eval_prepare([layers[i].m.weight_rho.detach() for i in hoisted],
+                                           cast=x if want_cast else None, want_sq=lr_sq and want_cast)
+        hoisted = dict(zip(hoisted, sig))
+        if want_cast:
+            h, h_sq = c16, c16sq
     stats = []
     # forward-only ELBO with on-chip eps: the output layer may take the pre-sampled row-split form (final_rows_ok)
     pre_from = presample_from(layers, n_local, x.shape[-2], hidden_dtype) \
@@ -195,10 +222,9 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                     h = ops.bbb_library_matmul(h, sm["w"], sm["b"], n_samples=n_local, relu=sp.relu, y_dtype=call.y_dtype)
                     stats.append(sm["workspace"])
                     continue
-                if h.dtype == torch.bfloat16 and n_local >= SIGMA_HOIST_MIN_SAMPLES and eps_mode != L.EPS_ZERO and \
-                        ((sp.in_out[1] + 63) // 64) * n_local >= 450:
-                    kw["w_sigma"] = ops.softplus(pd[1])        # consumed by the throughput (GEMM) form only
-                if h.dtype == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], n_local):
+                if i in hoisted and h.dtype == torch.bfloat16:
+                    kw["w_sigma"] = hoisted[i]                 # consumed by the block-GEMM forms only
+                if h.dtype == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], n_local, h.shape[-2]):
                     kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
@@ -446,11 +472,12 @@ class GraphedElbo:
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]
         self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
-                      if (not self.lr and hid == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], S)) else None
+                      if (not self.lr and hid == torch.bfloat16 and not self.lib[i] and
+                          use_split(sp.in_out[0], sp.in_out[1], S, B)) else None
                       for i, sp in enumerate(self.specs)]
         self.wsigma = [torch.empty_like(sp.m.weight_rho.detach())
-                      if (not self.lr and hid == torch.bfloat16 and S >= SIGMA_HOIST_MIN_SAMPLES and
-                          ((sp.in_out[1] + 63) // 64) * S >= 450) else None for sp in self.specs]
+                      if (not self.lr and hid == torch.bfloat16 and not lb and hoist_sigma(*sp.in_out, S, B)) else None
+                      for sp, lb in zip(self.specs, self.lib)]
         self.wfrag = [None] * len(self.specs)
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
@@ -482,12 +509,15 @@ class GraphedElbo:
         """One evaluation of all local (minibatch, MC sample) pairs."""
         math_mode = state.math
         h_sq = None
-        if self.x16 is None:
-            h = self.x
-        elif self.lr_sq:
-            h, h_sq = ops.cast_bf16(self.x, out=self.x16, out_sq=self.x16_sq)
-        else:
-            h = ops.cast_bf16(self.x, out=self.x16)
+        # one launch for everything that depends on no activation: the bf16 input batch (+ squares), the hoisted sigmas
+        hoist = [i for i, w in enumerate(self.wsigma) if w is not None]
+        h = self.x
+        if self.x16 is not None or hoist:
+            ops.eval_prepare([self.specs[i].m.weight_rho.detach() for i in hoist], [self.wsigma[i] for i in hoist],
+                             cast=self.x if self.x16 is not None else None, cast_out=self.x16,
+                             cast_out_sq=self.x16_sq if self.lr_sq else None)
+            if self.x16 is not None:
+                h, h_sq = self.x16, (self.x16_sq if self.lr_sq else None)
         last = len(self.specs) - 1
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
@@ -515,8 +545,6 @@ class GraphedElbo:
                 if i == last:
                     ops.elbo_finalize(workspaces=self.ws, logits=self.bufs[i], **fin_kw)
             else:
-                if self.wsigma[i] is not None:
-                    ops.softplus(p[1], out=self.wsigma[i])
                 kw = dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], w_sigma=self.wsigma[i], **common)
                 if i == last and self.rows:
                     ops.bbb_final_fwd((h, None, None, None, None),

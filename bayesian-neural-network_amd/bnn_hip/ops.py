@@ -87,12 +87,14 @@ def bbb_workspace(n_samples: int, out_features: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
-SPLIT_MAX_SLICES = 8
-
-
 def split_scratch(n_samples: int, batch: int, out_features: int, device) -> torch.Tensor:
-    """Scratch for the K-sliced GEMM form of K1 (fp32 partial tiles, up to 8 slices)."""
-    return torch.empty(SPLIT_MAX_SLICES * n_samples * batch * out_features, dtype=torch.float32, device=device)
+    """Scratch for the K-sliced GEMM form of K1: arrival counters (zeroed here, once; launches leave them zero) followed
+    by the fp32 partial tiles (uninitialised).  One scratch serves one launch at a time."""
+    lib = L.load()
+    nbytes = lib.bnn_bbb_split_scratch_bytes(n_samples, batch, out_features)
+    t = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+    t[:lib.bnn_bbb_split_scratch_zero_bytes(n_samples, batch, out_features) // 4].zero_()
+    return t
 
 
 def final_scratch(n_samples: int, device) -> torch.Tensor:
@@ -799,6 +801,38 @@ def softplus(rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
         out = torch.empty_like(rho)
     L.check(lib.bnn_softplus(rho.data_ptr(), out.data_ptr(), rho.numel(), _stream()), "bnn_softplus")
     return out
+
+
+def eval_prepare(rhos=(), sigmas=None, cast: Optional[torch.Tensor] = None, cast_out: Optional[torch.Tensor] = None,
+                 cast_out_sq: Optional[torch.Tensor] = None, want_sq: bool = False):
+    """bnn_eval_prepare: sigma = softplus(rho) for every tensor of `rhos` and (optionally) the bf16 cast of `cast`
+    (+ its squares) in ONE launch -- everything of an evaluation that depends on no activation.
+    Returns (list of sigma tensors, cast_out, cast_out_sq)."""
+    lib = L.load()
+    rhos = [_f32c(r, "rho") for r in rhos]
+    require_device(*rhos, cast)
+    if len(rhos) > L.PREPARE_MAX:
+        raise BnnHipError(f"eval_prepare: at most {L.PREPARE_MAX} tensors per launch")
+    if sigmas is None:
+        sigmas = [torch.empty_like(r) for r in rhos]
+    a = L.PrepareArgs()
+    a.struct_bytes = C.sizeof(L.PrepareArgs)
+    a.n_softplus = len(rhos)
+    for i, (r, sg) in enumerate(zip(rhos, sigmas)):
+        if sg.shape != r.shape or sg.dtype != torch.float32 or not sg.is_contiguous():
+            raise BnnHipError("eval_prepare: sigma must be a contiguous fp32 tensor of rho's shape")
+        a.rho[i], a.sigma[i], a.n[i] = r.data_ptr(), sg.data_ptr(), r.numel()
+    if cast is not None:
+        cast = _f32c(cast, "x")
+        if cast_out is None:
+            cast_out = torch.empty(cast.shape, dtype=torch.bfloat16, device=cast.device)
+        if want_sq and cast_out_sq is None:
+            cast_out_sq = torch.empty(cast.shape, dtype=torch.bfloat16, device=cast.device)
+        a.cast_src, a.cast_dst, a.cast_dst_sq, a.cast_n = cast.data_ptr(), cast_out.data_ptr(), _ptr(cast_out_sq), cast.numel()
+    if not rhos and cast is None:
+        return [], None, None
+    L.check(lib.bnn_eval_prepare(C.byref(a), _stream()), "bnn_eval_prepare")
+    return list(sigmas), cast_out, cast_out_sq
 
 
 def ece_bins(probs: torch.Tensor, labels: torch.Tensor, bin_edges) -> torch.Tensor:

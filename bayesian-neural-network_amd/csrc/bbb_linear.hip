@@ -54,8 +54,9 @@ struct BbbK {
   float4* ws;       // stats workspace (see above) or nullptr
   int S, B, K, N;
   int eps_mode, prior_kind, want_stats, relu, y_bf16, spb;
-  int ksl;          // GEMM form: K-range slices per (tile group, sample); 1 = none
-  float* ks_part;   // GEMM form, ksl > 1: fp32 partial outputs [ksl][S][B][N] (bias in slice 0)
+  int ksl;          // GEMM form: K-range slices per (tile group, sample, batch block) unit; 1 = none
+  float4* ks_part;  // GEMM form, ksl > 1: fp32 partial tiles [unit][ksl][wave][batch tile][lane] (bias in slice 0)
+  uint32_t* ks_ticket;  // GEMM form, ksl > 1: [unit] arrival counters of a unit's slice blocks, zero between launches
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
   const float* b_pre;   // PRE only: sampled biases [S, N]
@@ -884,9 +885,7 @@ __global__ __launch_bounds__(768) void bbb_input_grad_kernel(const BbbK p) {
 //   issued at the top of step t and drained (vmcnt(0)) just before the step's single barrier:
 //   a whole k-step of Philox/softplus work covers its latency.  ~115 VGPRs -> 4 waves/SIMD.
 template <int NW, bool SIG>
-__global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) {
-  __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];      // 2 x 8 KiB
-  __shared__ float bias_s[NW][16];
+__device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64], float (*bias_s)[16]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
@@ -1031,26 +1030,64 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   __syncthreads();
   const int nb = tile * 16 + q * 4;
   const bool vec_ok = (N & 3) == 0;
-  if (nb < N) {
-    float bq[4];
+  float bq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+  for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+  if (KS > 1) {
+    // ---- the K-range slices of one (tile group, sample, batch block) unit meet here, nobody waits: every wave
+    // stores its eight fp32 partial tiles write-through (sc1; 1 KiB lane-linear per tile, whole 128-B lines per
+    // store instruction) and drains them, one lane takes the unit's ticket behind the block barrier, and the block
+    // whose ticket is last adds the slices up IN SLICE ORDER (its own from registers, the others by sc1 loads:
+    // served by L2 / memory, never by this CU's L1), so the result does not depend on who arrived last.
+    __shared__ uint32_t last_s;
+    float4* const unit_part = p.ks_part + (size_t)item * KS * (NW * 8 * 64);
+    float4* const mine = unit_part + ((size_t)ks * NW + wave) * (8 * 64) + lane;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      f32x4 v = acc[m];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += bq[i];           // bias_s is zero outside slice 0
+      acc[m] = v;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + m * 64), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tk = __hip_atomic_fetch_add(p.ks_ticket + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_s = (tk == (uint32_t)KS - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_s == 0u) return;                                // block-uniform
+    if (threadIdx.x == 0) __hip_atomic_store(p.ks_ticket + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 sum[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) sum[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+    for (int j = 0; j < KS; ++j) {                           // slice order; one round of 8 loads per lane per slice
+      f32x4 part[8];
+      if (j != ks) {                                         // block-uniform
+        const float4* src = unit_part + ((size_t)j * NW + wave) * (8 * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[m]) : "v"(src + m * 64) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) part[m] = acc[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) sum[m] += part[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = sum[m];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = 0.f;                 // already in the partials
+  }
+  if (nb < N) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int brow = m0 + m * 16 + r;
-      if (brow < B && KS > 1) {                          // raw fp32 partial of this K slice
-        f32x4 v = acc[m];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += bq[i];
-        float* pp = p.ks_part + (((size_t)ks * p.S + s) * B + brow) * N + nb;
-        if (vec_ok) {
-          *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (nb + i < N) pp[i] = v[i];
-        }
-      } else if (brow < B) {
+      if (brow < B) {
         f32x4 v = acc[m];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1086,37 +1123,24 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   }
 }
 
-// Sum of the K-slice partials of the GEMM form (slice order), ReLU, down-conversion.
-__global__ void ks_reduce_kernel(const float* __restrict__ part, int KS, long cnt, int relu, void* __restrict__ y,
-                                 int y_bf16, int vec_ok) {
-  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long)gridDim.x * blockDim.x;
-  if (vec_ok) {
-    for (long i = tid; i < (cnt >> 2); i += nt) {
-      float4 v = reinterpret_cast<const float4*>(part)[i];
-      for (int j = 1; j < KS; ++j) {
-        const float4 u = reinterpret_cast<const float4*>(part + (size_t)j * cnt)[i];
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-      }
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      if (y_bf16) {
-        bf16x4 o;
-        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        reinterpret_cast<bf16x4*>(y)[i] = o;
-      } else {
-        reinterpret_cast<float4*>(y)[i] = v;
-      }
-    }
-  } else {
-    for (long i = tid; i < cnt; i += nt) {
-      float v = part[i];
-      for (int j = 1; j < KS; ++j) v += part[(size_t)j * cnt + i];
-      if (relu) v = fmaxf(v, 0.f);
-      if (y_bf16) reinterpret_cast<__bf16*>(y)[i] = (__bf16)v;
-      else reinterpret_cast<float*>(y)[i] = v;
-    }
+template <int NW, bool SIG>
+__global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) {
+  __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];      // 2 x 8 KiB
+  __shared__ float bias_s[NW][16];
+  bbb_gemm_body<NW, SIG>(p, xt, bias_s);
+}
+
+// The block GEMM carrying an independent sampling job (bnn_bbb_fwd_args.rider) as extra 256-thread blocks behind its
+// own (whose count is a multiple of 8, so the XCD-aware work order of the layer's blocks is unchanged).
+template <bool SIG>
+__global__ __launch_bounds__(256, 4) void bbb_fwd_gemm_rider_kernel(const BbbK p, const SampleK sk, int n_main) {
+  __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];
+  __shared__ float bias_s[4][16];
+  if ((int)blockIdx.x >= n_main) {                         // block-uniform
+    sample_block(sk, (int)blockIdx.x - n_main, &bias_s[0][0]);
+    return;
   }
+  bbb_gemm_body<4, SIG>(p, xt, bias_s);
 }
 
 // Per-layer reduction of the stats partials into the scalars BayesianLinear stores
@@ -1155,9 +1179,27 @@ __global__ void bbb_layer_scalars_kernel(const float4* __restrict__ ws, int K, i
 
 using namespace bnn;
 
+// One float4 entry per (sample, statistics writer): the narrowest tile form has ceil(N/4) writers per sample, the
+// K-sliced GEMM form kMaxSlices per 16-feature tile.
+static constexpr int kMaxSlices = 8;
 extern "C" size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features) {
   if (n_samples <= 0 || out_features <= 0) return 0;
-  return (1 + (size_t)n_samples * (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
+  return (1 + (size_t)n_samples * (size_t)(((out_features + 15) / 16) * kMaxSlices)) * 4 * sizeof(float);
+}
+
+// Scratch of the K-sliced GEMM form: [arrival counters: one uint32 per (64-feature group, sample, 128-row batch block)
+// unit, padded to 256 bytes | fp32 partial tiles: unit x kMaxSlices x 32 KiB].  The counter region must be zero
+// before the FIRST launch that uses the scratch (every launch leaves it zero again); the partial region needs no
+// initialisation.  One scratch serves one launch at a time (launches on one stream, or one scratch per stream).
+static size_t split_ticket_bytes(long units) { return (((size_t)units * 4 + 255) / 256) * 256; }
+extern "C" size_t bnn_bbb_split_scratch_bytes(int32_t n_samples, int32_t batch, int32_t out_features) {
+  if (n_samples <= 0 || batch <= 0 || out_features <= 0) return 0;
+  const long units = (long)((out_features + 63) / 64) * n_samples * ((batch + 127) / 128);
+  return split_ticket_bytes(units) + (size_t)units * kMaxSlices * (4 * 8 * 64 * 16);
+}
+extern "C" size_t bnn_bbb_split_scratch_zero_bytes(int32_t n_samples, int32_t batch, int32_t out_features) {
+  if (n_samples <= 0 || batch <= 0 || out_features <= 0) return 0;
+  return split_ticket_bytes((long)((out_features + 63) / 64) * n_samples * ((batch + 127) / 128));
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1174,10 +1216,9 @@ struct BbbPlan {
 };
 
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
-constexpr int kSliceMinBlocks = 300;         // ... or K-sliced from this many (group x sample x batch block x slice) items
-constexpr long kSliceMinWeights = 4000000;   // K-sliced GEMM only for layers this big: it ties the tile form on the
-                                             // 1200-wide layers (29 + 5 us against 32 us at 8 samples) and wins on
-                                             // 4096 x 4096 (126 against 175 us at 4 samples)
+constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
+constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
+constexpr int kSliceMinSamples = 4;          // ... from this many samples per launch (below: the tile form's narrow tiles)
 
 // TILE form.  Narrower tiles (more k-range classes per MFMA tile) until the launch covers the chip; the block's waves
 // divide the super-steps evenly.
@@ -1210,16 +1251,44 @@ void tile_plan(int S, int B, int K, int N, bool aligned, int mt, BbbPlan& pl) {
   pl.lds = ((size_t)pl.nw * mt * 64 * 4 + 16 + 3 * pl.nw) * sizeof(float);
 }
 
-// K-range slices of the GEMM form for `gemm_blocks` (group x sample x batch block) items: enough slices for ~600
-// blocks, at least 4 k-steps each, no more than the statistics workspace has entries for (ceil(N/4) per sample).
-int kslices(long gemm_blocks, int K, int N) {
+// K-range slices of the GEMM form for `gemm_blocks` (group x sample x batch block) units.  The generator work of a
+// launch is ksteps wave-steps per (16-feature tile, sample) whatever the decomposition (~0.6 us of vector issue each);
+// what the slicing chooses is how evenly that falls on the 256 CUs and how many waves a SIMD has to interleave.  Blocks
+// are 4 waves, one per SIMD, up to four blocks resident per CU, so a CU's time is (blocks it holds) x (k-steps per
+// slice) x a stretch for what 1 / 2 / 3 / 4 waves per SIMD leave uncovered -- measured (tools/few_sample_sweep.py,
+// 1200 x 1200): a lone wave runs a step in ~3500 cycles, 2.4 x its issue cost; two, three, four interleaved waves
+// take 1.4 / 1.27 / 1.2 x -- plus ~5 us of launch boundary, prologue and hand-off, plus the slices' fp32 partial tiles
+// (64 KiB written and read per slice and unit), which all leave at the end of the launch when every block is resident
+// (~12 MB/us) and hide behind later blocks otherwise.  E.g. 1200 x 1200, 8 samples: 152 units; whole-K blocks would
+// put 38 steps on 152 of the CUs, 4 slices 3 x 10 = 30 on all, 5 slices 3 x 8 = 24 (the ideal is 22.3).
+double slice_cost_us(long gemm_blocks, int ksteps, int ksl) {
+  const long blocks = gemm_blocks * ksl;
+  const long per_cu = (blocks + 255) / 256;
+  static const double stretch[5] = {0.0, 2.4, 1.4, 1.27, 1.2};
+  // (+1.5 steps per block: its prologue and epilogue bubbles)
+  double us = 0.5 * (double)per_cu * ((ksteps + ksl - 1) / ksl + 1.5) * stretch[per_cu > 4 ? 4 : per_cu] + 3.2;
+  if (ksl > 1) {
+    const double mb = (double)blocks * 65536.0 / 1.0e6;
+    us += 1.8 + mb / 12.0 * (blocks > 1024 ? 1024.0 / (double)blocks : 1.0);
+  }
+  return us;
+}
+
+int kslices(long gemm_blocks, int K, int min_ksl = 1, int forced = 0) {
   const int ksteps = (K + 31) / 32;
-  int ksl = (int)((600 + gemm_blocks - 1) / gemm_blocks);
-  if (ksl > 8) ksl = 8;
-  if (ksl > ksteps / 4) ksl = ksteps / 4;
-  const int max_ks = ((N + 3) / 4) / ((N + 15) / 16);
-  if (ksl > max_ks) ksl = max_ks;
-  return ksl < 1 ? 1 : ksl;
+  if (forced > 0) return forced > kMaxSlices ? kMaxSlices : (forced > ksteps ? ksteps : forced);
+  if (min_ksl * 2 > ksteps) return 1;
+  int best = min_ksl;
+  double best_cost = 0;
+  for (int ksl = min_ksl; ksl <= kMaxSlices && (ksl == 1 || ksl * 2 <= ksteps); ++ksl) {
+    if (ksl > min_ksl && gemm_blocks * ksl > kSliceMaxBlocks) break;
+    const double cost = slice_cost_us(gemm_blocks, ksteps, ksl);
+    if (ksl == min_ksl || cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = ksl;
+    }
+  }
+  return best;
 }
 
 template <typename KernelT>
@@ -1248,15 +1317,20 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
   }
   const long gemm_blocks = (long)((N + 63) / 64) * S * mbs;
   const bool gemm_ok = al && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && K >= 8;
-  const bool slice_ok = gemm_ok && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15);
-  int ksl = slice_ok ? kslices(gemm_blocks, K, N) : 1;
-  if (ksl > 1 && a->split_scratch_bytes < (size_t)ksl * S * B * N * sizeof(float)) ksl = 1;
+  const bool slice_ok = gemm_ok && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
+                        a->split_scratch_bytes >= bnn_bbb_split_scratch_bytes(S, B, N);
+  int forced = 0;
+#ifdef BNN_TUNE
+  if (const char* v = getenv("BNN_TUNE_KSL")) forced = atoi(v);
+#endif
+  // a preference for the sliced form asks for at least two slices
+  const int ksl = slice_ok ? kslices(gemm_blocks, K, a->form == BNN_FORM_GEMM_KSLICE ? 2 : 1, forced) : 1;
   // a->form is a preference: taken when the arguments allow that form, otherwise the plan's own choice
   int form = a->form;
   if ((form == BNN_FORM_GEMM && !gemm_ok) || (form == BNN_FORM_GEMM_KSLICE && ksl <= 1)) form = BNN_FORM_AUTO;
   if (form == BNN_FORM_AUTO) {
-    if (gemm_ok && gemm_blocks >= kGemmMinBlocks) form = BNN_FORM_GEMM;
-    else if (ksl > 1 && (long)K * N >= kSliceMinWeights && gemm_blocks * ksl >= kSliceMinBlocks) form = BNN_FORM_GEMM_KSLICE;
+    if (ksl > 1 && (long)K * N >= kSliceMinWeights && S >= kSliceMinSamples) form = BNN_FORM_GEMM_KSLICE;
+    else if (gemm_ok && gemm_blocks >= kGemmMinBlocks) form = BNN_FORM_GEMM;
     else form = BNN_FORM_TILE;
   }
   if (form == BNN_FORM_TILE) {
@@ -1313,7 +1387,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = a->want_stats ? 1 : 0;
-  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1; k.ksl = 1; k.ks_part = nullptr; k.ldw = 0;
+  k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1; k.ksl = 1; k.ks_part = nullptr; k.ks_ticket = nullptr; k.ldw = 0;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;
 #ifdef BNN_STAMPS
@@ -1389,7 +1463,7 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
   if (a->rider) {
     rc = fill_sample(a->rider, sk, rider_blocks);
     if (rc != BNN_OK) return rc;
-    ride = pl.form == BNN_FORM_TILE && !a->w_sampled && al && math == BNN_MATH_BF16 && pl.nw * 64 >= kSampleThreads;
+    ride = !a->w_sampled && al && math == BNN_MATH_BF16 && pl.nw * 64 >= kSampleThreads;
     if (!ride) {
       rc = bnn_bbb_sample_weights(a->rider, stream_);
       if (rc != BNN_OK) return rc;
@@ -1409,25 +1483,26 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     return err == hipSuccess ? BNN_OK : (int)err;
   }
   if (pl.form != BNN_FORM_TILE) {
-    // Throughput form (block GEMM, x tile shared through LDS); K-range slices write fp32 partial tiles into the
-    // caller's split scratch and a tiny reduce kernel sums them in slice order (deterministic), applies ReLU and the
-    // down-conversion.
+    // Throughput form (block GEMM, x tile shared through LDS); K-range slices leave fp32 partial tiles in the caller's
+    // split scratch and the last-arriving slice block of each unit sums them in slice order (deterministic), applies
+    // ReLU and the down-conversion: one launch.
     k.ksl = pl.ksl;
-    k.ks_part = reinterpret_cast<float*>(a->split_scratch);
-    if (a->w_sigma)
+    if (pl.ksl > 1) {
+      char* base = reinterpret_cast<char*>(a->split_scratch);
+      k.ks_ticket = reinterpret_cast<uint32_t*>(base);
+      k.ks_part = reinterpret_cast<float4*>(base + split_ticket_bytes(pl.blocks / pl.ksl));
+    }
+    if (ride) {
+      const unsigned n_main = grid.x;
+      const dim3 grid_r(n_main + (unsigned)rider_blocks);
+      if (a->w_sigma)
+        hipLaunchKernelGGL((bbb_fwd_gemm_rider_kernel<true>), grid_r, block, 0, stream, k, sk, (int)n_main);
+      else
+        hipLaunchKernelGGL((bbb_fwd_gemm_rider_kernel<false>), grid_r, block, 0, stream, k, sk, (int)n_main);
+    } else if (a->w_sigma)
       hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
     else
       hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
-    if (pl.ksl > 1) {
-      err = hipGetLastError();
-      if (err != hipSuccess) return (int)err;
-      const long cnt = (long)a->n_samples * a->batch * a->out_features;
-      const int vec_ok = (cnt % 4 == 0) && !(reinterpret_cast<uintptr_t>(a->y) & 15);
-      long nb = (cnt / 4 + 255) / 256;
-      nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
-      hipLaunchKernelGGL(ks_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, k.ks_part, pl.ksl, cnt, k.relu, a->y,
-                         k.y_bf16, vec_ok);
-    }
   } else if (ride) {
     const unsigned n_main = (unsigned)(((pl.blocks + 7) / 8) * 8);
     const dim3 grid_r(n_main + (unsigned)rider_blocks);

@@ -34,7 +34,7 @@ using namespace bnn;
 extern "C" size_t bnn_bbb_sample_workspace_bytes(int32_t n_samples, int32_t in_features, int32_t out_features) {
   if (n_samples <= 0 || in_features <= 0 || out_features <= 0 || (in_features & 7)) return 0;
   // at least what bnn_bbb_linear_fwd asks for the same layer, so one workspace serves either form
-  const size_t k1 = (1 + (size_t)n_samples * (size_t)((out_features + 3) / 4)) * 16;
+  const size_t k1 = bnn_bbb_linear_fwd_workspace_bytes(n_samples, out_features);
   const size_t ks = (1 + (size_t)n_samples * (size_t)sample_chunks(in_features, out_features)) * 16;
   return k1 > ks ? k1 : ks;
 }

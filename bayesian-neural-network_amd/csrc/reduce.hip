@@ -219,6 +219,54 @@ __global__ void softplus_kernel(const float* __restrict__ rho, float* __restrict
   }
 }
 
+// ----------------------------------------------------------------------------- evaluation prologue
+// Everything of an evaluation that depends on no activation, in ONE launch: sigma = softplus(rho) of up to
+// BNN_PREPARE_MAX tensors (read by the block-GEMM forms of K1 instead of a softplus per sampled weight) and the bf16
+// cast (+ squares) of the input batch.  Each block owns 4096 consecutive elements of one job; elementwise, so the
+// results are those of bnn_softplus / bnn_cast_bf16.
+struct PrepK {
+  const float* rho[BNN_PREPARE_MAX];
+  float* sigma[BNN_PREPARE_MAX];
+  long n[BNN_PREPARE_MAX];
+  int first_block[BNN_PREPARE_MAX + 1];   // of each softplus job; [n_softplus] = first block of the cast
+  int n_softplus;
+  const float* cast_src;
+  __bf16* cast_dst;
+  __bf16* cast_dsq;
+  long cast_n;
+  int cast_vec;
+};
+constexpr int kPrepPerBlock = 4096;
+
+__global__ __launch_bounds__(256) void eval_prepare_kernel(const PrepK p) {
+  const int b = blockIdx.x;
+  if (b >= p.first_block[p.n_softplus]) {                  // block-uniform
+    const long lo = (long)(b - p.first_block[p.n_softplus]) * kPrepPerBlock;
+    const long cnt = min((long)kPrepPerBlock, p.cast_n - lo);
+    // a block-local span: the vector path needs the span's start 16-byte aligned in all three arrays (lo is a
+    // multiple of 4096 elements)
+    cast_bf16_span(p.cast_src + lo, p.cast_dst + lo, p.cast_dsq ? p.cast_dsq + lo : nullptr, cnt, p.cast_vec, threadIdx.x, 256);
+    return;
+  }
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < p.n_softplus && b >= p.first_block[j + 1]) ++j;
+  const long lo = (long)(b - p.first_block[j]) * kPrepPerBlock;
+  const long cnt = min((long)kPrepPerBlock, p.n[j] - lo);
+  const float* rho = p.rho[j] + lo;
+  float* sg = p.sigma[j] + lo;
+  const bool vec = !((reinterpret_cast<uintptr_t>(rho) | reinterpret_cast<uintptr_t>(sg)) & 15);
+  if (vec) {
+    for (long i = threadIdx.x; i < (cnt >> 2); i += 256) {
+      const float4 r = reinterpret_cast<const float4*>(rho)[i];
+      reinterpret_cast<float4*>(sg)[i] = make_float4(softplus(r.x), softplus(r.y), softplus(r.z), softplus(r.w));
+    }
+    for (long i = ((cnt >> 2) << 2) + threadIdx.x; i < cnt; i += 256) sg[i] = softplus(rho[i]);
+  } else {
+    for (long i = threadIdx.x; i < cnt; i += 256) sg[i] = softplus(rho[i]);
+  }
+}
+
 // ----------------------------------------------------------------------------- Philox fill
 __global__ void philox_normal_kernel(float* __restrict__ eps, uint32_t k0, uint32_t k1, uint32_t tensor_id,
                                      uint32_t sample_offset, int S, int rows, int cols) {
@@ -528,6 +576,41 @@ extern "C" int bnn_cast_bf16(const float* src, void* dst, void* dst_sq, int64_t 
   nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), src,
                      reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dst_sq), (long)n, vec_ok);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
+}
+
+extern "C" int bnn_eval_prepare(const bnn_prepare_args* a, void* stream_) {
+  if (!a) return BNN_ERR_NULL;
+  if (a->struct_bytes != sizeof(bnn_prepare_args)) return BNN_ERR_ABI;
+  if (a->n_softplus < 0 || a->n_softplus > BNN_PREPARE_MAX || a->cast_n < 0) return BNN_ERR_SHAPE;
+  PrepK k{};
+  long blocks = 0;
+  for (int i = 0; i < a->n_softplus; ++i) {
+    if (!a->rho[i] || !a->sigma[i]) return BNN_ERR_NULL;
+    if (a->n[i] <= 0) return BNN_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(a->rho[i]) | reinterpret_cast<uintptr_t>(a->sigma[i])) & 3) return BNN_ERR_ALIGN;
+    k.rho[i] = a->rho[i]; k.sigma[i] = a->sigma[i]; k.n[i] = (long)a->n[i];
+    k.first_block[i] = (int)blocks;
+    blocks += (a->n[i] + kPrepPerBlock - 1) / kPrepPerBlock;
+    if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
+  }
+  k.n_softplus = a->n_softplus;
+  for (int i = a->n_softplus; i <= BNN_PREPARE_MAX; ++i) k.first_block[i] = (int)blocks;
+  if (a->cast_n > 0) {
+    if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(a->cast_src) & 3) || (reinterpret_cast<uintptr_t>(a->cast_dst) & 1) ||
+        (reinterpret_cast<uintptr_t>(a->cast_dst_sq) & 1))
+      return BNN_ERR_ALIGN;
+    k.cast_src = a->cast_src; k.cast_dst = reinterpret_cast<__bf16*>(a->cast_dst);
+    k.cast_dsq = reinterpret_cast<__bf16*>(a->cast_dst_sq); k.cast_n = (long)a->cast_n;
+    k.cast_vec = !((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst) |
+                    reinterpret_cast<uintptr_t>(a->cast_dst_sq)) & 15);
+    blocks += (a->cast_n + kPrepPerBlock - 1) / kPrepPerBlock;
+    if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
+  }
+  if (blocks == 0) return BNN_ERR_SHAPE;
+  hipLaunchKernelGGL(eval_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), k);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -176,9 +176,12 @@ typedef struct bnn_bbb_fwd_args {
                                the arguments allow that form (bnn_bbb_plan tells), else the plan's own choice.
                                Tests compare the forms with each other through it; bnn_bbb_final_fwd fuses the
                                finalize only under BNN_FORM_AUTO */
-  void* split_scratch;      /* optional, 16-byte aligned, >= 8 * n_samples*batch*out_features*4 bytes:
-                               lets a mid-sized launch split its K range over several blocks
-                               (fp32 partial tiles summed in a fixed order by a tiny second kernel) */
+  void* split_scratch;      /* optional, 16-byte aligned, >= bnn_bbb_split_scratch_bytes(n_samples, batch, out_features),
+                               its first bnn_bbb_split_scratch_zero_bytes(...) bytes zero before the first launch that
+                               uses it (launches leave them zero): lets a mid-sized launch (4 .. ~100 samples) split its
+                               K range over several blocks; the block of a slice that finishes last adds the slices'
+                               fp32 partial tiles up in slice order (bitwise reproducible), in the same launch.  One
+                               scratch serves one launch at a time */
   size_t split_scratch_bytes;
   const float* w_sigma;     /* optional [out,in]: softplus(w_rho) from bnn_softplus, computed once per
                                evaluation; the throughput kernel then skips the per-sample softplus */
@@ -195,6 +198,8 @@ typedef struct bnn_bbb_fwd_args {
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
+size_t bnn_bbb_split_scratch_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
+size_t bnn_bbb_split_scratch_zero_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
 int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
 int bnn_bbb_plan(const bnn_bbb_fwd_args* args, bnn_plan* plan);
 
@@ -622,6 +627,27 @@ int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sa
 int bnn_softplus(const float* rho, float* sigma, int64_t n, void* stream);
 
 int bnn_cast_bf16(const float* src, void* dst_bf16, void* dst_sq_bf16 /* optional: x*x */, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * bnn_eval_prepare — the two passes above for a whole evaluation in ONE launch: everything that depends on no
+ * activation.  sigma[i] = softplus(rho[i]) for up to BNN_PREPARE_MAX parameter tensors (networks.py:37-39 evaluates
+ * it three times per node and forward; here once per evaluation, then shared by all MC samples through
+ * bnn_bbb_fwd_args.w_sigma) and, optionally, the bf16 cast (+ squares) of the input batch.  Elementwise: the same
+ * values as bnn_softplus / bnn_cast_bf16.
+ * ---------------------------------------------------------------------------------- */
+#define BNN_PREPARE_MAX 8
+typedef struct bnn_prepare_args {
+  uint32_t struct_bytes;
+  int32_t n_softplus;                     /* 0 .. BNN_PREPARE_MAX */
+  const float* rho[BNN_PREPARE_MAX];
+  float* sigma[BNN_PREPARE_MAX];
+  int64_t n[BNN_PREPARE_MAX];             /* elements of each tensor */
+  const float* cast_src;                  /* optional (cast_n > 0) */
+  void* cast_dst;                         /* bf16 */
+  void* cast_dst_sq;                      /* optional bf16: src * src */
+  int64_t cast_n;
+} bnn_prepare_args;
+int bnn_eval_prepare(const bnn_prepare_args* args, void* stream);
 
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
 const char* bnn_status_string(int status); /* static string for a negative status */

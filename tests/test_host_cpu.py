@@ -38,7 +38,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     from bnn_hip import _lib
     pairs = [("bnn_bbb_fwd_args", _lib.BbbFwdArgs), ("bnn_lr_fwd_args", _lib.LrFwdArgs),
              ("bnn_finalize_args", _lib.FinalizeArgs), ("bnn_bbb_bwd_args", _lib.BbbBwdArgs),
-             ("bnn_lr_bwd_args", _lib.LrBwdArgs), ("bnn_adam_args", _lib.AdamArgs), ("bnn_prior", _lib.Prior)]
+             ("bnn_lr_bwd_args", _lib.LrBwdArgs), ("bnn_adam_args", _lib.AdamArgs), ("bnn_prior", _lib.Prior),
+             ("bnn_prepare_args", _lib.PrepareArgs)]
     lines, want = [], []
     for cname, cls in pairs:
         lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
@@ -69,7 +70,9 @@ def test_argument_validation_without_a_device():
     assert lib.bnn_elbo_finalize(C.byref(f), None) == -2
     assert lib.bnn_gauss_kl(None, None, 10, 1.0, None, 0, None, None) == -1
     assert lib.bnn_philox_normal(None, 1, 0, 0, 1, 1, 1, None) == -1
-    assert lib.bnn_bbb_linear_fwd_workspace_bytes(2, 1200) == (1 + 2 * 300) * 16
+    assert lib.bnn_bbb_linear_fwd_workspace_bytes(2, 1200) == (1 + 2 * 75 * 8) * 16    # 8 statistics writers per 16-feature tile
+    assert lib.bnn_bbb_split_scratch_bytes(8, 128, 1200) == 768 + 152 * 8 * 32768 and \
+        lib.bnn_bbb_split_scratch_zero_bytes(8, 128, 1200) == 768
     assert lib.bnn_lr_linear_fwd_workspace_bytes(1200) == (1 + 300) * 16
     lb = L.LrBwdArgs()
     assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -5
@@ -302,7 +305,7 @@ def test_launch_plans_are_a_function_of_the_shape():
     def bbb(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, scratch=False):
         a = _plan_args(L.BbbFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
                        b_mu=P, b_rho=P, math=math, y=P, form=form, split_scratch=P if scratch else None,
-                       split_scratch_bytes=(8 * S * B * N * 4) if scratch else 0)
+                       split_scratch_bytes=lib.bnn_bbb_split_scratch_bytes(S, B, N) if scratch else 0)
         a.prior.sigma_p = 1.0
         pl = L.Plan()
         assert lib.bnn_bbb_plan(C.byref(a), C.byref(pl)) == 0
@@ -320,18 +323,28 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert (pl.form, pl.k_classes, pl.waves, pl.blocks, pl.features_per_block) == (L.FORM_TILE, 2, 12, 150, 8)
     pl = bbb(1, 128, 784, 1200, xdt=L.F32)
     assert (pl.form, pl.k_classes, pl.blocks) == (L.FORM_TILE, 2, 150)
-    # C4's per-GPU share (8 samples): whole 16-feature tiles, 4-wave blocks, three to a CU
+    # C4's per-GPU share (8 samples): the K-sliced block GEMM when a scratch is there -- 5 slices put 760 blocks of 8
+    # k-steps on the 256 CUs, 3 x 8 = 24 steps per SIMD against the ideal 22.3 -- else whole 16-feature tiles, 4-wave blocks
+    pl = bbb(8, 128, 1200, 1200, scratch=True)
+    assert (pl.form, pl.k_slices, pl.waves, pl.blocks) == (L.FORM_GEMM_KSLICE, 5, 4, 760)
+    assert [bbb(S, 128, 1200, 1200, scratch=True).k_slices for S in (4, 16, 32, 64)] == [6, 3, 2, 1]
     pl = bbb(8, 128, 1200, 1200)
     assert (pl.form, pl.k_classes, pl.waves, pl.blocks) == (L.FORM_TILE, 1, 4, 600)
-    # the throughput regime: block GEMM from 450 (64-feature group x sample) items
+    assert bbb(8, 128, 784, 1200, scratch=True).form == L.FORM_GEMM_KSLICE
+    assert bbb(8, 128, 784, 1200, xdt=L.F32, scratch=True).form == L.FORM_TILE          # the block GEMM streams bf16 x
+    # the throughput regime: block GEMM from 450 (64-feature group x sample) items; slices stop paying once the
+    # whole-K blocks alone balance
     assert bbb(24, 128, 1200, 1200).form == L.FORM_GEMM and bbb(23, 128, 1200, 1200).form == L.FORM_TILE
+    assert bbb(256, 128, 1200, 1200, scratch=True).form == L.FORM_GEMM
     pl = bbb(256, 128, 1200, 1200)
     assert (pl.form, pl.waves, pl.blocks, pl.features_per_block) == (L.FORM_GEMM, 4, 19 * 256, 64)
     assert bbb(256, 128, 1200, 1200, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE      # fp32 math has no GEMM form
     # C5's per-GPU share: K-sliced GEMM for the 16.8 M-weight layer when a scratch is there, the tile form without
     pl = bbb(4, 128, 4096, 4096, scratch=True)
     assert pl.form == L.FORM_GEMM_KSLICE and pl.k_slices >= 2 and pl.blocks == 64 * 4 * pl.k_slices
-    assert bbb(4, 128, 4096, 4096).form == L.FORM_TILE and bbb(4, 128, 1200, 1200, scratch=True).form == L.FORM_TILE
+    assert bbb(4, 128, 4096, 4096).form == L.FORM_TILE
+    # below 4 samples and for small layers the narrow-tile form stays
+    assert bbb(3, 128, 1200, 1200, scratch=True).form == L.FORM_TILE and bbb(8, 128, 1200, 64, scratch=True).form == L.FORM_TILE
     # a form preference is honoured when the arguments allow it, ignored otherwise
     assert bbb(2, 128, 1200, 1200, form=L.FORM_GEMM).form == L.FORM_GEMM
     assert bbb(2, 128, 1200, 1200, math=L.MATH_F32, xdt=L.F32, form=L.FORM_GEMM).form == L.FORM_TILE
