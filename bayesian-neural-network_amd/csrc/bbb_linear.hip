@@ -57,6 +57,7 @@ struct BbbK {
   int ksl;          // GEMM form: K-range slices per (tile group, sample, batch block) unit; 1 = none
   float4* ks_part;  // GEMM form, ksl > 1: fp32 partial tiles [unit][ksl][wave][batch tile][lane] (bias in slice 0)
   uint32_t* ks_ticket;  // GEMM form, ksl > 1: [unit] arrival counters of a unit's slice blocks, zero between launches
+  Xcd2D xc;             // GEMM form: work order (feature group x (sample, batch block) x K slice), see bnn_device.h
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
   const float* b_pre;   // PRE only: sampled biases [S, N]
@@ -890,12 +891,11 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
   const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
-  int item;
   const int KS = p.ksl;                                       // K-range slices (deterministic split-K)
-  if (!xcd_work_item(tbs * p.S * mbs * KS, item)) return;      // block-uniform
-  const int ks = item % KS;
-  item /= KS;
-  const int tb = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
+  int tb, unit, ks;
+  if (!xcd2d_work_item(p.xc, tb, unit, ks)) return;            // block-uniform
+  const int s = unit / mbs, mb = unit - s * mbs;
+  const int item = tb * (p.S * mbs) + unit;                    // dense (group, sample, batch block) index
   const int tile = tb * NW + wave;
   const int n = tile * 16 + r;
   const bool n_ok = n < N;
@@ -1215,6 +1215,8 @@ struct BbbPlan {
   size_t lds;
 };
 
+constexpr size_t kL2WeightBudget = 2560 * 1024;   // of an XCD's 4 MiB L2: the (mu, rho | sigma) of the feature groups a class of the
+                                                  // 2-D work order keeps resident while the units' x tiles stream through
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
 constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
 constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
@@ -1487,6 +1489,14 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     // split scratch and the last-arriving slice block of each unit sums them in slice order (deterministic), applies
     // ReLU and the down-conversion: one launch.
     k.ksl = pl.ksl;
+    {
+      size_t l2_budget = kL2WeightBudget;
+#ifdef BNN_TUNE
+      if (const char* v = getenv("BNN_TUNE_L2KB")) l2_budget = (size_t)atol(v) * 1024;
+#endif
+      const int mbs_ = (a->batch + 127) / 128;
+      k.xc = xcd2d_make((a->out_features + 63) / 64, a->n_samples * mbs_, pl.ksl, (size_t)64 * K * 8, l2_budget);
+    }
     if (pl.ksl > 1) {
       char* base = reinterpret_cast<char*>(a->split_scratch);
       k.ks_ticket = reinterpret_cast<uint32_t*>(base);

@@ -129,6 +129,55 @@ __device__ __forceinline__ bool xcd_work_item(int total, int& item) {
   return (b >> 3) < chunk && item < total;
 }
 
+// 2-D XCD-aware work order of the block-GEMM forms (speed only, never correctness).  A work item is (feature group
+// g < G, unit u < U, sub-item in < inner) with unit = (sample, 128-row batch block) and sub-items such as K slices.
+// Through its XCD's L2 a block pulls its group's weights (shared by every unit) and its unit's x tiles (shared by every
+// group).  Dealing the items out group-major (the 1-D order above) keeps the weights resident but fetches a unit's x
+// from memory once per GROUP -- measured on the 1200 x 1200 LR layer: 1.8 GB per 256-sample launch, 10 x the x bytes,
+// and the kernel's bound at 6.2 TB/s.  Here the groups are split into `classes` classes of (nearly) equal size, each
+// small enough to stay L2-resident; the work list is class-major, then unit, then group within the class, then
+// sub-item, and XCD x owns the contiguous range [x * chunk, (x + 1) * chunk) of it (block b runs on XCD b % 8, launch
+// after launch: tools/xcc_probe.hip).  An XCD therefore works on one class at a time, the sibling blocks of a unit
+// (same x, the class's groups) are dispatched back to back, run side by side and read the unit's x tiles within
+// microseconds of each other: memory serves them once per class instead of once per group, and the XCDs hold equal
+// item counts whatever the class sizes.  Grid: 8 * ceil(G * U * inner / 8) blocks; false for the padding blocks.
+struct Xcd2D {
+  int G, U, classes, inner;
+};
+__device__ __forceinline__ bool xcd2d_work_item(const Xcd2D& m, int& g, int& u, int& in) {
+  const long total = (long)m.G * m.U * m.inner;
+  const long chunk = (total + 7) >> 3;
+  const int b = blockIdx.x;
+  long f = (long)(b & 7) * chunk + (b >> 3);
+  if ((b >> 3) >= chunk || f >= total) return false;
+  const int base = m.G / m.classes, extra = m.G % m.classes;
+  const long per_group = (long)m.U * m.inner;
+  int h = 0, start = 0, size = base + (extra > 0 ? 1 : 0);
+#pragma unroll 1
+  while (f >= (long)size * per_group) {              // wave-uniform: at most `classes` rounds on the scalar unit
+    f -= (long)size * per_group;
+    start += size;
+    ++h;
+    size = base + (h < extra ? 1 : 0);
+  }
+  const int row = size * m.inner;
+  u = (int)(f / row);
+  const int rem = (int)(f - (long)u * row);
+  g = start + rem / m.inner;
+  in = rem % m.inner;
+  return true;
+}
+// Host side: as few classes as keep a class's groups within the L2 budget.
+inline Xcd2D xcd2d_make(int G, int U, int inner, size_t group_bytes, size_t l2_budget) {
+  Xcd2D m;
+  m.G = G; m.U = U; m.inner = inner < 1 ? 1 : inner;
+  size_t per = group_bytes ? l2_budget / group_bytes : (size_t)G;
+  if (per < 1) per = 1;
+  int c = (int)((G + per - 1) / per);
+  m.classes = c < 1 ? 1 : (c > G ? G : c);
+  return m;
+}
+
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
 // the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
 __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,

@@ -41,6 +41,10 @@ struct LrK {
   void* y;
   const void* x_sq; // optional bf16 x*x (same shape as x)
   const float4* w_frag;  // optional prepared weights (lr_prepare_kernel): [T][ksteps][2][64] x 16 B
+  Xcd2D xc;              // K3b: work order (feature group x (sample, batch block)), see bnn_device.h
+#ifdef BNN_TUNE
+  int tune;              // tuning build only: 1 = no MFMAs, 2 = no LDS reads, 4 = no loads in the k loop
+#endif
   void* y_sq;       // optional bf16 y*y
   float* v_out;     // optional fp32 variance
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
@@ -493,17 +497,27 @@ __global__ __launch_bounds__(512) void lr_prepare_kernel(const float* __restrict
   }
 }
 
-template <int NW, bool PREP>
-__global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_gemm_kernel(const LrK p) {
-  __shared__ __attribute__((aligned(16))) float4 xt[2][2][8 * 64];   // [buffer][x | x^2][tile] = 32 KiB
+// DEPTH = k-steps of prefetch (PREP only takes 2).  A step's loads -- x / x^2 tiles by LDS-DMA, prepared fragments to
+// registers -- are issued DEPTH steps ahead and waited for one step ahead (s_waitcnt vmcnt(ops of the younger step)),
+// in a ring of DEPTH + 1 LDS buffers.  With one step of prefetch every block-step lasted a whole L2 round trip on top
+// of its own work: with the fabric traffic out of the way (2-D work order) the counters showed MFMA, LDS, L2 and VALU
+// each ~26 % busy and the waves parked two thirds of the time.
+template <int NW, bool PREP, int DEPTH>
+__global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(const LrK p) {
+  static_assert(DEPTH == 1 || (PREP && DEPTH == 2), "two steps of prefetch: prepared fragments only");
+  typedef float4 XtB[2][8 * 64];                                    // [x | x^2][tile]: 16 KiB
+  __shared__ __attribute__((aligned(16))) XtB xt[DEPTH + 1];        // ring: step t reads xt[t % (DEPTH + 1)]
   __shared__ float bias_s[NW][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
   const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
-  int item;
-  if (!xcd_work_item(tbs * p.S * mbs, item)) return;          // block-uniform
-  const int tb = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
+  int tb, unit, in_;
+  if (!xcd2d_work_item(p.xc, tb, unit, in_)) return;          // block-uniform
+  LR_STAMP(0);
+  LR_STAMP_RT(8);
+  const int s = unit / mbs, mb = unit - s * mbs;
+  const int item = tb * (p.S * mbs) + unit;
   const int tile = tb * NW + wave;
   const int n = tile * 16 + r;
   const bool n_ok = n < N;
@@ -517,35 +531,44 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
   const int T = (N + 15) >> 4;
   if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
 
-  size_t xrow[8 / NW];
+  // staging: 16 tile pieces per k-step (8 batch tiles of x, 8 of x^2); NW <= 8: wave w brings batch tiles w, w + NW, ...
+  // of both; NW == 16: waves 0..7 bring the x tiles, waves 8..15 the x^2 tiles
+  constexpr int NX = NW >= 8 ? 1 : 8 / NW;
+  constexpr int OPS = (NW == 16 ? 1 : 2 * NX) + 2;          // vector-memory operations a wave issues per step (PREP)
+  size_t xrow[NX];
 #pragma unroll
-  for (int i = 0; i < 8 / NW; ++i) xrow[i] = (size_t)min(m0 + (wave + i * NW) * 16 + r, B - 1) * K;
-  auto stage_dma = [&](int t, int buf) {
+  for (int i = 0; i < NX; ++i) xrow[i] = (size_t)min(m0 + ((wave & 7) + i * NW) * 16 + r, B - 1) * K;
+  auto stage_dma = [&](int t, XtB& xb_) __attribute__((always_inline)) {
     const int kk = min(t * 32 + q * 8, K - 8);
+    if (NW == 16) {
+      const __bf16* src = (wave < 8 ? xs : xq) + xrow[0] + kk;          // wave-uniform select
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&xb_[wave >> 3][(wave & 7) * 64], 16, 0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8 / NW; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
-                                       (__attribute__((address_space(3))) void*)&xt[buf][0][(wave + i * NW) * 64], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + xrow[i] + kk),
-                                       (__attribute__((address_space(3))) void*)&xt[buf][1][(wave + i * NW) * 64], 16, 0, 0);
+      for (int i = 0; i < NX; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
+                                         (__attribute__((address_space(3))) void*)&xb_[0][(wave + i * NW) * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + xrow[i] + kk),
+                                         (__attribute__((address_space(3))) void*)&xb_[1][(wave + i * NW) * 64], 16, 0, 0);
+      }
     }
   };
   float mu_n[8], rho_n[8];
-  float4 ma_n, sa_n;                                   // PREP: prepared bf16 fragments
+  float4 ma_a, sa_a, ma_b, sa_b;                       // PREP: prepared bf16 fragments of the steps in flight
   const int tclamp = min(tile, T - 1);
-  auto load_params = [&](int t) {
-    if (PREP) {
-      const float4* src = p.w_frag + ((size_t)tclamp * ksteps + t) * 128;
-      ma_n = src[lane];
-      sa_n = src[64 + lane];
-    } else {
-      const int k = t * 32 + q * 8;
+  auto load_frag = [&](int t, float4& ma_r, float4& sa_r) {
+    const float4* src = p.w_frag + ((size_t)tclamp * ksteps + t) * 128;
+    ma_r = src[lane];
+    sa_r = src[64 + lane];
+  };
+  auto load_raw = [&](int t) {
+    const int k = t * 32 + q * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const size_t off = (size_t)min(k + j, K - 1) * N + nc;
-        mu_n[j] = p.w_mu[off];
-        rho_n[j] = p.w_rho[off];
-      }
+    for (int j = 0; j < 8; ++j) {
+      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
+      mu_n[j] = p.w_mu[off];
+      rho_n[j] = p.w_rho[off];
     }
   };
   float bmu_pre = 0.f, bsig_pre = 0.f, beps_pre = 0.f;
@@ -561,11 +584,24 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
     }
     if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
   }
-  load_params(0);
-  stage_dma(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the bias loads are not part of the ring's count
+  if (PREP) load_frag(0, ma_a, sa_a); else load_raw(0);
+  stage_dma(0, xt[0]);
+  if (DEPTH == 2 && ksteps > 1) {
+    load_frag(1, ma_b, sa_b);
+    stage_dma(1, xt[1]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (PREP) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
 
+  LR_STAMP(1);
   f32x4 am[8], av[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -573,18 +609,14 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
     av[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
-#pragma nounroll
-  for (int t = 0; t < ksteps; ++t) {
-    const int k = t * 32 + q * 8;
+  // one k-step: consume the fragments of step t (held in ma_r / sa_r), refill them for step t + DEPTH, 16 MFMAs on
+  // ring buffer `buf`, then wait for step t + 1's loads and meet the block
+  auto step = [&](int t, XtB& cur, XtB& nxt, float4& ma_r, float4& sa_r, bool steady) __attribute__((always_inline)) {
     bf16x8 ma, sa;
     float mu[8], s2[8];
     if (PREP) {
-      ma = __builtin_bit_cast(bf16x8, ma_n);
-      sa = __builtin_bit_cast(bf16x8, sa_n);
-      if (tile >= T) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ma[j] = sa[j] = (__bf16)0.f;
-      }
+      ma = __builtin_bit_cast(bf16x8, ma_r);             // a wave past the last tile computes on the last tile's
+      sa = __builtin_bit_cast(bf16x8, sa_r);             // fragments (finite) and stores nothing
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -592,11 +624,18 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
         s2[j] = rho_n[j];
       }
     }
-    if (t + 1 < ksteps) {
-      stage_dma(t + 1, (t + 1) & 1);
-      load_params(t + 1);
+    const bool more = steady || t + DEPTH < ksteps;      // block-uniform; `steady`: known at compile time in the main loop
+#ifdef BNN_TUNE
+    const bool tune_noload = (p.tune & 4) != 0;
+#else
+    constexpr bool tune_noload = false;
+#endif
+    if (more && !tune_noload) {
+      stage_dma(t + DEPTH, nxt);
+      if (PREP) load_frag(t + DEPTH, ma_r, sa_r); else load_raw(t + DEPTH);
     }
     if (!PREP) {
+      const int k = t * 32 + q * 8;
       float ls = 0.f, a2 = 0.f, m2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -619,19 +658,100 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
         sa[j] = (__bf16)s2[j];
       }
     }
-    const float4* xb = xt[t & 1][0];
-    const float4* qb = xt[t & 1][1];
+    if (PREP) {
+      // The B fragments are read with hand-written ds_read_b128: a compiler-visible LDS load is ordered behind EVERY
+      // LDS-DMA in flight that may alias it (s_waitcnt vmcnt(0) ahead of the step's first read), i.e. behind the
+      // prefetch this step has just issued -- the step then costs a memory round trip plus its own work.  Here the
+      // order is stated by hand: buffer `cur` was complete at the last barrier, and LDS returns in order, so
+      // lgkmcnt(2) means "all but the 2 youngest reads are back".  Two fragments in flight behind two in use.
+      const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&cur[0][0] + (uint32_t)((q * 16 + r) * 16);
+      f32x4 f0, f1, g0, g1;
+#define BNN_LDS2(a, b, O)                                                                         \
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                   \
+               : "=v"(a), "=v"(b)                                                                 \
+               : "v"(la), "n"((O)), "n"((O) + 1024))
+#define BNN_LGKM(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b))
+#ifdef BNN_TUNE
+#define BNN_MF(ACC, W, F) if (!(p.tune & 1)) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, __builtin_bit_cast(bf16x8, F), ACC, 0, 0, 0)
+#define BNN_RD (!(p.tune & 2))
+#else
+#define BNN_MF(ACC, W, F) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, __builtin_bit_cast(bf16x8, F), ACC, 0, 0, 0)
+#define BNN_RD true
+#endif
+#define BNN_PAIR(M, LAST)                                                                         \
+  BNN_LGKM(2, f0, f1);                                                                            \
+  BNN_MF(am[M], ma, f0); BNN_MF(am[M + 1], ma, f1);                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (!(LAST) && BNN_RD) BNN_LDS2(f0, f1, (M + 2) * 1024);                                                  \
+  if (LAST) { BNN_LGKM(0, g0, g1); } else { BNN_LGKM(2, g0, g1); }                                \
+  BNN_MF(av[M], sa, g0); BNN_MF(av[M + 1], sa, g1);                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (!(LAST) && BNN_RD) BNN_LDS2(g0, g1, 8192 + (M + 2) * 1024);
+      BNN_LDS2(f0, f1, 0);                               // x,   batch tiles 0, 1
+      BNN_LDS2(g0, g1, 8192);                            // x^2, batch tiles 0, 1
+      BNN_PAIR(0, false)
+      BNN_PAIR(2, false)
+      BNN_PAIR(4, false)
+      BNN_PAIR(6, true)
+#undef BNN_PAIR
+#undef BNN_RD
+#undef BNN_LDS2
+#undef BNN_LGKM
+#undef BNN_MF
+    } else {
+      const float4* xb = cur[0];
+      const float4* qb = cur[1];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
-      const bf16x8 qf = __builtin_bit_cast(bf16x8, qb[(m * 4 + q) * 16 + r]);
-      am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xf, am[m], 0, 0, 0);
-      av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, qf, av[m], 0, 0, 0);
+      for (int m = 0; m < 8; ++m) {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
+        const bf16x8 qf = __builtin_bit_cast(bf16x8, qb[(m * 4 + q) * 16 + r]);
+        am[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xf, am[m], 0, 0, 0);
+        av[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, qf, av[m], 0, 0, 0);
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // all but this step's own issues have landed; then the block meets.  A bare s_barrier, not __syncthreads(): its
+    // workgroup fence would drain every LDS-DMA in flight (vmcnt(0)) and with it the second step of prefetch.  What the
+    // barrier must order is stated by hand: this wave's LDS reads of `buf` are complete (the MFMAs consumed them), its
+    // DMA pieces of step t + 1 have landed (the vmcnt wait).
+    if (DEPTH == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PREP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      __syncthreads();
+    }
+  };
+  if (DEPTH == 1) {
+#pragma nounroll
+    for (int t = 0; t < ksteps; ++t) step(t, xt[t & 1], xt[(t + 1) & 1], ma_a, sa_a, false);
+  } else {
+    // step t reads ring buffer t % 3 and fills buffer (t + 2) % 3 for step t + 2; the fragments alternate between two
+    // register sets.  Steady state: both steps of a pair refill (no branch in the body), so the compiler's own
+    // wait-count bookkeeping for the fragment registers stays exact instead of draining to zero at the back edge.
+    int t = 0, b0 = 0;
+    // (the compiler still drains vmcnt to zero at the loop header -- it cannot see the hand-written waits -- so the
+    // body holds six steps: one full drain per six)
+#pragma nounroll
+    for (; t + 7 < ksteps; t += 6) {
+      step(t, xt[0], xt[2], ma_a, sa_a, true);
+      step(t + 1, xt[1], xt[0], ma_b, sa_b, true);        // step t + 3 reuses the buffer of step t
+      step(t + 2, xt[2], xt[1], ma_a, sa_a, true);
+      step(t + 3, xt[0], xt[2], ma_b, sa_b, true);
+      step(t + 4, xt[1], xt[0], ma_a, sa_a, true);
+      step(t + 5, xt[2], xt[1], ma_b, sa_b, true);
+    }
+#pragma nounroll
+    for (; t < ksteps; t += 2) {
+      const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+      step(t, xt[b0], xt[b2], ma_a, sa_a, false);
+      if (t + 1 < ksteps) step(t + 1, xt[b1], xt[b0], ma_b, sa_b, false);
+      b0 = b2;
+    }
   }
 
+  LR_STAMP(2);
   if (q == 0) {
     float b = 0.f;
     if (n_ok) {
@@ -659,10 +779,18 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int brow = m0 + m * 16 + r;
+#ifdef BNN_TUNE
+      if (brow < B && !((p.tune & 16) && brow > 0)) {
+#else
       if (brow < B) {
+#endif
         const size_t yoff = ((size_t)s * B + brow) * N + nb;
         float e4[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef BNN_TUNE
+        if (p.eps_mode == BNN_EPS_PHILOX && !(p.tune & 8)) {
+#else
         if (p.eps_mode == BNN_EPS_PHILOX) {
+#endif
           philox_normal4((uint32_t)brow * (uint32_t)gprN + (uint32_t)(nb >> 2), gs, p.layer_id * 4u + 2u, p.k0, p.k1, e4);
         } else if (p.eps_mode == BNN_EPS_MEMORY) {
 #pragma unroll
@@ -719,6 +847,12 @@ __global__ __launch_bounds__(NW * 64, PREP ? (NW == 8 ? 4 : 4) : 3) void lr_fwd_
       }
     }
   }
+#ifdef BNN_STAMPS
+  LR_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LR_STAMP(4);
+  LR_STAMP_RT(9);
+#endif
 }
 
 // KL of one LR layer from its partials (networks.py:113, :134-136).  The partials fold
@@ -854,9 +988,13 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
     pl.form = BNN_FORM_GEMM;
     pl.R = 1; pl.MT = 8;
     // prepared fragments, wide layer: 8 waves share each x / x^2 tile (twice the MFMA work per LDS-DMA round trip)
-    pl.nw = (a->w_frag && N >= 128) ? 8 : 4;
+    // ... 16 waves on a layer of >= 512 features: the x / x^2 tiles serve 256 features, a quarter less L2 traffic per MFMA
+    pl.nw = (a->w_frag && N >= 512) ? 16 : (a->w_frag && N >= 128) ? 8 : 4;
+#ifdef BNN_TUNE
+    if (const char* v = getenv("BNN_TUNE_LRNW")) { const int f = atoi(v); if (a->w_frag && (f == 4 || f == 8 || f == 16)) pl.nw = f; }
+#endif
     pl.total = (long)((N + 16 * pl.nw - 1) / (16 * pl.nw)) * a->n_samples * mbs;
-    pl.lds = 2 * 2 * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);
+    pl.lds = (size_t)(a->w_frag ? 3 : 2) * 2 * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);   // static: the ring of x / x^2 tile pairs + biases
     return BNN_OK;
   }
   int R = 1;
@@ -918,12 +1056,27 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   hipError_t err = hipSuccess;
   const dim3 grid((unsigned)(((pl.total + 7) / 8) * 8)), block(pl.nw * 64);
   if (pl.form == BNN_FORM_GEMM) {
+#ifdef BNN_TUNE
+    k.tune = getenv("BNN_TUNE_LRFLAGS") ? atoi(getenv("BNN_TUNE_LRFLAGS")) : 0;
+#endif
+    {
+      // of an XCD's 4 MiB L2 for the prepared weights of a class's feature groups: each unit streams 614 KB of x and
+      // x^2 tiles through the same L2 (measured on 1200 x 1200, 256 samples: 1300 KB 290 us, 2560 KB 322, one class 362)
+      size_t l2_budget = 1300 * 1024;
+#ifdef BNN_TUNE
+      if (const char* v = getenv("BNN_TUNE_L2KB")) l2_budget = (size_t)atol(v) * 1024;
+#endif
+      const int feats = 16 * pl.nw;
+      k.xc = xcd2d_make((N + feats - 1) / feats, a->n_samples * ((a->batch + 127) / 128), 1,
+                        (size_t)feats * K * (a->w_frag ? 4 : 8), l2_budget);
+    }
     if (a->w_frag) {
       if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
-      if (pl.nw == 8) hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true>), grid, block, 0, stream, k);
-      else hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
+      if (pl.nw == 16) hipLaunchKernelGGL((lr_fwd_gemm_kernel<16, true, 2>), grid, block, 0, stream, k);
+      else if (pl.nw == 8) hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true, 2>), grid, block, 0, stream, k);
+      else hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true, 2>), grid, block, 0, stream, k);
     } else {
-      hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
+      hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, false, 1>), grid, block, 0, stream, k);
     }
   } else {
     const int R = pl.R, MT = pl.MT;

@@ -353,7 +353,7 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert lr(1, 128, 1200, 1200).form == L.FORM_TILE and lr(64, 128, 1200, 1200).form == L.FORM_TILE
     pl = lr(64, 128, 1200, 1200, sq=True)
     assert (pl.form, pl.waves) == (L.FORM_GEMM, 4)
-    assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 8
+    assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 16 and lr(64, 128, 1200, 256, sq=True, frag=True).waves == 8
     pl = lr(1, 128, 1200, 10)
     assert (pl.form, pl.batch_rows, pl.k_classes) == (L.FORM_TILE, 32, 4)
     # invariants over a sweep of shapes
