@@ -107,6 +107,13 @@ def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
     return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 300
 
 
+def wide_nll(specs, batch: int) -> bool:
+    """The finalize of this network sums its NLL by row blocks spread over the chip (bnn_elbo_finalize with a scratch):
+    wide outputs, where one block per sample would walk batch x outputs elements through a single CU."""
+    n_out = specs[-1].in_out[1]
+    return n_out > 32 and batch * n_out >= 32768
+
+
 def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of global sample indices owned by `rank`: [first, first+count).
     The first (n_samples % world) ranks own one extra sample."""
@@ -317,7 +324,7 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
                           local_reparam=local_reparam, prior=layers[0].m._prior_spec, n_samples=n_local, target=target,
                           mode=mode, nll_sigma=float(sigma),
                           ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None,
-                          scratch=None if local_reparam else ops.final_scratch(n_local, dev))
+                          scratch=ops.final_scratch(n_local, dev) if (not local_reparam or wide_nll(layers, x.shape[0])) else None)
         fused_node = differentiable and injected is None and FUSED_ELBO_NODE and x.dtype == torch.float32 and \
             all(bool(sp.lr) == bool(local_reparam) for sp in layers)
         if fused_node:
@@ -454,7 +461,7 @@ class GraphedElbo:
         self._sums = torch.zeros((self.G, 4), dtype=torch.float32, device=dev)
         self.sums = self._sums if self.G > 1 else self._sums.view(4)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.scratch = None if self.lr else ops.final_scratch(S, dev)
+        self.scratch = ops.final_scratch(S, dev) if (not self.lr or wide_nll(self.specs, B)) else None
         # large batches: sample once per launch, then a plain library GEMM (use_library_gemm)
         self.lib = [use_library_gemm(sp, B, hid) for sp in self.specs]
         self.lib_w = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) if lb else None

@@ -22,6 +22,8 @@ struct FinK {
   uint32_t sample_counter_inc;
   int group;                     // MC samples per minibatch when the launch holds several (0: one evaluation)
   long tgt_stride;               // elements between the targets of consecutive minibatches (0: one target for all)
+  const float* nll_partial;      // optional [S][nll_rb]: the NLL of row blocks, summed here instead of walking the logits
+  int nll_rb;
 };
 
 // All transcendental constants of the priors, precomputed on the host in fp64.
@@ -65,6 +67,7 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
   k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
   k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
   k.group = a->group_samples;
+  k.nll_partial = nullptr; k.nll_rb = 0;
   k.tgt_stride = a->target_per_group
                      ? (a->nll_mode == BNN_NLL_CLASSIFICATION ? (long)a->batch : (long)a->batch * a->classes) : 0;
   const double c0 = -0.91893853320467274178;
@@ -81,6 +84,109 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
   cst.reg_const = log(ns) - c0;
   cst.reg_inv2var = 1.0 / (2.0 * ns * ns);
   return BNN_OK;
+}
+
+// This thread's share of the NLL of rows [row0, row1) of sample s (networks.py:183-190): cross-entropy with
+// reduction='sum', or -sum log N(target; out, sigma).  Summed over the block by the caller.
+__device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, const float* lg, int ldc, int row0, int row1) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+    if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
+    const long long* tgt = reinterpret_cast<const long long*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
+    if (p.C <= 32) {                           // a thread per row
+      for (int b = row0 + (int)threadIdx.x; b < row1; b += blockDim.x) {
+        const float* row = lg + (size_t)b * ldc;
+        const long long tc = tgt[b];
+        float mx, se = 0.f;
+        if (ldc == 16 && p.C <= 16) {
+          // a row of the LDS tile [rows][16] held in registers: lane b starts at column b so that a wave's 64
+          // reads spread over all 32 banks (walking the same column put them on two); hardware exp2 / log2
+          float vr[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) vr[i] = row[(i + b) & 15];
+          mx = -3.0e38f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mx = (((i + b) & 15) < p.C) ? fmaxf(mx, vr[i]) : mx;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) se += (((i + b) & 15) < p.C) ? __expf(vr[i] - mx) : 0.f;
+          se = __logf(se);
+        } else if (p.C <= 16) {
+          // a row in global memory: all of its loads issued at once (a rolled loop waits for each in turn)
+          float vr[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) vr[i] = row[min(i, p.C - 1)];
+          mx = vr[0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) mx = i < p.C ? fmaxf(mx, vr[i]) : mx;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) se += i < p.C ? __expf(vr[i] - mx) : 0.f;
+          se = __logf(se);
+        } else {
+          mx = row[0];
+          for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
+          for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
+          se = logf(se);
+        }
+        const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
+        acc += (mx + se) - picked;
+      }
+    } else {                                   // a wave per row, lanes stride over the classes
+      const int nwv = blockDim.x >> 6;
+      for (int b = row0 + wave; b < row1; b += nwv) {
+        const float* row = lg + (size_t)b * ldc;
+        float mx = -3.0e38f;
+#pragma unroll 8
+        for (int cc = lane; cc < p.C; cc += 64) mx = fmaxf(mx, row[cc]);     // 8 loads in flight
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float se = 0.f;
+#pragma unroll 8
+        for (int cc = lane; cc < p.C; cc += 64) se += __expf(row[cc] - mx);
+        se = wave_sum(se);
+        if (lane == 0) {
+          const long long tc = tgt[b];
+          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
+          acc += (mx + logf(se)) - picked;
+        }
+      }
+    }
+  } else {
+    const float* tgt = reinterpret_cast<const float*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
+    if (p.C <= 8) {                            // a thread per row (the 1-output regression net)
+      for (int b = row0 + (int)threadIdx.x; b < row1; b += blockDim.x)
+        for (int cc = 0; cc < p.C; ++cc) {
+          const float d = tgt[(size_t)b * p.C + cc] - lg[(size_t)b * ldc + cc];
+          acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
+        }
+    } else {                                   // wide outputs: a wave per row, lanes stride over the outputs
+      // sum of squares in fp32 per lane (<= B*C/threads terms), the affine map applied once per lane
+      const int nwv = blockDim.x >> 6;
+      float d2 = 0.f;
+      int cnt = 0;
+      for (int b = row0 + wave; b < row1; b += nwv) {
+        const float* row = lg + (size_t)b * ldc;
+        const float* trow = tgt + (size_t)b * p.C;
+        if (((p.C | ldc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(trow)) & 15) == 0) {
+#pragma unroll 4
+          for (int cc = lane * 4; cc < p.C; cc += 256) {                    // 16-byte loads, 4 of each stream in flight
+            const float4 t4 = *reinterpret_cast<const float4*>(trow + cc), r4 = *reinterpret_cast<const float4*>(row + cc);
+            const float dx = t4.x - r4.x, dy = t4.y - r4.y, dz = t4.z - r4.z, dw = t4.w - r4.w;
+            d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, __builtin_fmaf(dz, dz, __builtin_fmaf(dw, dw, d2))));
+            cnt += 4;
+          }
+        } else {
+#pragma unroll 8
+          for (int cc = lane; cc < p.C; cc += 64) {                         // 8 loads of each stream in flight
+            const float d = trow[cc] - row[cc];
+            d2 = __builtin_fmaf(d, d, d2);
+            ++cnt;
+          }
+        }
+      }
+      acc = (float)((double)d2 * cst.reg_inv2var + (double)cnt * cst.reg_const);
+    }
+  }
+  return acc;
 }
 
 // ELBO scalars of sample s, valid in thread 0 on return.
@@ -122,104 +228,12 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     }
   }
   FIN_STAMP(12);
-  if (p.nll && lg) {
+  if (p.nll && p.nll_partial) {               // row blocks already reduced by nll_rows_kernel: add them up
     float acc = 0.f;
-    if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
-      const long long* tgt = reinterpret_cast<const long long*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
-      if (p.C <= 32) {                           // a thread per row
-        for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
-          const float* row = lg + (size_t)b * ldc;
-          const long long tc = tgt[b];
-          float mx, se = 0.f;
-          if (ldc == 16 && p.C <= 16) {
-            // a row of the LDS tile [rows][16] held in registers: lane b starts at column b so that a wave's 64
-            // reads spread over all 32 banks (walking the same column put them on two); hardware exp2 / log2
-            float vr[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vr[i] = row[(i + b) & 15];
-            mx = -3.0e38f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = (((i + b) & 15) < p.C) ? fmaxf(mx, vr[i]) : mx;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) se += (((i + b) & 15) < p.C) ? __expf(vr[i] - mx) : 0.f;
-            se = __logf(se);
-          } else if (p.C <= 16) {
-            // a row in global memory: all of its loads issued at once (a rolled loop waits for each in turn)
-            float vr[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vr[i] = row[min(i, p.C - 1)];
-            mx = vr[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = i < p.C ? fmaxf(mx, vr[i]) : mx;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) se += i < p.C ? __expf(vr[i] - mx) : 0.f;
-            se = __logf(se);
-          } else {
-            mx = row[0];
-            for (int cc = 1; cc < p.C; ++cc) mx = fmaxf(mx, row[cc]);
-            for (int cc = 0; cc < p.C; ++cc) se += expf(row[cc] - mx);
-            se = logf(se);
-          }
-          const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
-          acc += (mx + se) - picked;
-        }
-      } else {                                   // a wave per row, lanes stride over the classes
-        const int nwv = blockDim.x >> 6;
-        for (int b = wave; b < p.B; b += nwv) {
-          const float* row = lg + (size_t)b * ldc;
-          float mx = -3.0e38f;
-#pragma unroll 8
-          for (int cc = lane; cc < p.C; cc += 64) mx = fmaxf(mx, row[cc]);     // 8 loads in flight
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-          float se = 0.f;
-#pragma unroll 8
-          for (int cc = lane; cc < p.C; cc += 64) se += __expf(row[cc] - mx);
-          se = wave_sum(se);
-          if (lane == 0) {
-            const long long tc = tgt[b];
-            const float picked = (tc >= 0 && tc < p.C) ? row[tc] : __builtin_nanf("");   // bad label: NaN loss, loudly
-            acc += (mx + logf(se)) - picked;
-          }
-        }
-      }
-    } else {
-      const float* tgt = reinterpret_cast<const float*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
-      if (p.C <= 8) {                            // a thread per row (the 1-output regression net)
-        for (int b = threadIdx.x; b < p.B; b += blockDim.x)
-          for (int cc = 0; cc < p.C; ++cc) {
-            const float d = tgt[(size_t)b * p.C + cc] - lg[(size_t)b * ldc + cc];
-            acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
-          }
-      } else {                                   // wide outputs: a wave per row, lanes stride over the outputs
-        // sum of squares in fp32 per lane (<= B*C/threads terms), the affine map applied once per lane
-        const int nwv = blockDim.x >> 6;
-        float d2 = 0.f;
-        int cnt = 0;
-        for (int b = wave; b < p.B; b += nwv) {
-          const float* row = lg + (size_t)b * ldc;
-          const float* trow = tgt + (size_t)b * p.C;
-          if (((p.C | ldc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(trow)) & 15) == 0) {
-#pragma unroll 4
-            for (int cc = lane * 4; cc < p.C; cc += 256) {                    // 16-byte loads, 4 of each stream in flight
-              const float4 t4 = *reinterpret_cast<const float4*>(trow + cc), r4 = *reinterpret_cast<const float4*>(row + cc);
-              const float dx = t4.x - r4.x, dy = t4.y - r4.y, dz = t4.z - r4.z, dw = t4.w - r4.w;
-              d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, __builtin_fmaf(dz, dz, __builtin_fmaf(dw, dw, d2))));
-              cnt += 4;
-            }
-          } else {
-#pragma unroll 8
-            for (int cc = lane; cc < p.C; cc += 64) {                         // 8 loads of each stream in flight
-              const float d = trow[cc] - row[cc];
-              d2 = __builtin_fmaf(d, d, d2);
-              ++cnt;
-            }
-          }
-        }
-        acc = (float)((double)d2 * cst.reg_inv2var + (double)cnt * cst.reg_const);
-      }
-    }
+    for (int t = threadIdx.x; t < p.nll_rb; t += blockDim.x) acc += p.nll_partial[(size_t)s * p.nll_rb + t];
     v[NV - 1] = acc;
+  } else if (p.nll && lg) {
+    v[NV - 1] = fin_nll(p, cst, s, lg, ldc, 0, p.B);
   }
   FIN_STAMP(13);
   const int nv = 3 * p.n_layers;

@@ -157,6 +157,20 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const FinK p, const 
   }
 }
 
+// NLL of wide outputs, split by rows: one block per (row block, sample) sums the NLL of its rows into
+// partial[s][rb]; elbo_finalize_kernel then adds the row blocks up instead of walking B x C logits through ONE CU per
+// sample (4096 outputs, batch 128, 4 samples: 101 us of a 485 us evaluation, 40 GB/s per CU).
+__global__ __launch_bounds__(256) void nll_rows_kernel(const FinK p, const FinC cst, int rows_per_block, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int rb = blockIdx.x, s = blockIdx.y, nrb = gridDim.x;
+  const int row0 = rb * rows_per_block, row1 = min(p.B, row0 + rows_per_block);
+  const float acc = fin_nll(p, cst, s, p.logits + (size_t)s * p.B * p.C, p.C, row0, row1);
+  const float w = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)s * nrb + rb] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // Sums of the per-sample scalars over the local samples: the 4-vector a sharded job all-reduces (one per minibatch
 // of `g` samples).  One evaluation: index order per thread and a fixed tree across threads; several minibatches: a
 // thread per minibatch, sample order.
@@ -505,6 +519,8 @@ extern "C" int bnn_mc_softmax_mean(const float* logits, int32_t n_samples, int32
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 
+extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);   // bbb_linear.hip
+
 extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   FinK k;
   FinC cst;
@@ -514,6 +530,20 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
   // one sample, or a few with small logits and no ticket word to fold them in parallel: one block walks them all
   // and writes the sums; otherwise a block per sample, the sums folded by the last arriver (ticket) or by a
   // follow-up launch
+  // wide outputs: the rows' NLL first, spread over the chip (needs the caller's scratch for the row-block sums)
+  if (a->nll && a->classes > 32 && (long)a->batch * a->classes >= 32768 && a->scratch &&
+      a->scratch_bytes >= bnn_bbb_final_scratch_bytes(a->n_samples) && !(reinterpret_cast<uintptr_t>(a->scratch) & 15)) {
+    const int rpb = 4;                                        // a wave per row
+    const int nrb = (a->batch + rpb - 1) / rpb;
+    if (nrb <= 32) {                                          // the scratch holds 32 floats per sample in this region
+      float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a->scratch) + (((size_t)a->n_samples * 4 + 255) / 256) * 256);
+      hipLaunchKernelGGL(nll_rows_kernel, dim3((unsigned)nrb, (unsigned)a->n_samples), dim3(256), 0, stream, k, cst, rpb, partial);
+      const hipError_t e0 = hipGetLastError();
+      if (e0 != hipSuccess) return (int)e0;
+      k.nll_partial = partial;
+      k.nll_rb = nrb;
+    }
+  }
   const bool small = (long)a->n_samples * a->batch * a->classes <= 65536;
   const bool ticketed = a->n_samples > 1 && a->n_samples <= 64 && a->ticket != nullptr;
   const int single = a->n_samples == 1 || (a->n_samples <= 16 && small && !ticketed);

@@ -276,7 +276,7 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     flops = n * (4 if lr else 2) * batch * dims[1] * dims[1]
     form = {1: "tile", 2: "gemm", 3: "gemm_kslice"}[plan["form"]]
     kname = {("bbb", "tile"): "K1a bbb_fwd_kernel", ("bbb", "gemm"): "K1b bbb_fwd_gemm_kernel",
-             ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel (K-sliced) + ks_reduce_kernel",
+             ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
              ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel"}[("lr" if lr else "bbb", form)]
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_key": f"{'lr' if lr else 'bbb'}_{dims[1]}_n{n}_b{batch}_{math_name}",

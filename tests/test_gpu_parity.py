@@ -734,7 +734,7 @@ def test_eval_prepare_equals_the_separate_passes(dev):
     assert nosq is None and torch.equal(only16, ops.cast_bf16(x[:, :, :36].contiguous()))
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 4096), (2, 37, 37), (20, 16, 100), (1, 128, 1)])
+@pytest.mark.parametrize("shape", [(3, 128, 4096), (2, 37, 37), (20, 16, 100), (1, 128, 1), (4, 100, 1000)])
 def test_regression_nll_wide_outputs(dev, shape):
     """K4's Gaussian NLL (networks.py:185-187) for output widths the 1-output regression net never
     reaches (the 4096-wide stack of BASELINE configs[4]): wave-per-row / 16-byte path and the
@@ -748,6 +748,17 @@ def test_regression_nll_wide_outputs(dev, shape):
                             logits=logits, target=target, mode="regression", nll_sigma=sig)
     ref = torch.stack([-torch.distributions.Normal(logits[s].double(), sig).log_prob(target.double()).sum() for s in range(S)])
     close(out["nll"], ref.cpu().numpy(), rtol=2e-6)
+    # with a scratch the rows' NLL is reduced by row blocks spread over the chip first (wide outputs only)
+    out2 = ops.elbo_finalize(workspaces=[], layer_in=[], layer_out=[], local_reparam=False, prior=ops.PriorSpec(), n_samples=S,
+                             logits=logits, target=target, mode="regression", nll_sigma=sig, scratch=ops.final_scratch(S, dev))
+    close(out2["nll"], ref.cpu().numpy(), rtol=2e-6)
+    if Cc >= 37:
+        labels = torch.randint(0, Cc, (B,), generator=gen).to(dev)
+        refc = torch.stack([torch.nn.functional.cross_entropy(logits[s].double(), labels, reduction="sum") for s in range(S)])
+        for scratch in (None, ops.final_scratch(S, dev)):
+            oc = ops.elbo_finalize(workspaces=[], layer_in=[], layer_out=[], local_reparam=False, prior=ops.PriorSpec(), n_samples=S,
+                                   logits=logits, target=labels, mode="classification", scratch=scratch)
+            close(oc["nll"], refc.cpu().numpy(), rtol=2e-6)
 
 
 def test_misaligned_operands_are_rejected_or_handled(dev):
