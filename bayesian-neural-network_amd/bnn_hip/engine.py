@@ -232,7 +232,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 if i in hoisted and h.dtype == torch.bfloat16:
                     kw["w_sigma"] = hoisted[i]                 # consumed by the block-GEMM forms only
                 if h.dtype == torch.bfloat16 and use_split(sp.in_out[0], sp.in_out[1], n_local, h.shape[-2]):
-                    kw["split_scratch"] = ops.split_scratch(n_local, h.shape[-2], sp.in_out[1], h.device)
+                    kw["split_scratch"] = ops.split_scratch_cached(n_local, h.shape[-2], sp.in_out[1], h.device)
                 if last and fin_kw is not None and want_stats:
                     # last layer + finalize in one launch (when the layer is a single feature tile)
                     if i in presampled:

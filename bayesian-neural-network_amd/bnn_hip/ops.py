@@ -97,6 +97,23 @@ def split_scratch(n_samples: int, batch: int, out_features: int, device) -> torc
     return t
 
 
+_split_cache = {}
+
+
+def split_scratch_cached(n_samples: int, batch: int, out_features: int, device) -> torch.Tensor:
+    """The eager path's scratch: one per (device, current stream, shape), allocated and zeroed once -- launches on one
+    stream run one after the other and each leaves the counters at zero.  (Captured evaluators own theirs.)"""
+    if torch.cuda.is_current_stream_capturing():
+        return split_scratch(n_samples, batch, out_features, device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, n_samples, batch, out_features)
+    t = _split_cache.get(key)
+    if t is None:
+        if len(_split_cache) >= 16:
+            _split_cache.clear()
+        t = _split_cache[key] = split_scratch(n_samples, batch, out_features, device)
+    return t
+
+
 def final_scratch(n_samples: int, device) -> torch.Tensor:
     """Zeroed scratch for the fused last layer (K-range slices per sample)."""
     nbytes = L.load().bnn_bbb_final_scratch_bytes(n_samples)
