@@ -25,7 +25,7 @@ EXPORTS = (
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare", "bnn_bbb_chain_fwd",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
 )
 
@@ -171,13 +171,6 @@ class Plan(C.Structure):
 
 
 PREPARE_MAX = 8
-CHAIN_MAX_LAYERS = 4
-
-
-class BbbChainArgs(C.Structure):
-    _fields_ = [("struct_bytes", C.c_uint32), ("n_layers", C.c_int32), ("layers", C.c_void_p * CHAIN_MAX_LAYERS),
-                ("last_sampler", C.c_void_p), ("fin", C.c_void_p), ("counters", C.c_void_p)]
-
 
 
 class PrepareArgs(C.Structure):
@@ -275,8 +268,6 @@ def load():
                                       C.c_int32, C.c_void_p]
     lib.bnn_softplus.restype = C.c_int
     lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-    lib.bnn_bbb_chain_fwd.restype = C.c_int
-    lib.bnn_bbb_chain_fwd.argtypes = [C.POINTER(BbbChainArgs), C.c_void_p]
     lib.bnn_eval_prepare.restype = C.c_int
     lib.bnn_eval_prepare.argtypes = [C.POINTER(PrepareArgs), C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int

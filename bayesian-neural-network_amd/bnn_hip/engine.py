@@ -39,9 +39,6 @@ FUSED_ELBO_NODE = True
 # layer before it (a sampling job riding on that launch, bnn_bbb_fwd_args.rider) and run the output layer + finalize in
 # the row-split matmul-only form (K1r): the tail of the dependent chain is then ~5 us instead of ~13
 FINAL_ROWS_MAX_SAMPLES = 16
-# ... and evaluations of at most this many pairs run as ONE launch (bnn_bbb_chain_fwd): the layers are block ranges of one
-# grid, a hidden layer's blocks draw their weights while the layer below is still running and wait for it in the launch
-CHAIN_MAX_SAMPLES = 3
 # (Letting the FIRST layer's launch carry the sampling of every later layer -- hidden layers matmul-only too -- was
 # built and measured slower at every size: one evaluation 36.8 against 35.4 us at one sample, 58.8 against 43.6 at three:
 # the rider blocks inherit the layer's 768-thread / 98 KB-LDS block shape, one per CU, and queue behind the layer's own.
@@ -501,9 +498,6 @@ class GraphedElbo:
                 self.w_pre[i] = torch.empty((S, n_i, k_i), dtype=torch.bfloat16, device=dev)
                 self.b_pre[i] = torch.empty((S, n_i), dtype=torch.float32, device=dev)
                 self.ws[i] = ops.sample_workspace(S, k_i, n_i, dev)
-        self.chain = self.rows and self.pre_from == len(self.specs) - 2 and 0 < S <= CHAIN_MAX_SAMPLES and \
-            not any(w is not None for w in self.wsigma) and not any(sp is not None for sp in self.split) and not any(self.lib)
-        self.chain_counters = torch.zeros(16, dtype=torch.int32, device=dev) if self.chain else None
         self.graph = None
         if capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
@@ -538,8 +532,6 @@ class GraphedElbo:
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
                       sample_counter_inc=self.total_samples, out=self.out, sums=self._sums,
                       ticket=self.ticket, scratch=self.scratch, group_samples=self.group)
-        if self.chain and self._enqueue_chain(h, fin_kw, grp):
-            return
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
@@ -584,36 +576,6 @@ class GraphedElbo:
             h = self.bufs[i]
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
-
-    def _enqueue_chain(self, h, fin_kw, grp) -> bool:
-        """The whole evaluation as one launch (ops.bbb_chain_fwd); False if the library declines the shapes."""
-        math_mode = state.math
-        last = len(self.specs) - 1
-        calls = []
-        for i, sp in enumerate(self.specs):
-            if i == last:
-                calls.append(((h, None, None, None, None),
-                              dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
-                                   y_dtype=self.bufs[i].dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=self.bufs[i],
-                                   w_sampled=self.w_pre[i], b_sampled=self.b_pre[i])))
-                break
-            p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
-            calls.append(((h,) + p,
-                          dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
-                               y_dtype=self.bufs[i].dtype, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
-                               sample_offset=self.lo, sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i],
-                               want_stats=True, form=state.form, **grp)))
-            h = self.bufs[i]
-        q = self.specs[last]
-        sampler = ops.build_sample_job(
-            [dict(w_mu=q.m.weight_mu.detach(), w_rho=q.m.weight_rho.detach(), b_mu=q.m.bias_mu.detach(),
-                  b_rho=q.m.bias_rho.detach(), prior=q.m._prior_spec, layer_id=q.layer_id, workspace=self.ws[last],
-                  w_out=self.w_pre[last], b_out=self.b_pre[last])],
-            n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
-        ok = ops.bbb_chain_fwd(calls, sampler, dict(workspaces=self.ws, **fin_kw), self.chain_counters)
-        if not ok:
-            self.chain = False
-        return ok
 
     def _eager(self):
         for _ in range(self.per_replay):

@@ -522,31 +522,6 @@ def bbb_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
     return res, out
 
 
-def bbb_chain_fwd(layer_calls, sampler, fin_kw: dict, counters: torch.Tensor) -> bool:
-    """bnn_bbb_chain_fwd: a whole few-sample BBB evaluation in one launch.  `layer_calls` = [(args tuple, kwargs dict)]
-    as for bbb_linear_fwd, the last one as for the pre-sampled bbb_final_fwd; `sampler` = build_sample_job(...) of the
-    output layer; `fin_kw` as for bbb_final_fwd (its `workspaces` list complete, `logits` taken from the last layer).
-    Returns False when the library declines the shapes (nothing was launched: issue the separate launches)."""
-    lib = L.load()
-    built = [_bbb_build(*args, **kw) for args, kw in layer_calls]
-    fin_kw = dict(fin_kw)
-    fin_kw["logits"] = built[-1][1]["y"]
-    f, _out, keep_f = _fin_build(**fin_kw)
-    a = L.BbbChainArgs()
-    a.struct_bytes = C.sizeof(L.BbbChainArgs)
-    a.n_layers = len(built)
-    for i, (la, _res, _keep) in enumerate(built):
-        a.layers[i] = C.addressof(la)
-    a.last_sampler = C.addressof(sampler[0])
-    a.fin = C.addressof(f)
-    a.counters = counters.data_ptr()
-    rc = lib.bnn_bbb_chain_fwd(C.byref(a), _stream())
-    if rc == -2:                                             # BNN_ERR_SHAPE: not this form
-        return False
-    L.check(rc, "bnn_bbb_chain_fwd")
-    return True
-
-
 def philox_normal(seed: int, tensor_id: int, sample_offset: int, n_samples: int, rows: int, cols: int,
                   device) -> torch.Tensor:
     """The on-chip epsilon stream, materialised: float32[n_samples, rows, cols]."""

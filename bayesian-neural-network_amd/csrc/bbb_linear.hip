@@ -58,11 +58,6 @@ struct BbbK {
   float4* ks_part;  // GEMM form, ksl > 1: fp32 partial tiles [unit][ksl][wave][batch tile][lane] (bias in slice 0)
   uint32_t* ks_ticket;  // GEMM form, ksl > 1: [unit] arrival counters of a unit's slice blocks, zero between launches
   Xcd2D xc;             // GEMM form: work order (feature group x (sample, batch block) x K slice), see bnn_device.h
-  int blk0;             // first block of this layer's work list in the grid (0 unless the launch holds several lists)
-  uint32_t* done;       // chain launch: counter this layer's blocks add to when their outputs are stored
-  const uint32_t* wait; // chain launch: counter of the layer below ...
-  uint32_t wait_n;      // ... and the count that means "all of it is stored"
-  uint32_t* err;        // chain launch: word that receives a code if a bounded wait gives up
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
   const float* b_pre;   // PRE only: sampled biases [S, N]
@@ -200,7 +195,7 @@ __device__ __forceinline__ float sample_bias(const BbbK& p, float bmu, float brh
 
 // Epilogue: sum the NW slabs (and the R k-range classes of a feature), + bias, ReLU,
 // convert, store 4 consecutive features per item.
-template <int R, int MT = 8, bool SC1 = false>
+template <int R, int MT = 8>
 __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __restrict__ slab,
                                                const float* __restrict__ lds_bias, int nw, int mtiles, int nt, int s,
                                                int m0, float* __restrict__ lds_out = nullptr,
@@ -247,8 +242,7 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
         bf16x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-        if (SC1) st_sc1_b64(yp, __builtin_bit_cast(uint2, o));      // handed to a later phase of this launch
-        else *reinterpret_cast<bf16x4*>(yp) = o;
+        *reinterpret_cast<bf16x4*>(yp) = o;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -257,8 +251,7 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
     } else {
       float* yp = reinterpret_cast<float*>(p.y) + yoff;
       if (vec_ok) {
-        if (SC1) st_sc1_b128(yp, make_float4(v[0], v[1], v[2], v[3]));
-        else *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -294,7 +287,7 @@ struct FinPack {
 // MT: 16-row batch tiles per block (8 = 128 rows).  The matmul-only forms use 2: without generator work a block's
 // cost is the x it pulls through its CU's L1 (all of K for its rows), so four times the blocks each ingest a quarter;
 // with sampling fused every batch block would redo the tile's sampling, hence 8 there.
-template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8, bool CHAIN = false>
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8>
 __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -305,7 +298,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
   int item;
   const int KS = FINAL ? fp->ks : 1;                          // K-range slices per sample (FINAL only)
-  if (!xcd_work_item(ntiles * p.S * mbs * KS, item, p.blk0)) return false;   // block-uniform
+  if (!xcd_work_item(ntiles * p.S * mbs * KS, item)) return false;   // block-uniform
   const int ks = item % KS;
   item /= KS;
   const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
@@ -335,10 +328,8 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-  if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0) {
-    if (CHAIN) st_sc1_b128(p.ws, make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f));
-    else p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
-  }
+  if (do_stats && item == 0 && ks == 0 && threadIdx.x == 0)
+    p.ws[0] = make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f);
 
   // (mu, rho) of this lane for super-step t: prefetched one step ahead.
   float mu_n[8], rho_n[8];
@@ -583,19 +574,11 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       own1 += lds_red[wv * 3 + 1];
       own2 += lds_red[wv * 3 + 2];
     }
-    if (KS == 1) {
-      if (CHAIN) st_sc1_b128(p.ws + 1 + (size_t)s * ntiles + nt, make_float4(own0, own1, own2, 0.f));
-      else p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
-    }
+    if (KS == 1) p.ws[1 + (size_t)s * ntiles + nt] = make_float4(own0, own1, own2, 0.f);
   }
   float* fin_lg = lds_red + 3 * nw;               // FINAL only: [128][16] final logits + reduce scratch
   if (!FINAL || KS == 1) {
-    epilogue_store<R, MT, CHAIN>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
-  }
-  if (CHAIN) {                                     // this block's outputs and statistics are stored: tell the next phase
-    phase_signal(p.done);
-    BNN_STAMP_RT(12);
-    return true;
+    epilogue_store<R, MT>(p, slab, lds_bias, nw, mtiles, nt, s, m0, FINAL ? fin_lg : nullptr);
   }
   BNN_STAMP(6);
   BNN_STAMP_RT(9);
@@ -699,189 +682,6 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   return true;
 }
 
-// K1h  a HIDDEN layer inside a chain launch (bnn_bbb_chain_fwd): K1a's decomposition and arithmetic -- the same
-// tiles, the same k-steps per wave, the same order of every sum, so the outputs and statistics are those of
-// bbb_fwd_kernel bit for bit -- with the phases re-ordered around the one thing the layer has to wait for.  Sampling
-// depends on no activation: the block first draws its tile's weights (all of a wave's k-steps: at most kChainSPW of 8
-// weights per lane, kept as bf16 fragments) and folds the statistics, THEN waits until the layer below has stored
-// its output (phase_wait with an L1-invalidating acquire), and only then streams x through the
-// matrix core.  What the dependent chain sees of this layer is x ingest + MFMAs + slab reduce + epilogue; parameter
-// fetch and generator work ran beside the layer below.  bf16 math, bf16 x, aligned shapes.
-constexpr int kChainSPW = 4;      // k-steps per wave a hidden layer may have (its weights wait in registers: 4 VGPRs a step)
-template <int R>
-__device__ __forceinline__ bool bbb_chain_hidden_body(const BbbK& p) {
-  constexpr int F = 16 / R, MT = 8;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int c = r / F, f = r % F;
-  const int K = p.K, N = p.N, B = p.B;
-  const int ntiles = (N + F - 1) / F, mbs = (B + 16 * MT - 1) / (16 * MT);
-  int item;
-  if (!xcd_work_item(ntiles * p.S * mbs, item, p.blk0)) return false;   // block-uniform
-  const int nt = item / (p.S * mbs), s = (item / mbs) % p.S, mb = item % mbs;
-  const int n = nt * F + f;
-  const bool n_ok = n < N;
-  const int nc = min(n, N - 1);
-  const int m0 = mb * (16 * MT);
-  const int mtiles = min(MT, (B - m0 + 15) >> 4);
-  const int ssteps = (K + 32 * R - 1) / (32 * R);
-  const uint32_t gs = global_sample(p, s);
-  const bool do_stats = p.want_stats && mb == 0;
-  const bool do_ls = do_stats && s == 0;
-  const int gpr = (K + 3) >> 2;
-  const uint32_t wid = p.layer_id * 4u;
-  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
-  float* lds_bias = lds + (size_t)nw * MT * 64 * 4;
-  float* lds_red = lds_bias + 16;
-  f32x4* slab = reinterpret_cast<f32x4*>(lds);
-
-  BNN_STAMP_RT(8);
-  if (do_stats && item == 0 && threadIdx.x == 0) st_sc1_b128(p.ws, make_float4(__int_as_float(ntiles), 0.f, 0.f, 0.f));
-
-  // ---- phase A: this wave's weights (k-steps wave, wave + nw, ...) and their statistics
-  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
-  bf16x8 wa[kChainSPW];
-  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (wave == nw - 1 && lane < F && n_ok) {
-    bmu_pre = p.b_mu[n];
-    brho_pre = p.b_rho[n];
-    beps_pre = bias_eps(p, n, s, gs, false);
-  }
-#pragma unroll
-  for (int sp = 0; sp < kChainSPW; sp += 2) {             // two k-steps at a time: their parameter loads first
-    float4 mr[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int t = wave + (sp + u) * nw;
-      const int k = (t * R + c) * 32 + q * 8;
-      const size_t woff = (size_t)nc * K + min(max(k, 0), K - 8);
-      if (t < ssteps) {
-        mr[u][0] = *reinterpret_cast<const float4*>(p.w_mu + woff);
-        mr[u][1] = *reinterpret_cast<const float4*>(p.w_mu + woff + 4);
-        mr[u][2] = *reinterpret_cast<const float4*>(p.w_rho + woff);
-        mr[u][3] = *reinterpret_cast<const float4*>(p.w_rho + woff + 4);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int st = sp + u;
-      const int t = wave + st * nw;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wa[st][j] = (__bf16)0.f;
-      if (t < ssteps) {                                    // wave-uniform
-        const int k = (t * R + c) * 32 + q * 8;
-        const int valid = n_ok ? min(8, K - k) : 0;        // 8 or <= 0
-        const float mu[8] = {mr[u][0].x, mr[u][0].y, mr[u][0].z, mr[u][0].w, mr[u][1].x, mr[u][1].y, mr[u][1].z, mr[u][1].w};
-        float sg[8] = {mr[u][2].x, mr[u][2].y, mr[u][2].z, mr[u][2].w, mr[u][3].x, mr[u][3].y, mr[u][3].z, mr[u][3].w};
-        float e[8], w[8];
-        const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-        philox_normal4(g, gs, wid, p.k0, p.k1, e);
-        philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
-        float e2 = 0.f, a = 0.f, ls = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sg[j] = softplus(sg[j]);
-          w[j] = __builtin_fmaf(sg[j], e[j], mu[j]);
-          e2 = __builtin_fmaf(e[j], e[j], e2);
-        }
-        if (do_stats) {
-          if (p.prior_kind == BNN_PRIOR_GAUSS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a = add_log(a, mix_p(p, w[j]));
-          }
-          if (do_ls) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ls = add_log(ls, sg[j]);
-          }
-          const bool lane_ok = valid > 0;
-          s_e2 += lane_ok ? e2 : 0.f;
-          s_a += lane_ok ? a : 0.f;
-          s_ls += lane_ok ? ls : 0.f;
-        }
-        if (valid > 0) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) wa[st][j] = (__bf16)w[j];
-        }
-      }
-    }
-  }
-  // bias of the tile and the block's statistics: nothing of it needs the layer below
-  if (wave == nw - 1 && lane < 16) {
-    float b = 0.f;
-    if (lane < F && n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
-    lds_bias[lane] = b;
-  }
-  if (do_stats) {
-    const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
-    if (lane == 0) {
-      lds_red[wave * 3 + 0] = a;
-      lds_red[wave * 3 + 1] = b;
-      lds_red[wave * 3 + 2] = cc;
-    }
-  }
-
-  // ---- phase B: the layer below has stored all of its output
-  BNN_STAMP_RT(9);
-  phase_wait<true>(p.wait, p.wait_n, p.err);
-  BNN_STAMP_RT(10);
-
-  // ---- phase C: x . w^T for this wave's k-steps (plain loads behind the acquire: L1 / L2 serve the re-reads)
-  f32x4 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 wz;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wz[j] = (__bf16)0.f;
-#pragma unroll
-  for (int st = 0; st < kChainSPW; ++st) {
-    const int t = wave + st * nw;
-    if (t < ssteps) {                                    // wave-uniform
-#pragma unroll
-      for (int mm = 0; mm < MT; mm += 16 / R) {          // sixteen fragments per round of sc1 loads (R = 2: a whole k-step)
-        float4 xr[16];
-        const void* px[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int m = min(mm + u / R, MT - 1), cc = u % R;
-          const int row = m0 + m * 16 + r;
-          const int xk = (t * R + cc) * 32 + q * 8;
-          px[u] = xs + (size_t)min(row, B - 1) * K + min(xk, K - 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) xr[u] = *reinterpret_cast<const float4*>(px[u]);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int m = mm + u / R, cc = u % R;
-          if (m < MT)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((R == 1 || c == cc) ? wa[st] : wz, __builtin_bit_cast(bf16x8, xr[u]), acc[m], 0, 0, 0);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-    if (m < mtiles) slab[(wave * MT + m) * 64 + lane] = acc[m];
-  __syncthreads();
-  if (do_stats && threadIdx.x == 0) {
-    float own0 = 0.f, own1 = 0.f, own2 = 0.f;
-    for (int wv = 0; wv < nw; ++wv) {
-      own0 += lds_red[wv * 3 + 0];
-      own1 += lds_red[wv * 3 + 1];
-      own2 += lds_red[wv * 3 + 2];
-    }
-    st_sc1_b128(p.ws + 1 + (size_t)s * ntiles + nt, make_float4(own0, own1, own2, 0.f));
-  }
-  BNN_STAMP_RT(11);
-  epilogue_store<R, MT, true>(p, slab, lds_bias, nw, mtiles, nt, s, m0);
-  phase_signal(p.done);
-  BNN_STAMP_RT(12);
-  return true;
-}
-
 template <int MATH, int XDT, int R, bool ALIGNED>
 __global__ __launch_bounds__(768) void bbb_fwd_kernel(const BbbK p) {
   bbb_fwd_body<MATH, XDT, R, ALIGNED, false>(p, nullptr);
@@ -924,51 +724,23 @@ struct FinRows {
   float* parts;         // [S][16]: 0..7 the row blocks' NLL, 8 / 9 log p (KL) / log q
 };
 
-// CHAIN: the block belongs to a chain launch (bnn_bbb_chain_fwd): `blk` is its index among the rows blocks; x, the
-// sampled weights and every statistics entry were stored by earlier phases of the same launch and are read with sc1
-// loads after the phase waits.  Only the first 256 threads of the block take part.
-struct ChainWait {
-  const uint32_t* layer_done;   // counter of the last hidden layer, and its final value
-  uint32_t layer_n;
-  const uint32_t* rider_done;   // counter of the sampling job that draws this layer's weights
-  uint32_t rider_n;
-  uint32_t* err;
-  uint32_t* reset;              // counters the launch's last block zeroes again (n_reset words)
-  int n_reset;
-#ifdef BNN_STAMPS
-  unsigned long long* dbg;
-#endif
-};
-#ifdef BNN_STAMPS
-#define CW_STAMP_RT(i) do { if (CHAIN && cw->dbg && threadIdx.x == 0) cw->dbg[((size_t)blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CW_STAMP_RT(i)
-#endif
-template <bool CHAIN>
-__device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinPack& fp, int blk, const ChainWait* cw) {
+__global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, const FinPack fp) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4][64];
   __shared__ float lg[16][17];
   __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
   const FinK& fk = fp.k;
   const int RB = (p.B + 15) >> 4;
-  const int s = blk / (RB + 1), rb = blk - s * (RB + 1);
+  const int s = (int)blockIdx.x / (RB + 1), rb = (int)blockIdx.x - s * (RB + 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pub0 = 0.f, pub1 = 0.f;
   int slot = rb;                                            // where thread 0 publishes
-  CW_STAMP_RT(8);
-  if (CHAIN) {
-    phase_wait(cw->rider_done, cw->rider_n, cw->err);       // this layer's weights, biases and statistics are stored
-    phase_wait(cw->layer_done, cw->layer_n, cw->err);       // ... and the layer below's output and statistics
-  }
-  CW_STAMP_RT(10);
   if (rb == RB) {
     // ---- statistics block: every layer's partial sums of sample s (no logits: nll stays 0)
     int T[8];
 #pragma unroll
-    for (int l = 0; l < 8; ++l)
-      T[l] = (l < fk.n_layers) ? __float_as_int(CHAIN ? ld_sc1_b128(fk.ws[l]).x : reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
+    for (int l = 0; l < 8; ++l) T[l] = (l < fk.n_layers) ? __float_as_int(reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
     float a = 0.f, b = 0.f, nll = 0.f;
-    fin_sample(fk, fp.c, s, T, nullptr, 0, -1, 0.f, 0.f, 0.f, part, a, b, nll, nullptr, 256);   // (a chain launch's blocks are wider)
+    fin_sample(fk, fp.c, s, T, nullptr, 0, -1, 0.f, 0.f, 0.f, part, a, b, nll);
     pub0 = a;
     pub1 = b;
     slot = 8;
@@ -980,28 +752,8 @@ __device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinP
     const __bf16* wr = p.w + ((size_t)s * N + min(r, N - 1)) * K;
     const int ksteps = (K + 31) >> 5;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (CHAIN) {
-      for (int base = wave; base < ksteps; base += 4 * 8) {  // rounds of 8 k-steps: 8 x and 8 w fragments, one round trip
-        float4 xw[16];
-        const void* pp[16];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int kk = min((base + 4 * u) * 32 + q * 8, K - 8);
-          pp[u] = xr + kk;
-          pp[8 + u] = wr + kk;
-        }
-        ld_sc1_b128x16(pp, xw);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = (base + 4 * u) * 32 + q * 8;
-          const bool ok = (base + 4 * u) < ksteps && k < K && r < N;
-          const float4 wz = ok ? xw[8 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wz), __builtin_bit_cast(bf16x8, xw[u]), acc, 0, 0, 0);
-        }
-      }
-    }
     constexpr int U = 10;                                   // k-steps in flight per wave: 38 steps of the 1200-wide layer = one round
-    for (int base = wave; base < (CHAIN ? 0 : ksteps); base += 4 * U) {
+    for (int base = wave; base < ksteps; base += 4 * U) {
       float4 xa[U], wa[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1029,7 +781,7 @@ __device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinP
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int n = q * 4 + i;
-        float o = v[i] + (n < N ? (CHAIN ? ld_sc1_f32(p.b + (size_t)s * N + n) : p.b[(size_t)s * N + n]) : 0.f);
+        float o = v[i] + (n < N ? p.b[(size_t)s * N + n] : 0.f);
         if (p.relu) o = fmaxf(o, 0.f);
         v[i] = o;
         lg[r][n] = o;
@@ -1071,7 +823,6 @@ __device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinP
       pub0 = wave_sum(acc_n);
     }
   }
-  CW_STAMP_RT(11);
   if (threadIdx.x != 0) return;
   float* mine = p.parts + (size_t)s * 16;
   __hip_atomic_store(mine + slot, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1094,8 +845,6 @@ __device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinP
       fp.sums[0] = a; fp.sums[1] = b; fp.sums[2] = nll; fp.sums[3] = 1.f;
     }
     if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
-    if (CHAIN)
-      for (int i = 0; i < cw->n_reset; ++i) __hip_atomic_store(cw->reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   // ---- samples meet: the sample whose ticket is last folds the 4-vector(s) and advances the Philox counter
@@ -1105,60 +854,6 @@ __device__ __forceinline__ void bbb_final_rows_body(const FinRows& p, const FinP
   if (fp.sums) fin_fold_sums(fk, fp.sums);
   __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
-  if (CHAIN)
-    for (int i = 0; i < cw->n_reset; ++i) __hip_atomic_store(cw->reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, const FinPack fp) {
-  bbb_final_rows_body<false>(p, fp, (int)blockIdx.x, nullptr);
-}
-
-
-// K1x  a whole few-sample BBB evaluation as ONE grid (bnn_bbb_chain_fwd).  Block ranges, in dispatch order:
-//   [layer 0: K1a] [sampling job of the output layer's weights] [hidden layer 1: K1h] ... [output layer: K1r rows + stats]
-// A block waits only for blocks with SMALLER indices (the layer below, the sampling job), which were dispatched before
-// it and wait for nobody further up: every wait ends.  (Dispatch order is an observed property, not an architectural
-// guarantee: the waits are bounded and trap instead of hanging.)
-struct ChainK {
-  BbbK first;                 // layer 0
-  BbbK hid[2];                // hidden layers above it
-  SampleK sk;
-  FinRows fr;
-  FinPack fp;
-  ChainWait cw;
-  int n_hid, xdt0, R0, Rh[2];   // (dtype and classes select the kernel instantiation)
-  int rider0, hid0[2], rows0; // first block of each range (multiples of 8)
-  uint32_t* rider_done;
-};
-
-static_assert(sizeof(ChainK) <= 4096, "kernel arguments are limited to 4 KiB");
-// One instantiation per (first layer's x dtype, its k-range classes, the hidden layers' k-range classes): the union of
-// all variants in one kernel ran out of registers (90 spilled VGPRs).
-template <int XDT0, int R0, int RH>
-__global__ __launch_bounds__(768) void bbb_chain_kernel(const ChainK c) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int b = (int)blockIdx.x;
-  if (b < c.rider0) {                                       // block-uniform branches throughout
-    bbb_fwd_body<BNN_MATH_BF16, XDT0, R0, true, false, false, false, 8, true>(c.first, nullptr);
-    return;
-  }
-  if (b < c.hid0[0]) {
-    if (b - c.rider0 < (int)c.cw.rider_n) {
-      sample_block<true>(c.sk, b - c.rider0, lds);
-      phase_signal(c.rider_done);
-    }
-    return;
-  }
-  if (c.n_hid > 0 && b < (c.n_hid > 1 ? c.hid0[1] : c.rows0)) {
-    bbb_chain_hidden_body<RH>(c.hid[0]);
-    return;
-  }
-  if (c.n_hid > 1 && b < c.rows0) {
-    bbb_chain_hidden_body<RH>(c.hid[1]);
-    return;
-  }
-  if (threadIdx.x >= 256) return;                           // the row-split output layer works in 256-thread blocks
-  bbb_final_rows_body<true>(c.fr, c.fp, b - c.rows0, &c.cw);
 }
 
 // matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
@@ -1656,7 +1351,6 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
 // applies (K % 8 == 0, aligned bases).
 static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.mask = nullptr; k.mask_sstride = 0;      // input-gradient form only
-  k.blk0 = 0; k.done = nullptr; k.wait = nullptr; k.wait_n = 0u; k.err = nullptr;   // chain launches only
   k.w_pre = nullptr; k.b_pre = nullptr;      // set below for the matmul-only form
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
@@ -1995,148 +1689,6 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   return tail_kernel ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
-}
-
-// A whole few-sample BBB evaluation in one launch (see bbb_chain_kernel).  BNN_ERR_SHAPE when the arguments do not
-// fit this form: the caller then issues the layers as separate launches (same results bit for bit).
-extern "C" int bnn_bbb_chain_fwd(const bnn_bbb_chain_args* a, void* stream_) {
-  if (!a) return BNN_ERR_NULL;
-  if (a->struct_bytes != sizeof(bnn_bbb_chain_args)) return BNN_ERR_ABI;
-  const int nl = a->n_layers;
-  if (nl < 2 || nl > 4) return BNN_ERR_SHAPE;
-  if (!a->last_sampler || !a->fin || !a->counters) return BNN_ERR_NULL;
-  for (int i = 0; i < nl; ++i)
-    if (!a->layers[i]) return BNN_ERR_NULL;
-  ChainK c{};
-  constexpr int kNW = 12;                                  // every range runs in 768-thread blocks
-  const bnn_bbb_fwd_args* last = a->layers[nl - 1];
-  const int S = last->n_samples, B = last->batch;
-  if (S <= 0 || S > 16 || B <= 0 || B > 128) return BNN_ERR_SHAPE;
-  // ---- the layers below the output layer
-  long blk = 0;
-  size_t lds = 0;
-  uint32_t expect_prev = 0;
-  for (int i = 0; i + 1 < nl; ++i) {
-    const bnn_bbb_fwd_args* l = a->layers[i];
-    BbbK& k = i == 0 ? c.first : c.hid[i - 1];
-    bool al = false;
-    int rc = prepare(l, k, al);
-    if (rc != BNN_OK) return rc;
-    if (!al || l->math != BNN_MATH_BF16 || l->y_dtype != BNN_BF16 || l->eps_mode != BNN_EPS_PHILOX || !l->want_stats ||
-        l->w_sampled || l->rider || l->eps_w_dump || l->eps_b_dump || l->log_prior || l->log_q || l->n_samples != S ||
-        l->batch != B || l->form != BNN_FORM_AUTO)
-      return BNN_ERR_SHAPE;
-    if (i > 0 && (l->x != a->layers[i - 1]->y || l->x_dtype != BNN_BF16 || l->x_per_sample != 1 ||
-                  l->in_features != a->layers[i - 1]->out_features))
-      return BNN_ERR_SHAPE;
-    BbbPlan pl{};
-    tile_plan(S, B, l->in_features, l->out_features, true, 8, pl);
-    const int ssteps = (l->in_features + 32 * pl.R - 1) / (32 * pl.R);
-    if (pl.nw != kNW) return BNN_ERR_SHAPE;               // the launch's blocks are 12 waves: only layers whose own plan is
-                                                          // (then the k-steps fall on the waves as in the separate launch)
-    if (i > 0 && (ssteps + kNW - 1) / kNW > kChainSPW) return BNN_ERR_SHAPE;
-    k.blk0 = (int)blk;
-    k.done = a->counters + i;
-    k.err = a->counters + 15;
-    if (i > 0) {
-      k.wait = a->counters + (i - 1);
-      k.wait_n = expect_prev;
-      c.Rh[i - 1] = pl.R;
-      c.hid0[i - 1] = (int)blk;
-    } else {
-      c.R0 = pl.R;
-      c.xdt0 = l->x_dtype;
-    }
-    expect_prev = (uint32_t)pl.blocks;
-    blk += ((pl.blocks + 7) / 8) * 8;
-    const size_t need = ((size_t)kNW * 8 * 64 * 4 + 16 + 3 * kNW) * sizeof(float);
-    lds = need > lds ? need : lds;
-    if (i == 0) {                                           // the sampling job sits right behind layer 0's blocks
-      long rider_blocks = 0;
-      rc = fill_sample(a->last_sampler, c.sk, rider_blocks);
-      if (rc != BNN_OK) return rc;
-      if (a->last_sampler->n_layers != 1 || a->last_sampler->n_samples != S || a->last_sampler->cast_n != 0) return BNN_ERR_SHAPE;
-      c.rider0 = (int)blk;
-      c.cw.rider_n = (uint32_t)rider_blocks;
-      blk += ((rider_blocks + 7) / 8) * 8;
-    }
-  }
-  c.n_hid = nl - 2;
-  if (c.n_hid == 0) c.hid0[0] = (int)blk;                   // no hidden range: the rows blocks follow the sampling job
-  c.rows0 = (int)blk;
-  // ---- the output layer: row-split over the sampled weights, with the finalize (as bnn_bbb_final_fwd)
-  {
-    BbbK k;
-    bool al = false;
-    int rc = prepare(last, k, al);
-    if (rc != BNN_OK) return rc;
-    const bnn_finalize_args* f = a->fin;
-    rc = make_fin(f, c.fp.k, c.fp.c);
-    if (rc != BNN_OK) return rc;
-    const int N = last->out_features, K = last->in_features;
-    const bool rows = last->w_sampled && last->x_dtype == BNN_BF16 && last->y_dtype == BNN_F32 && N <= 16 && !f->local_reparam &&
-                      f->n_layers == nl && f->n_samples == S && f->classes == N && f->batch == B && f->logits == last->y && f->nll &&
-                      f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
-                      !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) && !last->rider &&
-                      (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(last->y) & 15)) && last->x == a->layers[nl - 2]->y &&
-                      last->x_per_sample == 1 && K == a->layers[nl - 2]->out_features &&
-                      last->w_sampled == a->last_sampler->layer[0].w_out && last->b_sampled == a->last_sampler->layer[0].b_out;
-    if (!rows) return BNN_ERR_SHAPE;
-    c.fr.x = reinterpret_cast<const __bf16*>(last->x);
-    c.fr.x_sstride = k.x_sstride; c.fr.xg = k.xg;
-    c.fr.w = k.w_pre; c.fr.b = k.b_pre;
-    c.fr.y = reinterpret_cast<float*>(last->y);
-    c.fr.S = S; c.fr.B = B; c.fr.K = K; c.fr.N = N; c.fr.relu = last->relu ? 1 : 0;
-    char* base = reinterpret_cast<char*>(f->scratch);
-    c.fr.tickets = reinterpret_cast<uint32_t*>(base);
-    c.fr.parts = reinterpret_cast<float*>(base + (((size_t)S * 4 + 255) / 256) * 256);
-    c.fp.sums = f->sums;
-    c.fp.ticket = f->ticket;
-    c.fp.ks = 1; c.fp.ks_ticket = nullptr; c.fp.ks_stats = nullptr; c.fp.ks_tiles = nullptr;
-    c.fp.k.ws_sc1 = 1;
-  }
-  c.rider_done = a->counters + 8;
-  c.cw.rider_done = a->counters + 8;
-  c.cw.layer_done = a->counters + (nl - 2);
-  c.cw.layer_n = expect_prev;
-  c.cw.err = a->counters + 15;
-  c.cw.reset = a->counters;
-  c.cw.n_reset = 9;
-#ifdef BNN_STAMPS
-  c.cw.dbg = c.first.dbg;
-#endif
-  const int RB = (B + 15) / 16;
-  blk += (long)S * (RB + 1);
-  if (c.n_hid > 1 && c.Rh[1] != c.Rh[0]) return BNN_ERR_SHAPE;    // one tile width for the hidden layers of a launch
-  const int RH = c.n_hid > 0 ? c.Rh[0] : 1;
-  hipError_t err = hipSuccess;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-#define BNN_CHAIN(XDT, RR0, RRH)                                                                           \
-  do {                                                                                                     \
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(bbb_chain_kernel<XDT, RR0, RRH>),              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-    if (err == hipSuccess)                                                                                 \
-      hipLaunchKernelGGL((bbb_chain_kernel<XDT, RR0, RRH>), dim3((unsigned)blk), dim3(kNW * 64), lds, stream, c); \
-  } while (0)
-#define BNN_CHAIN_H(XDT, RR0)                    \
-  do {                                           \
-    if (RH == 1) BNN_CHAIN(XDT, RR0, 1);         \
-    else if (RH == 2) BNN_CHAIN(XDT, RR0, 2);    \
-    else BNN_CHAIN(XDT, RR0, 4);                 \
-  } while (0)
-#define BNN_CHAIN_0(XDT)                         \
-  do {                                           \
-    if (c.R0 == 1) BNN_CHAIN_H(XDT, 1);          \
-    else if (c.R0 == 2) BNN_CHAIN_H(XDT, 2);     \
-    else BNN_CHAIN_H(XDT, 4);                    \
-  } while (0)
-  if (c.xdt0 == BNN_F32) BNN_CHAIN_0(BNN_F32); else BNN_CHAIN_0(BNN_BF16);
-#undef BNN_CHAIN_0
-#undef BNN_CHAIN_H
-#undef BNN_CHAIN
-  if (err != hipSuccess) return (int)err;
-  err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
 }
 
 // gx[S,B,K] = gz[S,B,N] . w_s with w regenerated (TRANS form of the K-split kernel).  Called by

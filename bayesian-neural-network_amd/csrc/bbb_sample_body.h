@@ -51,8 +51,6 @@ __device__ __forceinline__ float sample_mix_p(const SampleL& L, float w) {
 // One block of the sampling job: `block` = index within the job's own block range, `red` = LDS scratch of
 // >= (blockDim.x / 64) * 3 floats.  Every thread of the block must call it (one barrier inside); threads beyond
 // kSampleThreads take no octet.
-// SC1: the outputs are handed to a later phase of the SAME launch (bnn_bbb_chain_fwd): write-through stores.
-template <bool SC1 = false>
 __device__ __forceinline__ void sample_block(const SampleK& p, int block, float* red) {
   if (block >= p.cast_first) {                             // rider: fp32 -> bf16 of the input batch, 8 per thread
     if ((int)threadIdx.x >= kSampleThreads) return;        // (block-uniform branch above: no barrier on this path)
@@ -144,8 +142,7 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
       bf16x8 wb;
 #pragma unroll
       for (int j = 0; j < 8; ++j) wb[j] = (__bf16)w[j];
-      if (SC1) st_sc1_b128(L.w_out + ((size_t)s * N + n[u]) * K + k[u], __builtin_bit_cast(float4, wb));
-      else *reinterpret_cast<bf16x8*>(L.w_out + ((size_t)s * N + n[u]) * K + k[u]) = wb;
+      *reinterpret_cast<bf16x8*>(L.w_out + ((size_t)s * N + n[u]) * K + k[u]) = wb;
     }
   }
   if (has_bias) {
@@ -154,8 +151,7 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
     const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
     const float sg = softplus(brho);
     const float b = __builtin_fmaf(sg, e, bmu);
-    if (SC1) st_sc1_b32(L.b_out + (size_t)s * N + bn, b);
-    else L.b_out[(size_t)s * N + bn] = b;
+    L.b_out[(size_t)s * N + bn] = b;
     s_e2 = __builtin_fmaf(e, e, s_e2);
     s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
     if (do_ls) s_ls = add_log(s_ls, sg);
@@ -174,13 +170,8 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
       t1 += red[wv * 3 + 1];
       t2 += red[wv * 3 + 2];
     }
-    if (SC1) {
-      st_sc1_b128(L.ws + 1 + (size_t)s * L.T + chunk, make_float4(t0, t1, t2, 0.f));
-      if (local == 0) st_sc1_b128(L.ws, make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f));
-    } else {
-      L.ws[1 + (size_t)s * L.T + chunk] = make_float4(t0, t1, t2, 0.f);
-      if (local == 0) L.ws[0] = make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f);
-    }
+    L.ws[1 + (size_t)s * L.T + chunk] = make_float4(t0, t1, t2, 0.f);
+    if (local == 0) L.ws[0] = make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f);
   }
 }
 

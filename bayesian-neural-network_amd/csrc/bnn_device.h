@@ -122,8 +122,8 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
 // range [x*chunk, (x+1)*chunk) of the (tile-major, sample-minor) work list: the few feature
 // tiles an XCD touches keep their (mu, rho) resident in that XCD's 4 MiB L2 while the samples
 // stream through.  Returns false for the padding blocks of the last range.
-__device__ __forceinline__ bool xcd_work_item(int total, int& item, int blk0 = 0) {   // blk0: first block of this work list
-  const int b = (int)blockIdx.x - blk0;                                                 // in the grid (a multiple of 8)
+__device__ __forceinline__ bool xcd_work_item(int total, int& item) {
+  const int b = blockIdx.x;
   const int chunk = (total + 7) >> 3;
   item = (b & 7) * chunk + (b >> 3);
   return (b >> 3) < chunk && item < total;
@@ -176,103 +176,6 @@ inline Xcd2D xcd2d_make(int G, int U, int inner, size_t group_bytes, size_t l2_b
   int c = (int)((G + per - 1) / per);
   m.classes = c < 1 ? 1 : (c > G ? G : c);
   return m;
-}
-
-// ---------------------------------------------------------------------------- in-launch hand-offs
-// One launch, several dependent phases (bnn_bbb_chain_fwd): blocks of a later phase consume what blocks of an earlier
-// phase stored.  The protocol is the one measured for gfx950 in MI355X_MICROARCH.md (hand-offs with sc1 loads in place
-// of the acquire, first row of its table): the producer stores EVERY handed-off byte write-through (sc1), every
-// storing wave drains its stores (s_waitcnt vmcnt(0)), the block meets, ONE lane adds to the phase's counter
-// (agent-scope atomic); a consumer polls that counter with sc1 loads in one lane, the block meets, and EVERY load of
-// the handed-off bytes is an sc1 load (served by L2 / memory, never by the CU's L1).
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-__device__ __forceinline__ void st_sc1_b64(void* p, uint2 v) {
-  const u32x2 r = {v.x, v.y};                              // inline asm takes native vectors, not HIP's struct types
-  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-}
-__device__ __forceinline__ void st_sc1_b128(void* p, float4 v) {
-  const f32x4 r = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-}
-__device__ __forceinline__ void st_sc1_b32(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one / four 16-byte sc1 loads, back when the function returns (the wait is inside the asm statement: the compiler
-// never sees a register whose data is still in flight)
-__device__ __forceinline__ float4 ld_sc1_b128(const void* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void ld_sc1_b128x4(const void* p0, const void* p1, const void* p2, const void* p3, float4& a, float4& b,
-                                              float4& c, float4& d) {
-  f32x4 va, vb, vc, vd;
-  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-               "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(va), "=&v"(vb), "=&v"(vc), "=&v"(vd)
-               : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-               : "memory");
-  a = make_float4(va[0], va[1], va[2], va[3]);
-  b = make_float4(vb[0], vb[1], vb[2], vb[3]);
-  c = make_float4(vc[0], vc[1], vc[2], vc[3]);
-  d = make_float4(vd[0], vd[1], vd[2], vd[3]);
-}
-// sixteen 16-byte sc1 loads in flight at once (a dependent phase has nothing to hide a round trip behind: the loads of
-// a whole k-step go out together).  Two asm statements -- an asm takes at most 30 operands -- the second of which
-// re-defines the first eight registers ("+v") and carries the wait, so no register is read before its data is back.
-__device__ __forceinline__ void ld_sc1_b128x16(const void* const p[16], float4 out[16]) {
-  f32x4 v[16];
-  asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-               "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-               "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-               "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
-               : "memory");
-  asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\t"
-               "global_load_dwordx4 %2, %18, off sc1\n\tglobal_load_dwordx4 %3, %19, off sc1\n\t"
-               "global_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
-               "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15]),
-                 "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-               : "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15])
-               : "memory");
-#pragma unroll
-  for (int i = 0; i < 16; ++i) out[i] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-}
-__device__ __forceinline__ float ld_sc1_f32(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// producer side: call in EVERY thread of the block after its last hand-off store (block-uniform control flow)
-__device__ __forceinline__ void phase_signal(uint32_t* counter) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// consumer side: every thread of the block calls it; returns when `counter` has reached `expected`.  The spin is
-// bounded: a block waits only for blocks with smaller indices (dispatched before it: resident or finished), so the
-// bound is never reached in a correct launch; if it is, the kernel traps instead of hanging the device.
-// ACQUIRE: the polling lane also invalidates this CU's L1 (agent-scope acquire) before the block meets, so that PLAIN
-// loads of the handed-off bytes are safe afterwards -- they then hit the XCD's L2 after its first fetch, where sc1
-// loads of bytes stored with sc1 go out to the fabric every time (150 blocks each reading all 307 KB of a layer's
-// output: 46 MB).  Costs ~1.7 us once per block; the producer side (sc1 stores, drained, then the counter) is unchanged.
-template <bool ACQUIRE = false>
-__device__ __forceinline__ void phase_wait(const uint32_t* counter, uint32_t expected, uint32_t* err_word) {
-  if (threadIdx.x == 0) {
-    uint32_t spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 24)) {                       // ~ seconds
-        if (err_word) __hip_atomic_store(err_word, 0xDEAD0000u | (blockIdx.x & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_trap();
-      }
-    }
-    if (ACQUIRE) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
 }
 
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of

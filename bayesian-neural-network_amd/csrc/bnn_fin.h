@@ -24,7 +24,6 @@ struct FinK {
   long tgt_stride;               // elements between the targets of consecutive minibatches (0: one target for all)
   const float* nll_partial;      // optional [S][nll_rb]: the NLL of row blocks, summed here instead of walking the logits
   int nll_rb;
-  int ws_sc1;                    // the statistics were stored by earlier phases of THIS launch: read them with sc1 loads
 };
 
 // All transcendental constants of the priors, precomputed on the host in fp64.
@@ -68,7 +67,7 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
   k.nll_sigma = a->nll_sigma; k.log_prior = a->log_prior; k.log_q = a->log_q; k.kl = a->kl; k.nll = a->nll;
   k.sample_counter = a->sample_counter; k.sample_counter_inc = a->sample_counter_inc;
   k.group = a->group_samples;
-  k.nll_partial = nullptr; k.nll_rb = 0; k.ws_sc1 = 0;
+  k.nll_partial = nullptr; k.nll_rb = 0;
   k.tgt_stride = a->target_per_group
                      ? (a->nll_mode == BNN_NLL_CLASSIFICATION ? (long)a->batch : (long)a->batch * a->classes) : 0;
   const double c0 = -0.91893853320467274178;
@@ -89,15 +88,13 @@ static inline int make_fin(const bnn_finalize_args* a, FinK& k, FinC& cst) {
 
 // This thread's share of the NLL of rows [row0, row1) of sample s (networks.py:183-190): cross-entropy with
 // reduction='sum', or -sum log N(target; out, sigma).  Summed over the block by the caller.
-__device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, const float* lg, int ldc, int row0, int row1,
-                                         int nthr = 0) {
-  const int bdim = nthr > 0 ? nthr : (int)blockDim.x;      // threads taking part (a wider block's other threads have left)
+__device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, const float* lg, int ldc, int row0, int row1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.f;
     if (p.nll_mode == BNN_NLL_CLASSIFICATION) {
     const long long* tgt = reinterpret_cast<const long long*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
     if (p.C <= 32) {                           // a thread per row
-      for (int b = row0 + (int)threadIdx.x; b < row1; b += bdim) {
+      for (int b = row0 + (int)threadIdx.x; b < row1; b += blockDim.x) {
         const float* row = lg + (size_t)b * ldc;
         const long long tc = tgt[b];
         float mx, se = 0.f;
@@ -134,7 +131,7 @@ __device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, 
         acc += (mx + se) - picked;
       }
     } else {                                   // a wave per row, lanes stride over the classes
-      const int nwv = bdim >> 6;
+      const int nwv = blockDim.x >> 6;
       for (int b = row0 + wave; b < row1; b += nwv) {
         const float* row = lg + (size_t)b * ldc;
         float mx = -3.0e38f;
@@ -156,14 +153,14 @@ __device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, 
   } else {
     const float* tgt = reinterpret_cast<const float*>(p.target) + (p.group > 0 ? (s / p.group) * p.tgt_stride : 0);
     if (p.C <= 8) {                            // a thread per row (the 1-output regression net)
-      for (int b = row0 + (int)threadIdx.x; b < row1; b += bdim)
+      for (int b = row0 + (int)threadIdx.x; b < row1; b += blockDim.x)
         for (int cc = 0; cc < p.C; ++cc) {
           const float d = tgt[(size_t)b * p.C + cc] - lg[(size_t)b * ldc + cc];
           acc += (float)((double)(d * d) * cst.reg_inv2var + cst.reg_const);
         }
     } else {                                   // wide outputs: a wave per row, lanes stride over the outputs
       // sum of squares in fp32 per lane (<= B*C/threads terms), the affine map applied once per lane
-      const int nwv = bdim >> 6;
+      const int nwv = blockDim.x >> 6;
       float d2 = 0.f;
       int cnt = 0;
       for (int b = row0 + wave; b < row1; b += nwv) {
@@ -202,13 +199,11 @@ __device__ __forceinline__ float fin_nll(const FinK& p, const FinC& cst, int s, 
 // fp64 only across waves; one barrier.
 __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s, const int T[8], const float* lg, int ldc,
                                            int own_layer, float own0, float own1, float own2, float* part,
-                                           float& out_a, float& out_b, float& out_nll, unsigned long long* dbg = nullptr,
-                                           int nthr = 0) {
+                                           float& out_a, float& out_b, float& out_nll, unsigned long long* dbg = nullptr) {
 // diagnostic build (-DBNN_STAMPS, tools/stamps_final.py) passes a stamp buffer; production callers pass none and
 // the stamps fold away
 #define FIN_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
   constexpr int NV = kFinNV;
-  const int bdim = nthr > 0 ? nthr : (int)blockDim.x;      // threads taking part (a wider block's other threads have left)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float v[NV];
 #pragma unroll
@@ -217,17 +212,12 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   for (int l = 0; l < 8; ++l) {
     if (l < p.n_layers && l != own_layer) {
       const float4* ws = reinterpret_cast<const float4*>(p.ws[l]);
-      for (int t = threadIdx.x; t < T[l]; t += bdim) {
+      for (int t = threadIdx.x; t < T[l]; t += blockDim.x) {
         if (p.local_reparam) {
           const float4 qv = ws[1 + t];
           v[3 * l + 0] += qv.x;                // sum log sigma
           v[3 * l + 1] += qv.y;                // sum sigma^2
           v[3 * l + 2] += qv.z;                // sum mu^2
-        } else if (p.ws_sc1) {
-          const float4 qv = ld_sc1_b128(ws + 1 + (size_t)s * T[l] + t);
-          v[3 * l + 0] += qv.x;
-          v[3 * l + 1] += qv.y;
-          v[3 * l + 2] += (s == 0) ? qv.z : ld_sc1_b128(ws + 1 + t).z;
         } else {
           const float4 qv = ws[1 + (size_t)s * T[l] + t];
           v[3 * l + 0] += qv.x;                // sum eps^2
@@ -240,10 +230,10 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   FIN_STAMP(12);
   if (p.nll && p.nll_partial) {               // row blocks already reduced by nll_rows_kernel: add them up
     float acc = 0.f;
-    for (int t = threadIdx.x; t < p.nll_rb; t += bdim) acc += p.nll_partial[(size_t)s * p.nll_rb + t];
+    for (int t = threadIdx.x; t < p.nll_rb; t += blockDim.x) acc += p.nll_partial[(size_t)s * p.nll_rb + t];
     v[NV - 1] = acc;
   } else if (p.nll && lg) {
-    v[NV - 1] = fin_nll(p, cst, s, lg, ldc, 0, p.B, bdim);
+    v[NV - 1] = fin_nll(p, cst, s, lg, ldc, 0, p.B);
   }
   FIN_STAMP(13);
   const int nv = 3 * p.n_layers;
@@ -272,7 +262,7 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   // ~70 dependent LDS reads, 3 us by the stamps), then hands the doubles to thread 0 through the same scratch
   double folded = 0;
   {
-    const int nwv = bdim >> 6;
+    const int nwv = blockDim.x >> 6;
     if ((int)threadIdx.x < NV && ((int)threadIdx.x < nv || (int)threadIdx.x == NV - 1))
       for (int w = 0; w < nwv; ++w) folded += (double)part[w * NV + threadIdx.x];
   }

@@ -204,36 +204,6 @@ int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* args, void* stream);
 int bnn_bbb_plan(const bnn_bbb_fwd_args* args, bnn_plan* plan);
 
 /* ------------------------------------------------------------------------------------
- * K1x  bnn_bbb_chain_fwd — a whole few-sample BBB evaluation (BayesianNetwork.forward + log_prior /
- * log_variational_posterior / get_nll for the MC samples of sample_elbo's loop, networks.py:166-190, :199-203) in ONE
- * launch: the layers are block ranges of one grid.  The first layer runs as in bnn_bbb_linear_fwd; the blocks of a
- * hidden layer first draw their tile's weights (sampling depends on no activation), then wait until the layer below
- * has stored its output, then multiply; the output layer runs row-split over the weights a sampling job of the same
- * launch drew, with the finalize (the row form of bnn_bbb_final_fwd).  Results are those of the separate launches,
- * bit for bit (same tiles, same summation orders, same Philox elements).
- *   layers[0 .. n_layers-2] : as for bnn_bbb_linear_fwd — bf16 math, bf16 y, want_stats, on-chip eps, aligned shapes,
- *                             layers[i].x == layers[i-1].y with x_per_sample = 1, form = BNN_FORM_AUTO;
- *   layers[n_layers-1]      : as for the pre-sampled bnn_bbb_final_fwd (w_sampled / b_sampled = last_sampler's outputs);
- *   last_sampler            : the one-layer bnn_bbb_sample_weights job that draws the output layer's weights;
- *   fin                     : as for bnn_bbb_final_fwd (scratch and, above one sample, ticket required);
- *   counters                : >= 16 zero-initialised device words, left at zero; word 15 receives a code if a
- *                             bounded in-launch wait gives up (the kernel then traps instead of hanging).
- * Returns BNN_ERR_SHAPE when the arguments do not fit this form (n_samples <= 16, batch <= 128, <= 16 outputs,
- * at most 2 k-steps per wave in a hidden layer, ...): issue the separate launches instead.
- * ---------------------------------------------------------------------------------- */
-#define BNN_CHAIN_MAX_LAYERS 4
-struct bnn_finalize_args;
-typedef struct bnn_bbb_chain_args {
-  uint32_t struct_bytes;
-  int32_t n_layers;                                          /* 2 .. BNN_CHAIN_MAX_LAYERS */
-  const bnn_bbb_fwd_args* layers[BNN_CHAIN_MAX_LAYERS];
-  const struct bnn_bbb_sample_args* last_sampler;
-  const struct bnn_finalize_args* fin;
-  uint32_t* counters;
-} bnn_bbb_chain_args;
-int bnn_bbb_chain_fwd(const bnn_bbb_chain_args* args, void* stream);
-
-/* ------------------------------------------------------------------------------------
  * K1s  bnn_bbb_sample_weights — the sampling half of BayesianLinear.forward (networks.py:73-86) for up to
  * BNN_SAMPLE_MAX_LAYERS layers and n_samples MC samples in ONE launch:
  *     w_out[s] = bf16(mu + softplus(rho) * eps_s)  [n_samples,out,in],   b_out[s] likewise, fp32 [n_samples,out]

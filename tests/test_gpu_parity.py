@@ -1085,43 +1085,6 @@ def test_row_split_output_layer_equals_the_two_launch_form(dev, monkeypatch, dim
     close(b1, b2.cpu().numpy(), rtol=nll_tol)
 
 
-@pytest.mark.parametrize("dims,mode,B,G,S", [((784, 1200, 10), "classification", 128, 1, 1), ((784, 1200, 10), "classification", 128, 1, 3),
-                                             ((784, 1200, 10), "classification", 100, 2, 1), ((784, 1200, 1), "regression", 128, 1, 2),
-                                             ((400, 1216, 16), "classification", 37, 1, 3), ((40, 72, 16), "classification", 37, 1, 3)])
-def test_chain_launch_equals_the_separate_launches(dev, monkeypatch, dims, mode, B, G, S):
-    """bnn_bbb_chain_fwd (the whole evaluation as one grid: a hidden layer's blocks draw their weights, wait in the
-    launch for the layer below, then multiply; row-split output layer behind a sampling job of the same launch) against
-    the same evaluation as one launch per layer: the same tiles, summation orders and Philox elements, so EVERYTHING is
-    equal bit for bit -- logits, per-sample scalars, sums -- replay after replay (hand-off counters back at zero, sample
-    counter advanced), eagerly and as a captured graph."""
-    from bnn_hip import engine
-    bnn_hip.set_math("bf16")
-    net, _ = build_net(dev, False, dims, mode, B=B)
-    xs, ys = zip(*[synth.synth_batch(mode, B, dims[0], dims[2], seed=90 + m) for m in range(G)])
-    xd, yd = torch.from_numpy(np.stack(xs)).to(dev), torch.from_numpy(np.stack(ys)).to(dev)
-    res = {}
-    for name, max_s, capture in (("separate", 0, False), ("chain", 3, False), ("separate-graph", 0, True), ("chain-graph", 3, True)):
-        monkeypatch.setattr(engine, "CHAIN_MAX_SAMPLES", max_s)
-        bnn_hip.manual_seed(11, counter=7)
-        ev = engine.GraphedElbo(net, xd if G > 1 else xd[0], yd if G > 1 else yd[0], S, sigma=0.4, stacked=G > 1, capture=capture)
-        assert ev.chain or not (max_s > 0 and dims[1] >= 1200), (name, ev.chain)
-        a = ev.replay().clone()
-        b = ev.replay().clone()
-        torch.cuda.synchronize()
-        # the library takes the form only for layers whose own plan has 12-wave blocks (the small net's do not)
-        assert ev.chain == (max_s > 0 and dims[1] >= 1200), "the library declined the chain form"
-        res[name] = (a, b, {k: v.clone() for k, v in ev.out.items()}, ev.logits.clone(), int(ev.counter.item()))
-        if ev.chain:
-            assert int(ev.chain_counters.abs().sum()) == 0
-    for name in ("chain", "chain-graph"):
-        got, ref = res[name], res[name.replace("chain", "separate")]      # (a captured evaluator's warm-up draws once more)
-        assert got[4] == ref[4]
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and not torch.equal(got[0], got[1]), name
-        assert torch.equal(got[3], ref[3]), name
-        for k in ref[2]:
-            assert torch.equal(got[2][k], ref[2][k]), (name, k)
-
-
 def test_large_batch_layers_take_the_library_gemm(dev, monkeypatch):
     """Batches of >= 512 rows: every BBB layer is one sampling launch (K1s) + a plain library GEMM over the sampled
     weights (ops.bbb_library_matmul) instead of the fused kernels; same Philox elements, so the evaluation agrees
