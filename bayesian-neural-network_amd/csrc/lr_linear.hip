@@ -431,48 +431,88 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
 //   = one batch tile's lane-linear 1 KiB fragment block), each wave gathers its (M, rho)
 //   fragment (prefetched a step ahead), forms sigma^2 and issues 16 MFMAs (mean and variance
 //   against the two tiles).  No per-weight sampling: ~150 VALU ops per k-step, one barrier.
-// Prepared weights for K3b: the eps-independent half of the LR layer, done ONCE per evaluation
-// instead of once per MC sample.  Block = one 16-feature tile, its waves split the k-steps;
-// lane (r,q) gathers its A fragment of (M, rho), forms sigma^2, and writes both as bf16 in
-// FRAGMENT ORDER ([tile][k-step][mean | variance][lane] x 16 B), so the GEMM kernel's operand
-// fetch is one coalesced 16-byte load per fragment.  The closed-form KL sums of the tile
-// (networks.py:113) are reduced here, deterministically, into the layer's KL workspace.
-__global__ __launch_bounds__(512) void lr_prepare_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
-                                                         const float* __restrict__ b_mu, const float* __restrict__ b_rho,
-                                                         int K, int N, float4* __restrict__ frag, float4* __restrict__ ws) {
-  __shared__ float red[8 * 3];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// Prepared weights for K3b: the eps-independent half of the LR layer, done ONCE per evaluation instead of once per MC
+// sample: sigma^2, bf16 (M, sigma^2) in FRAGMENT ORDER ([tile][k-step][mean | variance][lane] x 16 B), so that the GEMM
+// kernel's operand fetch is one coalesced 16-byte load per fragment, and the closed-form KL sums (networks.py:113).
+// (The first version gathered its fragments straight from the [in,out] matrices -- 4-byte loads, 64-byte segments --
+// in one block per feature tile: 23 us for the 1200 x 1200 layer, 46 us of every LR evaluation preparing two layers.)
+// A block owns `kb` k-steps x 128 out-features: it reads (mu, rho) rows as
+// 512-byte segments (16 bytes per thread), forms bf16 M and sigma^2 and the KL terms, parks the two 32 x 128 bf16
+// tiles in LDS and writes them out in MFMA-fragment order, 16 bytes per lane, 1 KiB per wave.  One KL entry per block
+// (the finalize only needs the layer's totals); the biases go with the blocks of the first k range.
+__global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+                                                               const float* __restrict__ b_mu, const float* __restrict__ b_rho,
+                                                               int K, int N, int kb, float4* __restrict__ frag,
+                                                               float4* __restrict__ ws) {
+  constexpr int LD = 130;                                   // bf16 elements per LDS row (128 + 2: the four 8-row groups a
+  __shared__ __bf16 m_s[32 * LD], v_s[32 * LD];             // fragment read touches fall on different banks)
+  __shared__ float red[4 * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x, T = gridDim.x;
-  const int n = tile * 16 + r;
-  const bool n_ok = n < N;
-  const int nc = min(n, N - 1);
-  const int ksteps = (K + 31) >> 5;
+  const int ksteps = (K + 31) >> 5, T = (N + 15) >> 4;
+  const int kblk = blockIdx.x, grp = blockIdx.y;            // k-step range, 128-feature group
+  const int n0 = grp * 128;
+  const bool vec = (N & 3) == 0 && !((reinterpret_cast<uintptr_t>(w_mu) | reinterpret_cast<uintptr_t>(w_rho)) & 15);
   float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
-  for (int t = wave; t < ksteps; t += nw) {
-    const int k = t * 32 + q * 8;
-    bf16x8 ma, sa;
+  for (int t = kblk * kb; t < min(ksteps, (kblk + 1) * kb); ++t) {
+    // ---- 32 rows x 128 columns: thread -> (row = i * 8 + tid / 32, 4 columns at (tid % 32) * 4), i = 0..3
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = n_ok && (k + j) < K;
-      const size_t off = (size_t)min(k + j, K - 1) * N + nc;
-      const float mu = w_mu[off];
-      const float sig = softplus(w_rho[off]);
-      if (ws) {
-        s_ls += ok ? fast_log(sig) : 0.f;
-        s_s2 += ok ? sig * sig : 0.f;
-        s_m2 += ok ? mu * mu : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int kr = i * 8 + ((int)threadIdx.x >> 5), k = t * 32 + kr;
+      const int c4 = ((int)threadIdx.x & 31) * 4, n = n0 + c4;
+      float mu[4] = {0.f, 0.f, 0.f, 0.f}, rh[4] = {0.f, 0.f, 0.f, 0.f};
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ok[j] = k < K && n + j < N;
+      if (k < K && n < N) {
+        const size_t off = (size_t)k * N + n;
+        if (vec) {                                           // n + 3 < N as N % 4 == 0
+          const float4 a = *reinterpret_cast<const float4*>(w_mu + off), b = *reinterpret_cast<const float4*>(w_rho + off);
+          mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; mu[3] = a.w;
+          rh[0] = b.x; rh[1] = b.y; rh[2] = b.z; rh[3] = b.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ok[j]) {
+              mu[j] = w_mu[off + j];
+              rh[j] = w_rho[off + j];
+            }
+        }
       }
-      ma[j] = ok ? (__bf16)mu : (__bf16)0.f;
-      sa[j] = ok ? (__bf16)(sig * sig) : (__bf16)0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sig = softplus(rh[j]);
+        if (ws) {
+          s_ls += ok[j] ? fast_log(sig) : 0.f;
+          s_s2 += ok[j] ? sig * sig : 0.f;
+          s_m2 += ok[j] ? mu[j] * mu[j] : 0.f;
+        }
+        m_s[kr * LD + c4 + j] = ok[j] ? (__bf16)mu[j] : (__bf16)0.f;
+        v_s[kr * LD + c4 + j] = ok[j] ? (__bf16)(sig * sig) : (__bf16)0.f;
+      }
     }
-    float4* dst = frag + ((size_t)tile * ksteps + t) * 128;
-    dst[lane] = __builtin_bit_cast(float4, ma);
-    dst[64 + lane] = __builtin_bit_cast(float4, sa);
+    __syncthreads();
+    // ---- fragments: wave w writes tiles w and w + 4 of the group; lane (r, q) holds W[t*32 + 8q .. +7][tile*16 + r]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int tl = wave + 4 * h, tile = grp * 8 + tl;
+      if (tile < T) {                                        // wave-uniform
+        bf16x8 ma, sa;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ma[j] = m_s[(q * 8 + j) * LD + tl * 16 + r];
+          sa[j] = v_s[(q * 8 + j) * LD + tl * 16 + r];
+        }
+        float4* dst = frag + ((size_t)tile * ksteps + t) * 128;
+        dst[lane] = __builtin_bit_cast(float4, ma);
+        dst[64 + lane] = __builtin_bit_cast(float4, sa);
+      }
+    }
+    __syncthreads();
   }
   if (ws) {
-    if (wave == 0 && q == 0 && n_ok) {                 // the tile's biases
-      const float sig = softplus(b_rho[n]), mu = b_mu[n];
+    if (kblk == 0 && (int)threadIdx.x < 128 && n0 + (int)threadIdx.x < N) {     // the group's biases
+      const float sig = softplus(b_rho[n0 + threadIdx.x]), mu = b_mu[n0 + threadIdx.x];
       s_ls += fast_log(sig);
       s_s2 = __builtin_fmaf(sig, sig, s_s2);
       s_m2 = __builtin_fmaf(mu, mu, s_m2);
@@ -486,13 +526,14 @@ __global__ __launch_bounds__(512) void lr_prepare_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
       float x = 0.f, y = 0.f, z = 0.f;
-      for (int w = 0; w < nw; ++w) {
+      for (int w = 0; w < 4; ++w) {
         x += red[w * 3 + 0];
         y += red[w * 3 + 1];
         z += red[w * 3 + 2];
       }
-      ws[1 + tile] = make_float4(x, y, z, 0.f);
-      if (tile == 0) ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+      const int entry = blockIdx.y * gridDim.x + blockIdx.x;
+      ws[1 + entry] = make_float4(x, y, z, 0.f);
+      if (entry == 0) ws[0] = make_float4(__int_as_float((int)(gridDim.x * gridDim.y)), 0.f, 0.f, 0.f);
     }
   }
 }
@@ -897,9 +938,13 @@ __global__ void lr_layer_kl_kernel(const float4* __restrict__ ws, int K, int N, 
 
 using namespace bnn;
 
+// One float4 entry per KL writer: a feature tile of the layer kernels (at most ceil(N / 4)), or a block of
+// bnn_lr_prepare (k-step range x 128 features: up to kPrepEntries, so that it can run as several hundred blocks).
+static constexpr int kPrepEntries = 4096;
 extern "C" size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features) {
   if (out_features <= 0) return 0;
-  return (1 + (size_t)((out_features + 3) / 4)) * 4 * sizeof(float);
+  const size_t tiles = (size_t)((out_features + 3) / 4);
+  return (1 + (tiles > (size_t)kPrepEntries ? tiles : (size_t)kPrepEntries)) * 4 * sizeof(float);
 }
 
 extern "C" size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features) {
@@ -918,10 +963,14 @@ extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float
     if (kl_workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(out_features)) return BNN_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(kl_workspace) & 15) return BNN_ERR_ALIGN;
   }
-  const int T = (out_features + 15) / 16;
-  hipLaunchKernelGGL(lr_prepare_kernel, dim3(T), dim3(512), 0, reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu,
-                     b_rho, in_features, out_features, reinterpret_cast<float4*>(w_frag),
-                     reinterpret_cast<float4*>(kl_workspace));
+  // blocks of kb k-steps x 128 features, at most one KL entry per 4 features (the workspace's size): kb from that
+  const int ksteps = (in_features + 31) / 32, groups = (out_features + 127) / 128;
+  const int max_entries = (out_features + 3) / 4 > kPrepEntries ? (out_features + 3) / 4 : kPrepEntries;
+  int kb = 1;
+  while ((long)((ksteps + kb - 1) / kb) * groups > max_entries) ++kb;
+  hipLaunchKernelGGL(lr_prepare_tiled_kernel, dim3((unsigned)((ksteps + kb - 1) / kb), (unsigned)groups), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu, b_rho, in_features, out_features, kb,
+                     reinterpret_cast<float4*>(w_frag), reinterpret_cast<float4*>(kl_workspace));
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -73,7 +73,7 @@ def test_argument_validation_without_a_device():
     assert lib.bnn_bbb_linear_fwd_workspace_bytes(2, 1200) == (1 + 2 * 75 * 8) * 16    # 8 statistics writers per 16-feature tile
     assert lib.bnn_bbb_split_scratch_bytes(8, 128, 1200) == 768 + 152 * 8 * 32768 and \
         lib.bnn_bbb_split_scratch_zero_bytes(8, 128, 1200) == 768
-    assert lib.bnn_lr_linear_fwd_workspace_bytes(1200) == (1 + 300) * 16
+    assert lib.bnn_lr_linear_fwd_workspace_bytes(1200) == (1 + 4096) * 16 and lib.bnn_lr_linear_fwd_workspace_bytes(20000) == (1 + 5000) * 16
     lb = L.LrBwdArgs()
     assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -5
     lb.struct_bytes = C.sizeof(L.LrBwdArgs)
