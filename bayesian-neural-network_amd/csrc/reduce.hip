@@ -535,8 +535,10 @@ extern "C" int bnn_elbo_finalize(const bnn_finalize_args* a, void* stream_) {
       a->scratch_bytes >= bnn_bbb_final_scratch_bytes(a->n_samples) && !(reinterpret_cast<uintptr_t>(a->scratch) & 15)) {
     const int rpb = 4;                                        // a wave per row
     const int nrb = (a->batch + rpb - 1) / rpb;
-    if (nrb <= 32) {                                          // the scratch holds 32 floats per sample in this region
-      float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a->scratch) + (((size_t)a->n_samples * 4 + 255) / 256) * 256);
+    if (nrb <= 8 * 2048) {                                    // the scratch's partial-tile region: 64 KiB per sample
+      float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(a->scratch) + (((size_t)a->n_samples * 4 + 255) / 256) * 256 +
+                                                (size_t)a->n_samples * 8 * 16);
+      // [sample][row block], 16384 floats of room per sample
       hipLaunchKernelGGL(nll_rows_kernel, dim3((unsigned)nrb, (unsigned)a->n_samples), dim3(256), 0, stream, k, cst, rpb, partial);
       const hipError_t e0 = hipGetLastError();
       if (e0 != hipSuccess) return (int)e0;

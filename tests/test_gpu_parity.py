@@ -734,7 +734,7 @@ def test_eval_prepare_equals_the_separate_passes(dev):
     assert nosq is None and torch.equal(only16, ops.cast_bf16(x[:, :, :36].contiguous()))
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 4096), (2, 37, 37), (20, 16, 100), (1, 128, 1), (4, 100, 1000)])
+@pytest.mark.parametrize("shape", [(3, 128, 4096), (2, 37, 37), (20, 16, 100), (1, 128, 1), (4, 100, 1000), (2, 300, 1000)])
 def test_regression_nll_wide_outputs(dev, shape):
     """K4's Gaussian NLL (networks.py:185-187) for output widths the 1-output regression net never
     reaches (the 4096-wide stack of BASELINE configs[4]): wave-per-row / 16-byte path and the
