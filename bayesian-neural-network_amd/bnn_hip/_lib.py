@@ -25,7 +25,7 @@ EXPORTS = (
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare", "bnn_bias_act",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
 )
 
@@ -268,6 +268,8 @@ def load():
                                       C.c_int32, C.c_void_p]
     lib.bnn_softplus.restype = C.c_int
     lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.bnn_bias_act.restype = C.c_int
+    lib.bnn_bias_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.bnn_eval_prepare.restype = C.c_int
     lib.bnn_eval_prepare.argtypes = [C.POINTER(PrepareArgs), C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int

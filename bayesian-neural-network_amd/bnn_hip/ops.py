@@ -321,22 +321,31 @@ def bbb_library_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dt
     if S % rows:
         raise BnnHipError("bbb_library_matmul: x row blocks must divide n_samples")
     g = S // rows
-    y = out if (out is not None and out.dtype == y_dtype) else torch.empty((S, B, N), dtype=y_dtype, device=x.device)
+    y = out if (out is not None and out.dtype == y_dtype and out.is_contiguous()) else torch.empty((S, B, N), dtype=y_dtype, device=x.device)
+    fused = N % 8 == 0                                   # bias + ReLU + conversion as ONE pass (bnn_bias_act) over the
+    prod = torch.empty((S, B, N), dtype=torch.bfloat16, device=x.device) if fused else None   # library's bf16 product
     if g == 1:
         # one NT GEMM per sample (each is >= 2 * 512 * out * in flops: large enough alone).  torch.bmm is avoided on
         # purpose: on this image (torch 2.10 + rocm 7.0 wheels on a ROCm 7.2 gfx950 box) a bf16 bmm of
         # [4,1024,4096] x [4,4096,4096]^T raises a GPU memory access fault inside the library, mm does not
         x3 = x.view(S, B, K)
         for s_ in range(S):
-            y[s_].copy_(torch.nn.functional.linear(x3[s_], w[s_]))
+            if fused:
+                torch.mm(x3[s_], w[s_].t(), out=prod[s_])     # straight into the product buffer: no copy pass
+            else:
+                y[s_].copy_(torch.nn.functional.linear(x3[s_], w[s_]))
     else:
         x3 = x.view(rows, B, K)
         for r in range(rows):                                                            # one NT GEMM per minibatch
-            prod = torch.nn.functional.linear(x3[r], w[r * g:(r + 1) * g].view(g * N, K))   # [B, g * N]
-            y[r * g:(r + 1) * g].copy_(prod.view(B, g, N).transpose(0, 1))
-    y.add_(b.view(S, 1, N).to(y.dtype))
-    if relu:
-        y.relu_()
+            pr = torch.nn.functional.linear(x3[r], w[r * g:(r + 1) * g].view(g * N, K))   # [B, g * N]
+            (prod if fused else y)[r * g:(r + 1) * g].copy_(pr.view(B, g, N).transpose(0, 1))
+    if fused:
+        L.check(L.load().bnn_bias_act(prod.data_ptr(), b.data_ptr(), y.data_ptr(), _dt(y), S, B, N, int(relu), _stream()),
+                "bnn_bias_act")
+    else:
+        y.add_(b.view(S, 1, N).to(y.dtype))
+        if relu:
+            y.relu_()
     if out is not None and y is not out:
         out.copy_(y)
         return out

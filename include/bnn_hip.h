@@ -649,6 +649,13 @@ typedef struct bnn_prepare_args {
 } bnn_prepare_args;
 int bnn_eval_prepare(const bnn_prepare_args* args, void* stream);
 
+/* y[s][b][n] = act(prod[s][b][n] + bias[s][n]) in one pass: the epilogue of a BayesianLinear layer (networks.py:88,
+ * :169-171) whose matmul over pre-sampled weights ran in the BLAS library (batches of >= 512 rows).  prod bf16
+ * [n_samples, batch, out], bias fp32 [n_samples, out] (bnn_bbb_sample_weights' b_out), y bf16 or fp32 (bnn_dtype);
+ * out_features % 8 == 0, 16-byte aligned pointers. */
+int bnn_bias_act(const void* prod_bf16, const float* bias, void* y, int32_t y_dtype, int32_t n_samples, int32_t batch,
+                 int32_t out_features, int32_t relu, void* stream);
+
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
 const char* bnn_status_string(int status); /* static string for a negative status */
 
