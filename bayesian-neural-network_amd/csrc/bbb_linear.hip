@@ -57,6 +57,9 @@ struct BbbK {
   int ksl;          // GEMM form: K-range slices per (tile group, sample, batch block) unit; 1 = none
   float4* ks_part;  // GEMM form, ksl > 1: fp32 partial tiles [unit][ksl][wave][batch tile][lane] (bias in slice 0)
   uint32_t* ks_ticket;  // GEMM form, ksl > 1: [unit] arrival counters of a unit's slice blocks, zero between launches
+#ifdef BNN_TUNE
+  int tune;             // tuning build only
+#endif
   Xcd2D xc;             // GEMM form: work order (feature group x (sample, batch block) x K slice), see bnn_device.h
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
@@ -1013,8 +1016,15 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
       const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
     }
+#ifdef BNN_TUNE
+    // tuning build only: BNN_TUNE_K1B bit 0 = no per-step barrier, bit 1 = no vmcnt wait (wrong results: an upper bound on what
+    // the per-step synchronisation costs)
+    if (!(p.tune & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.tune & 1)) __syncthreads();
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
@@ -1489,6 +1499,9 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     // split scratch and the last-arriving slice block of each unit sums them in slice order (deterministic), applies
     // ReLU and the down-conversion: one launch.
     k.ksl = pl.ksl;
+#ifdef BNN_TUNE
+    k.tune = getenv("BNN_TUNE_K1B") ? atoi(getenv("BNN_TUNE_K1B")) : 0;
+#endif
     {
       size_t l2_budget = kL2WeightBudget;
 #ifdef BNN_TUNE
