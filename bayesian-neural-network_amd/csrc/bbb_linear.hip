@@ -1581,6 +1581,9 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
 }
 
 static constexpr int kFinalMaxSlices = 8;
+// above this many samples a one-block follow-up launch folds the sums: per-block fences cost more (re-measured this
+// round at 20 / 32 / 64 pairs: 16 -> 32 loses 6 % / 4 % / 1 %)
+static constexpr int kFinalTicketMaxSamples = 16;
 
 // reduce.hip: sums over the per-sample outputs + sample-counter advance (one block)
 extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream);
@@ -1638,7 +1641,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   const bool fuse = al && a->out_features <= 16 && a->batch <= 128 && a->want_stats && !f->local_reparam && nl >= 1 &&
                     f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
                     f->classes == a->out_features && f->batch == a->batch && a->y_dtype == BNN_F32 &&
-                    (a->n_samples == 1 || a->n_samples > 16 || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
+                    (a->n_samples == 1 || a->n_samples > kFinalTicketMaxSamples || f->ticket != nullptr) && !(a->log_prior || a->log_q) &&
                     a->form == BNN_FORM_AUTO;
   if (!fuse) {
     rc = bnn_bbb_linear_fwd(a, stream_);
@@ -1650,7 +1653,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   // Few samples: the last-arriving sample block folds the sums and advances the counter (one
   // release/acquire per block).  Many samples: those fences (an L2 write-back each) cost more
   // than a launch, so a one-block follow-up kernel does it instead.
-  const bool tail_kernel = a->n_samples > 16;
+  const bool tail_kernel = a->n_samples > kFinalTicketMaxSamples;
   fp.ticket = tail_kernel ? nullptr : f->ticket;
   const int K = a->in_features;
   const int ssteps = (K + 31) / 32;
