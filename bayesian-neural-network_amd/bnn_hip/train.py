@@ -44,10 +44,11 @@ class GraphedTrainStep:
 
         `data_parallel`: every rank of the default torch.distributed group (RCCL on GPUs) holds a replica
         and feeds its own minibatch; the backward kernels write all gradients into ONE flat fp32
-        bucket (2 x 2.4 M floats at the MNIST config) that is sum-all-reduced in a single collective
-        between two captured graphs (forward+backward | Adam); the backward seeds carry the 1/ranks,
-        rank r draws MC-sample indices [first + r*S, first + (r+1)*S) of every step.  Replicas must
-        start identical (`broadcast_parameters`)."""
+        bucket (2 x 2.4 M floats at the MNIST config), sum-all-reduced in TWO pieces between three captured
+        graphs: forward + backward down to layer 1 | all-reduce of the upper layers' gradients (asynchronous, on
+        the collective's own stream) beside the backward of layer 0 | all-reduce of layer 0's gradients | Adam.
+        The backward seeds carry the 1/ranks, rank r draws MC-sample indices [first + r*S, first + (r+1)*S) of
+        every step.  Replicas must start identical (`broadcast_parameters`)."""
         if not all(g.get("capturable") for g in optimizer.param_groups):
             raise ops.BnnHipError("GraphedTrainStep needs FusedAdam(capturable=True)")
         if state.host_eps or any(sp.m._eps_stubbed() for sp in net._specs()):
@@ -77,6 +78,7 @@ class GraphedTrainStep:
             tot += (p.numel() + 63) // 64 * 64
         self.bucket = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.grad_views = [self.bucket[o:o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+        self.bucket_cut = offs[4] if len(offs) > 4 else 0      # first element of layer 1's gradients (layer 0 = 4 tensors)
         self._elbo = net.sample_elbo_lr if net.local_reparam else net.sample_elbo
         specs = net._specs()
         self.presample = (TRAIN_PRESAMPLE and not self.autograd and not net.local_reparam and state.math == L.MATH_BF16 and
@@ -131,13 +133,18 @@ class GraphedTrainStep:
         # ---- capture
         self.graph = torch.cuda.CUDAGraph()
         self.graph_update = None
+        self.graph_bwd0 = None
         state.device_counter = self.counter
         try:
             take_before = state.counter
             if self.dp:
                 with torch.cuda.graph(self.graph):
                     with torch.no_grad():
-                        self.out = self._chain()
+                        self.out = self._chain(stop_above_layer0=True)
+                self.graph_bwd0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_bwd0, pool=self.graph.pool()):
+                    with torch.no_grad():
+                        self._chain_layer0()
                 self.graph_update = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
                     self._update()
@@ -148,7 +155,7 @@ class GraphedTrainStep:
         finally:
             state.device_counter = None
 
-    def _chain(self):
+    def _chain(self, stop_above_layer0: bool = False):
         """zero_grad -> sample_elbo -> backward, as a hand-made chain of the C-ABI kernels (no autograd).
         Leaves the gradients in p.grad and returns what sample_elbo* returns."""
         net, S = self.net, self.samples
@@ -202,42 +209,60 @@ class GraphedTrainStep:
                                                          fin["nll"], self.beta, S, lr, h, self.y, net.mode, self.sigma,
                                                          grad_scale=1.0 / self.world)
         top = len(specs) - 1
-        for i in reversed(range(len(specs))):
-            sp = specs[i]
-            xin, y, v, p = saved[i]
-            # layer i's ReLU mask is applied by layer i+1's input-gradient kernel (its x IS layer i's output),
-            # so only a top layer with a ReLU masks its own gy
-            own_relu = sp.relu and i == top
-            kw = dict(n_samples=S, relu=own_relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
-                      sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4],
-                      gx_relu_mask=i > 0 and specs[i - 1].relu)
-            if sp.lr:
-                grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
-                                          **kw)
-            else:
-                grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
-                                           g_log_prior=g_a, g_log_q=g_b,
-                                           w_sampled=self.wsamp[i] if (self.presample and i > 0) else None, **kw)
-            sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
-            g = grads[4]
+        self._bwd_state = (specs, saved, g_a, g_b, g_kl3, first, lr, top)
+        self._bwd_g = g
+        for i in reversed(range(1 if stop_above_layer0 else 0, len(specs))):
+            self._backward_layer(i)
         if lr:
             return out4[0:1], out4[1], out4[3:4]
         return out4[0:1], out4[1], out4[2], out4[3:4]
+
+    def _chain_layer0(self):
+        """The rest of the backward (layer 0's weight gradients): in data-parallel steps it runs beside the all-reduce of
+        the upper layers' gradients."""
+        self._backward_layer(0)
+
+    def _backward_layer(self, i: int):
+        """Backward of layer i (weight gradients into the bucket; input gradient for the layer below)."""
+        specs, saved, g_a, g_b, g_kl3, first, lr, top = self._bwd_state
+        S, g, sp = self.samples, self._bwd_g, specs[i]
+        xin, y, v, p = saved[i]
+        # layer i's ReLU mask is applied by layer i+1's input-gradient kernel (its x IS layer i's output),
+        # so only a top layer with a ReLU masks its own gy
+        own_relu = sp.relu and i == top
+        kw = dict(n_samples=S, relu=own_relu, eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id,
+                  sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4],
+                  gx_relu_mask=i > 0 and specs[i - 1].relu)
+        if sp.lr:
+            grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3, **kw)
+        else:
+            grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
+                                       g_log_prior=g_a, g_log_q=g_b,
+                                       w_sampled=self.wsamp[i] if (self.presample and i > 0) else None, **kw)
+        sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
+        self._bwd_g = grads[4]
 
     def _update(self):
         with torch.no_grad():
             self.opt.step()                          # also advances self.counter (bump_after_step)
 
-    def _allreduce(self):
+    def _allreduce_upper(self):
+        """Layers 1..: issued right behind the graph that produced them, asynchronously (the collective runs on its own
+        stream and waits for the work queued so far), so that layer 0's backward overlaps it."""
         import torch.distributed as dist
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)      # seeds already carry 1 / ranks
+        return dist.all_reduce(self.bucket[self.bucket_cut:], op=dist.ReduceOp.SUM, async_op=True)   # seeds carry 1 / ranks
+
+    def _allreduce_layer0(self):
+        import torch.distributed as dist
+        return dist.all_reduce(self.bucket[:self.bucket_cut], op=dist.ReduceOp.SUM, async_op=True)
 
     def _one_step(self):
         if not self.autograd:
             with torch.no_grad():
                 out = self._chain()
             if self.dp:
-                self._allreduce()
+                for w in (self._allreduce_upper(), self._allreduce_layer0()):
+                    w.wait()
             self._update()
             return out
         state.device_counter = self.counter
@@ -263,7 +288,11 @@ class GraphedTrainStep:
         self.opt.sync_lr()
         self.graph.replay()
         if self.dp:
-            self._allreduce()
+            w_hi = self._allreduce_upper()              # beside ...
+            self.graph_bwd0.replay()                    # ... the backward of layer 0
+            w_lo = self._allreduce_layer0()
+            w_hi.wait()
+            w_lo.wait()
             self.graph_update.replay()
         take_samples(self.samples * self.world)
         return self.out
