@@ -23,7 +23,7 @@ EXPORTS = (
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare", "bnn_bias_act",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
@@ -212,6 +212,8 @@ def load():
     lib.bnn_bbb_linear_fwd.argtypes = [C.POINTER(BbbFwdArgs), C.c_void_p]
     lib.bnn_bbb_plan.restype = C.c_int
     lib.bnn_bbb_plan.argtypes = [C.POINTER(BbbFwdArgs), C.POINTER(Plan)]
+    lib.bnn_lr_final_fwd.restype = C.c_int
+    lib.bnn_lr_final_fwd.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(FinalizeArgs), C.c_void_p]
     lib.bnn_lr_plan.restype = C.c_int
     lib.bnn_lr_plan.argtypes = [C.POINTER(LrFwdArgs), C.POINTER(Plan)]
     lib.bnn_bbb_linear_bwd_workspace_bytes.restype = C.c_size_t

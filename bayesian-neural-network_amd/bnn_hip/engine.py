@@ -209,6 +209,17 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 wfrag, ws_pre = (None, None)
                 if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]):
                     wfrag, ws_pre = ops.lr_prepare(*pd)
+                if last and fin_kw is not None and want_stats and eps_mode == L.EPS_PHILOX and fin_kw.get("scratch") is not None \
+                        and not wide_nll(layers, h.shape[-2]) and all(q.lr for q in layers):
+                    # output layer + finalize through bnn_lr_final_fwd: one launch when its row-split form applies
+                    ws_last = ws_pre if ws_pre is not None else ops.lr_workspace(sp.in_out[1], h.device)
+                    out, fin = ops.lr_final_fwd((h,) + pd, dict(w_frag=wfrag, workspace=ws_last, form=state.form, n_samples=n_local,
+                                                                sigma_p=call.prior.sigma_p, math_mode=math_mode, relu=sp.relu,
+                                                                y_dtype=call.y_dtype, eps_mode=eps_mode, seed=state.seed,
+                                                                layer_id=sp.layer_id, sample_offset=first_sample, want_kl=True,
+                                                                x_sq=h_sq if lr_sq else None),
+                                                dict(workspaces=stats + [ws_last], **fin_kw))
+                    return out["y"], fin
                 out = ops.lr_linear_fwd(h, *pd, w_frag=wfrag, workspace=ws_pre, form=state.form, n_samples=n_local, sigma_p=call.prior.sigma_p, math_mode=math_mode,
                                         relu=sp.relu, y_dtype=call.y_dtype, eps_mode=eps_mode, eps_act=e_w, eps_b=e_b,
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
@@ -324,7 +335,8 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
                           local_reparam=local_reparam, prior=layers[0].m._prior_spec, n_samples=n_local, target=target,
                           mode=mode, nll_sigma=float(sigma),
                           ticket=torch.zeros(1, dtype=torch.int32, device=dev) if n_local > 1 else None,
-                          scratch=ops.final_scratch(n_local, dev) if (not local_reparam or wide_nll(layers, x.shape[0])) else None)
+                          scratch=ops.final_scratch(n_local, dev)
+                          if (not local_reparam or wide_nll(layers, x.shape[0]) or layers[-1].in_out[1] <= 16) else None)
         fused_node = differentiable and injected is None and FUSED_ELBO_NODE and x.dtype == torch.float32 and \
             all(bool(sp.lr) == bool(local_reparam) for sp in layers)
         if fused_node:
@@ -339,7 +351,7 @@ def elbo_terms(layers: Sequence[LayerSpec], x: torch.Tensor, target: torch.Tenso
             return sums[0], sums[1], sums[2], samples
         logits, stats = run_layers(layers, x, n_local, first_global + lo, want_stats=True, sample=True,
                                    injected=injected, differentiable=differentiable,
-                                   fin_kw=fin_kw if not local_reparam else None)
+                                   fin_kw=fin_kw)
         if differentiable:
             nll = NLLFn.apply(logits, target, mode, float(sigma))
             if local_reparam:
@@ -461,7 +473,7 @@ class GraphedElbo:
         self._sums = torch.zeros((self.G, 4), dtype=torch.float32, device=dev)
         self.sums = self._sums if self.G > 1 else self._sums.view(4)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.scratch = ops.final_scratch(S, dev) if (not self.lr or wide_nll(self.specs, B)) else None
+        self.scratch = ops.final_scratch(S, dev) if (not self.lr or wide_nll(self.specs, B) or self.specs[-1].in_out[1] <= 16) else None
         # large batches: sample once per launch, then a plain library GEMM (use_library_gemm)
         self.lib = [use_library_gemm(sp, B, hid) for sp in self.specs]
         self.lib_w = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) if lb else None
@@ -540,6 +552,11 @@ class GraphedElbo:
             if self.lr:
                 if self.wfrag[i] is not None:
                     ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
+                if i == last and self.scratch is not None and not wide_nll(self.specs, self.x.shape[-2]):
+                    # output layer + finalize in one launch when the library's row-split form applies (else it issues both)
+                    ops.lr_final_fwd((h,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq, w_frag=self.wfrag[i],
+                                                    **common), dict(workspaces=self.ws, **fin_kw))
+                    return
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
                 h_sq = self.bufs_sq[i]

@@ -422,6 +422,20 @@ def lr_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **kw):
     return res
 
 
+def lr_final_fwd(layer_args: tuple, layer_kw: dict, fin_kw: dict):
+    """Last LR layer + ELBO finalize through bnn_lr_final_fwd (one launch when the layer is narrow and the evaluation
+    has few samples, else the two launches).  `fin_kw["workspaces"]` lists the KL workspaces of ALL layers (the last
+    one's is filled only by the two-launch form); `logits` is taken from the layer call.
+    Returns (layer result dict, finalize result dict)."""
+    lib = L.load()
+    a, res, keep1 = _lr_build(*layer_args, **layer_kw)
+    fin_kw = dict(fin_kw)
+    fin_kw["logits"] = res["y"]
+    f, out, keep2 = _fin_build(**fin_kw)
+    L.check(lib.bnn_lr_final_fwd(C.byref(a), C.byref(f), _stream()), "bnn_lr_final_fwd")
+    return res, out
+
+
 def lr_plan(x, w_mu, w_rho, b_mu, b_rho, **kw) -> dict:
     """bnn_lr_plan: the launch geometry lr_linear_fwd would use for these arguments (no launch)."""
     a, res, keep = _lr_build(x, w_mu, w_rho, b_mu, b_rho, **kw)

@@ -896,6 +896,295 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
 #endif
 }
 
+// K3r  the output layer of a few-sample LR evaluation, split by batch rows, with the finalize: the LR counterpart of
+// bbb_final_rows_kernel.  Grid: per sample RB = ceil(B / 16) row blocks + 1 statistics block, 256 threads each.
+//   row block : m = x . M and v = x^2 . sigma^2 of its 16 batch rows for all (<= 16) output features (4 waves split the
+//               k-steps; the [in,out] weights of a 10-column layer are 48 KB per tensor and stay in L2), activation noise
+//               and bias in the D layout (networks.py:120-128), logits stored, the rows' NLL (networks.py:183-190);
+//   stats     : the KL of every layer (networks.py:109-114, :179-181): the layers below from their KL workspaces, this
+//               layer's closed-form sums from its own parameters.
+// Hand-off as in bbb_final_rows_kernel (nobody waits): each block publishes its scalar(s) write-through, drains, takes
+// the sample's ticket; the last one folds them in a fixed order and writes the sample's outputs; samples meet the
+// same way.  A separate K3a launch + bnn_elbo_finalize cost 9.4 + 7.3 us and two launch boundaries at one sample.
+struct LrRows {
+  const __bf16* x;      // [S | shared, B, K]
+  long x_sstride;
+  int xg;
+  const float *w_mu, *w_rho, *b_mu, *b_rho;   // [K, N], [N]
+  float* y;             // [S, B, N]
+  int S, B, K, N, relu;
+  uint32_t k0, k1, layer_id, sample_offset;
+  const uint32_t* sample_counter;
+  uint32_t sgrp, sgrp_stride;
+  uint32_t* tickets;    // [S], zero between launches
+  float* parts;         // [S][16]: 0..7 the row blocks' NLL, 8 the KL
+};
+constexpr int kRowsBatch = 12;   // 16-byte loads of each weight tensor a thread keeps in flight (12 x 256 x 4 = the 1200 x 10 layer)
+constexpr int kRowsX = 10;       // x fragments a wave requests up front (4 waves x 10 k-steps = K up to 1280)
+struct LrFin {
+  FinK k;
+  FinC c;
+  float* sums;
+  uint32_t* ticket;
+};
+
+__global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, const LrFin fp) {
+  __shared__ __attribute__((aligned(16))) f32x4 red_m[4][64], red_v[4][64];
+  __shared__ float lg[16][17];
+  __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
+  __shared__ float kl_red[4 * 3];
+  extern __shared__ __attribute__((aligned(16))) __bf16 wfrag_s[];     // 2 x ceil(K / 32) x 4 x 16 x 8 bf16
+  const FinK& fk = fp.k;
+  const int RB = (p.B + 15) >> 4;
+  const int s = (int)blockIdx.x / (RB + 1), rb = (int)blockIdx.x - s * (RB + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = p.K, N = p.N, B = p.B;
+  uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
+  if (p.sgrp == 0u) gs += (uint32_t)s;
+  else gs += ((uint32_t)s / p.sgrp) * p.sgrp_stride + (uint32_t)s % p.sgrp;
+  const bool vec4 = !((reinterpret_cast<uintptr_t>(p.w_mu) | reinterpret_cast<uintptr_t>(p.w_rho)) & 15);
+  float pub0 = 0.f;
+  int slot = rb;
+  if (rb == RB) {
+    // ---- statistics block: this layer's closed-form KL sums from its parameters, the layers below from their workspaces
+    float ls = 0.f, s2 = 0.f, m2 = 0.f;
+    auto kl_term = [&](float mu, float rho) {
+      const float sig = softplus(rho);
+      ls += fast_log(sig);
+      s2 = __builtin_fmaf(sig, sig, s2);
+      m2 = __builtin_fmaf(mu, mu, m2);
+    };
+    const int KN = K * N, n4 = vec4 ? KN >> 2 : 0;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * kRowsBatch) {   // kRowsBatch 16-byte loads of each tensor in flight
+      float4 a[kRowsBatch], b[kRowsBatch];
+#pragma unroll
+      for (int u = 0; u < kRowsBatch; ++u) {
+        const int i = min(i0 + u * 256, n4 - 1);
+        a[u] = reinterpret_cast<const float4*>(p.w_mu)[i];
+        b[u] = reinterpret_cast<const float4*>(p.w_rho)[i];
+      }
+#pragma unroll
+      for (int u = 0; u < kRowsBatch; ++u)
+        if (i0 + u * 256 < n4) {
+          kl_term(a[u].x, b[u].x); kl_term(a[u].y, b[u].y); kl_term(a[u].z, b[u].z); kl_term(a[u].w, b[u].w);
+        }
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < KN + N; i += 256) {
+      const bool w = i < KN;
+      kl_term(w ? p.w_mu[i] : p.b_mu[i - KN], w ? p.w_rho[i] : p.b_rho[i - KN]);
+    }
+    const float a0 = wave_sum(ls), a1 = wave_sum(s2), a2 = wave_sum(m2);
+    if (lane == 0) {
+      kl_red[wave * 3 + 0] = a0;
+      kl_red[wave * 3 + 1] = a1;
+      kl_red[wave * 3 + 2] = a2;
+    }
+    __syncthreads();
+    float own0 = 0.f, own1 = 0.f, own2 = 0.f;
+    for (int wv = 0; wv < 4; ++wv) {
+      own0 += kl_red[wv * 3 + 0];
+      own1 += kl_red[wv * 3 + 1];
+      own2 += kl_red[wv * 3 + 2];
+    }
+    const int own_layer = fk.n_layers - 1;
+    int T[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      T[l] = (l < own_layer) ? __float_as_int(reinterpret_cast<const float4*>(fk.ws[l])[0].x) : 0;
+    float a = 0.f, b = 0.f, nll = 0.f;
+    fin_sample(fk, fp.c, s, T, nullptr, 0, own_layer, own0, own1, own2, part, a, b, nll);
+    pub0 = a;
+    slot = 8;
+  } else {
+    const int r = lane & 15, q = lane >> 4;
+    const int row = min(rb * 16 + r, B - 1);
+    const __bf16* xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
+    const int ksteps = (K + 31) >> 5;
+    // ---- the layer's weights, once per block: whole-line reads of the [K, N] matrices (a lane gathering its fragment
+    // straight from them -- 16 four-byte loads per k-step, ten dependent rounds per wave -- made this kernel 14 us),
+    // bf16 M and sigma^2 parked in LDS in fragment order: [k / 8][feature 0..15][k % 8], 16 bytes per (octet, feature)
+    __bf16* const m_s = wfrag_s;
+    __bf16* const v_s = wfrag_s + (size_t)ksteps * 4 * 16 * 8;
+    // zero what no weight will fill: the padding features (n >= N) of every octet and the octets past K
+    const int pad = 16 - N, octs = ksteps * 4, full = K >> 3;
+    for (int i = threadIdx.x; i < octs * pad; i += 256) {
+      const int o = i / pad, n = N + (i - o * pad);
+      reinterpret_cast<float4*>(m_s)[o * 16 + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(v_s)[o * 16 + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = threadIdx.x; i < (octs - full) * N; i += 256) {
+      const int o = full + i / N, n = i % N;
+      reinterpret_cast<float4*>(m_s)[o * 16 + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(v_s)[o * 16 + n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_n = 1.0f / (float)N;
+    auto park = [&](int i, float mu, float rho) {               // element i = k * N + n
+      int k = (int)((float)i * inv_n);                          // i / N without the integer divide (i < 2^24: one fix-up)
+      k += ((k + 1) * N <= i) ? 1 : 0;
+      k -= (k * N > i) ? 1 : 0;
+      const int n = i - k * N;
+      const float sig = softplus(rho);
+      const int at = ((k >> 3) * 16 + n) * 8 + (k & 7);
+      m_s[at] = (__bf16)mu;
+      v_s[at] = (__bf16)(sig * sig);
+    };
+    // this wave's x fragments (its first kRowsX k-steps) go out BEFORE the weights: one round trip covers both
+    float4 xq[kRowsX];
+#pragma unroll
+    for (int u = 0; u < kRowsX; ++u)
+      xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+    {
+      const int KN = K * N, n4 = vec4 ? KN >> 2 : 0;
+      for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * kRowsBatch) {
+        float4 a[kRowsBatch], b[kRowsBatch];
+#pragma unroll
+        for (int u = 0; u < kRowsBatch; ++u) {
+          const int i = min(i0 + u * 256, n4 - 1);
+          a[u] = reinterpret_cast<const float4*>(p.w_mu)[i];
+          b[u] = reinterpret_cast<const float4*>(p.w_rho)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kRowsBatch; ++u) {
+          const int i = i0 + u * 256;
+          if (i < n4) {
+            park(4 * i, a[u].x, b[u].x); park(4 * i + 1, a[u].y, b[u].y); park(4 * i + 2, a[u].z, b[u].z); park(4 * i + 3, a[u].w, b[u].w);
+          }
+        }
+      }
+      for (int i = n4 * 4 + threadIdx.x; i < KN; i += 256) park(i, p.w_mu[i], p.w_rho[i]);
+    }
+    __syncthreads();
+    f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f}, av = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kRowsX + 0; ++u) {                      // the prefetched steps, then (long K only) the rest
+      const int t = wave + 4 * u;
+      if (t >= ksteps) break;
+      const int k = t * 32 + q * 8;
+      const bf16x8 xb = __builtin_bit_cast(bf16x8, xq[u]);
+      const bf16x8 ma = *reinterpret_cast<const bf16x8*>(m_s + ((size_t)(t * 4 + q) * 16 + r) * 8);
+      const bf16x8 sa = *reinterpret_cast<const bf16x8*>(v_s + ((size_t)(t * 4 + q) * 16 + r) * 8);
+      bf16x8 xz, x2b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (k < K) ? (float)xb[j] : 0.f;
+        xz[j] = (__bf16)xv;
+        x2b[j] = (__bf16)(xv * xv);
+      }
+      am = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xz, am, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, x2b, av, 0, 0, 0);
+    }
+#pragma unroll 2
+    for (int t = wave + 4 * kRowsX; t < ksteps; t += 4) {
+      const int k = t * 32 + q * 8;
+      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xr + min(k, K - 8));
+      const bf16x8 ma = *reinterpret_cast<const bf16x8*>(m_s + ((size_t)(t * 4 + q) * 16 + r) * 8);
+      const bf16x8 sa = *reinterpret_cast<const bf16x8*>(v_s + ((size_t)(t * 4 + q) * 16 + r) * 8);
+      bf16x8 xz, x2b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (k + j < K && k <= K - 8) ? (float)xb[j] : 0.f;   // (K % 8 == 0: a fragment is whole or absent)
+        xz[j] = (__bf16)xv;
+        x2b[j] = (__bf16)(xv * xv);
+      }
+      am = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, xz, am, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, x2b, av, 0, 0, 0);
+    }
+    red_m[wave][lane] = am;
+    red_v[wave][lane] = av;
+    __syncthreads();
+    if (wave == 0) {
+      // lane (r = batch row of the block, q): features 4q .. 4q+3
+      f32x4 m = red_m[0][lane], v = red_v[0][lane];
+#pragma unroll
+      for (int wv = 1; wv < 4; ++wv) {
+        m += red_m[wv][lane];
+        v += red_v[wv][lane];
+      }
+      const int brow = rb * 16 + r;
+      const int gprN = (N + 3) >> 2;
+      float ea[4], eb[4];
+      philox_normal4((uint32_t)min(brow, B - 1) * (uint32_t)gprN + (uint32_t)q, gs, p.layer_id * 4u + 2u, p.k0, p.k1, ea);
+      philox_normal4((uint32_t)q, gs, p.layer_id * 4u + 1u, p.k0, p.k1, eb);
+      float o4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = q * 4 + i;
+        const float bias = n < N ? __builtin_fmaf(softplus(p.b_rho[n]), eb[i], p.b_mu[n]) : 0.f;
+        float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(v[i]), ea[i], m[i]) + bias;
+        if (p.relu) o = fmaxf(o, 0.f);
+        o4[i] = o;
+        lg[r][n] = o;
+      }
+      if (brow < B) {
+        float* yp = p.y + ((size_t)s * B + brow) * N + q * 4;
+        if ((N & 3) == 0 && q * 4 < N) {
+          *reinterpret_cast<float4*>(yp) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < N) yp[i] = o4[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // ---- NLL of the block's rows: lane r < 16 takes row r
+      float acc_n = 0.f;
+      const int brow = rb * 16 + lane;
+      if (lane < 16 && brow < B && fk.nll) {
+        const int C = fk.C;
+        if (fk.nll_mode == BNN_NLL_CLASSIFICATION) {
+          const long long* tgt = reinterpret_cast<const long long*>(fk.target) + (fk.group > 0 ? (s / fk.group) * fk.tgt_stride : 0);
+          const long long tc = tgt[brow];
+          float mx = -3.0e38f, se = 0.f;
+          for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[lane][c]);
+          for (int c = 0; c < C; ++c) se += __expf(lg[lane][c] - mx);
+          const float picked = (tc >= 0 && tc < C) ? lg[lane][(int)tc] : __builtin_nanf("");
+          acc_n = (mx + __logf(se)) - picked;
+        } else {
+          const float* tgt = reinterpret_cast<const float*>(fk.target) + (fk.group > 0 ? (s / fk.group) * fk.tgt_stride : 0);
+          for (int c = 0; c < C; ++c) {
+            const float d = tgt[(size_t)brow * C + c] - lg[lane][c];
+            acc_n += (float)((double)(d * d) * fp.c.reg_inv2var + fp.c.reg_const);
+          }
+        }
+      }
+      pub0 = wave_sum(acc_n);
+    }
+  }
+  if (threadIdx.x != 0) return;
+  float* mine = p.parts + (size_t)s * 16;
+  __hip_atomic_store(mine + slot, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t tk = __hip_atomic_fetch_add(p.tickets + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tk != (uint32_t)RB) return;                           // RB + 1 blocks per sample
+  float pv[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pv[i] = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one round trip
+  double tn = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < RB) tn += pv[i];
+  const float a = pv[8];
+  const float nll = (float)tn;
+  __hip_atomic_store(p.tickets + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  if (fk.kl) __hip_atomic_store(fk.kl + s, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.nll) __hip_atomic_store(fk.nll + s, nll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.S == 1) {
+    if (fp.sums) {
+      fp.sums[0] = a; fp.sums[1] = 0.f; fp.sums[2] = nll; fp.sums[3] = 1.f;
+    }
+    if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t2 = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t2 != (uint32_t)fk.S - 1u) return;
+  if (fp.sums) fin_fold_sums(fk, fp.sums);
+  __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
+}
+
 // KL of one LR layer from its partials (networks.py:113, :134-136).  The partials fold
 // weights and biases together (the network only needs the total); the bias term is small
 // (N elements) and is recomputed here so that weight_kl_cost / bias_kl_cost can be
@@ -1167,4 +1456,53 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     if (err != hipSuccess) return (int)err;
   }
   return BNN_OK;
+}
+
+extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);   // bbb_linear.hip: the same scratch layout serves K3r
+
+// Last LR layer + ELBO finalize: ONE launch (K3r) for a few-sample evaluation with a narrow output layer, else
+// bnn_lr_linear_fwd followed by bnn_elbo_finalize.
+extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
+  LrK k;
+  int rc = lr_fill(a, k);
+  if (rc != BNN_OK) return rc;
+  LrFin fp;
+  rc = make_fin(f, fp.k, fp.c);
+  if (rc != BNN_OK) return rc;
+  const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features, nl = f->n_layers;
+  const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 16 &&
+                    (K % 8) == 0 && K <= 2048 && !(reinterpret_cast<uintptr_t>(a->x) & 15) && a->eps_mode == BNN_EPS_PHILOX &&
+                    !a->eps_act_dump && !a->eps_b_dump && !a->v_out && !a->y_sq && !a->kl_out && a->form == BNN_FORM_AUTO &&
+                    f->local_reparam && nl >= 1 && nl <= 8 && f->n_samples == S && f->classes == N && f->batch == B &&
+                    f->logits == a->y && f->nll && f->kl && f->layer_in[nl - 1] == K && f->layer_out[nl - 1] == N &&
+                    f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
+                    !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) &&
+                    (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(a->y) & 15));
+  if (!rows) {
+    rc = bnn_lr_linear_fwd(a, stream_);
+    return rc != BNN_OK ? rc : bnn_elbo_finalize(f, stream_);
+  }
+  LrRows r;
+  r.x = reinterpret_cast<const __bf16*>(a->x);
+  r.x_sstride = k.x_sstride; r.xg = k.xg;
+  r.w_mu = a->w_mu; r.w_rho = a->w_rho; r.b_mu = a->b_mu; r.b_rho = a->b_rho;
+  r.y = reinterpret_cast<float*>(a->y);
+  r.S = S; r.B = B; r.K = K; r.N = N; r.relu = a->relu ? 1 : 0;
+  r.k0 = k.k0; r.k1 = k.k1; r.layer_id = k.layer_id; r.sample_offset = k.sample_offset; r.sample_counter = k.sample_counter;
+  r.sgrp = k.sgrp; r.sgrp_stride = k.sgrp_stride;
+  char* base = reinterpret_cast<char*>(f->scratch);
+  r.tickets = reinterpret_cast<uint32_t*>(base);
+  r.parts = reinterpret_cast<float*>(base + (((size_t)S * 4 + 255) / 256) * 256);
+  fp.sums = f->sums;
+  fp.ticket = f->ticket;
+  const int RB = (B + 15) / 16;
+  const size_t lds = (size_t)2 * ((K + 31) / 32) * 4 * 16 * 8 * 2;       // bf16 M and sigma^2 fragments of the whole layer
+  if (lds > 64 * 1024) {
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_final_rows_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e0 != hipSuccess) return (int)e0;
+  }
+  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp);
+  const hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -385,6 +385,16 @@ typedef struct bnn_finalize_args {
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
 
+/* bnn_lr_final_fwd — the LAST BayesianLinearLR layer of an evaluation together with its finalize
+ * (networks.py:116-138 + :179-190): the same results as bnn_lr_linear_fwd(layer) followed by bnn_elbo_finalize(fin)
+ * with fin->logits == layer->y, in ONE launch when the layer is narrow (<= 16 outputs, batch <= 128, <= 16 samples,
+ * bf16 math and x, on-chip eps; fin->scratch as for bnn_bbb_final_fwd and, above one sample, fin->ticket): row blocks
+ * compute the logits and the rows' NLL, one more block per sample the KL of all layers (this layer's from its
+ * parameters: fin->layer_workspace[n_layers-1] is not read), the last block to arrive folds them.  Otherwise the two
+ * launches. */
+struct bnn_finalize_args;
+int bnn_lr_final_fwd(const bnn_lr_fwd_args* layer, const struct bnn_finalize_args* fin, void* stream);
+
 /* bnn_bbb_final_fwd — the LAST BBB layer of an evaluation together with its finalize: the
  * same results as bnn_bbb_linear_fwd(layer) followed by bnn_elbo_finalize(fin) with
  * fin->logits == layer->y and fin->layer_workspace[n_layers-1] == layer->workspace, but in ONE
