@@ -176,9 +176,19 @@ class GraphedTrainStep:
                       ticket=self.fin_ticket if S > 1 else None)
         for i, sp in enumerate(specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            if not lr and i == len(specs) - 1 and self.presample:
+                # output layer + finalize in one launch over the weights the sampling launch drew: split by batch rows
+                # when it is a single feature tile (K1r), else matmul + finalize
+                res, fin = ops.bbb_final_fwd((h, None, None, None, None),
+                                             dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math, relu=sp.relu,
+                                                  y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=False,
+                                                  w_sampled=self.wsamp[i], b_sampled=self.bsamp[i]),
+                                             dict(workspaces=wss + [self.wstat[i]], scratch=self.fin_scratch, **fin_kw))
+                saved.append((h, res["y"], None, p))
+                h = res["y"]
+                continue
             if not lr and i == len(specs) - 1:
-                # output layer + finalize in one launch (it samples its own few weights -- the same Philox elements the
-                # sampling launch drew for the backward's w_sampled)
+                # output layer + finalize in one launch (it samples its own few weights)
                 res, fin = ops.bbb_final_fwd((h,) + p, dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math,
                                                             relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                                                             seed=state.seed, layer_id=sp.layer_id, sample_offset=first,

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(768) void bbb_fwd_rider_kernel(const BbbK p, const 
 // relaxed atomic store = sc1), drains (vmcnt(0)) and takes a ticket; the block whose ticket is last reads the RB + 2
 // scalars back with agent-scope loads, in a fixed order, and writes the sample's outputs.  Samples meet the same way.
 struct FinRows {
-  const __bf16* x;      // [S | shared, B, K]
+  const void* x;        // [S | shared, B, K], bf16 or (XF32: the training step's saved activations) fp32 rounded here
   long x_sstride;
   int xg;
   const __bf16* w;      // [S, N, K]
@@ -727,6 +727,7 @@ struct FinRows {
   float* parts;         // [S][16]: 0..7 the row blocks' NLL, 8 / 9 log p (KL) / log q
 };
 
+template <bool XF32>
 __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, const FinPack fp) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4][64];
   __shared__ float lg[16][17];
@@ -751,18 +752,25 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
     const int r = lane & 15, q = lane >> 4;
     const int K = p.K, N = p.N, B = p.B;
     const int row = min(rb * 16 + r, B - 1);
-    const __bf16* xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
+    const size_t xoff = (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
+    const __bf16* xr = reinterpret_cast<const __bf16*>(p.x) + xoff;
+    const float* xr32 = reinterpret_cast<const float*>(p.x) + xoff;
     const __bf16* wr = p.w + ((size_t)s * N + min(r, N - 1)) * K;
     const int ksteps = (K + 31) >> 5;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int U = 10;                                   // k-steps in flight per wave: 38 steps of the 1200-wide layer = one round
     for (int base = wave; base < ksteps; base += 4 * U) {
-      float4 xa[U], wa[U];
+      float4 xa[U], xh[XF32 ? U : 1], wa[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = (base + 4 * u) * 32 + q * 8;
         const int kk = min(k, K - 8);
-        xa[u] = *reinterpret_cast<const float4*>(xr + kk);
+        if (XF32) {
+          xa[u] = *reinterpret_cast<const float4*>(xr32 + kk);
+          xh[u] = *reinterpret_cast<const float4*>(xr32 + kk + 4);
+        } else {
+          xa[u] = *reinterpret_cast<const float4*>(xr + kk);
+        }
         wa[u] = *reinterpret_cast<const float4*>(wr + kk);
       }
 #pragma unroll
@@ -770,7 +778,15 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
         const int k = (base + 4 * u) * 32 + q * 8;
         const bool ok = (base + 4 * u) < ksteps && k < K && r < N;    // past the reduction / a padding feature: zero weights
         const float4 wz = ok ? wa[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wz), __builtin_bit_cast(bf16x8, xa[u]), acc, 0, 0, 0);
+        bf16x8 xb;
+        if (XF32) {
+          const float xv[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xh[u].x, xh[u].y, xh[u].z, xh[u].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xb[j] = (__bf16)xv[j];
+        } else {
+          xb = __builtin_bit_cast(bf16x8, xa[u]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wz), xb, acc, 0, 0, 0);
       }
     }
     red[wave][lane] = acc;
@@ -1611,7 +1627,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   if (a->w_sampled) {
     // ---- pre-sampled output layer: the row-split form (K1r) when the shapes allow it, else matmul-only K1 + K4
     const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features;
-    const bool rows = a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 64 && !f->local_reparam &&
+    const bool rows = a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 64 && !f->local_reparam &&
                       nl >= 1 && f->n_samples == S && f->classes == N && f->batch == B && f->logits == a->y && f->nll &&
                       f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
                       !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) && !a->rider &&
@@ -1621,7 +1637,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
       return rc != BNN_OK ? rc : bnn_elbo_finalize(f, stream_);
     }
     FinRows fr;
-    fr.x = reinterpret_cast<const __bf16*>(a->x);
+    fr.x = a->x;
     fr.x_sstride = k.x_sstride; fr.xg = k.xg;
     fr.w = k.w_pre; fr.b = k.b_pre;
     fr.y = reinterpret_cast<float*>(a->y);
@@ -1633,8 +1649,12 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
     fp.ticket = f->ticket;
     fp.ks = 1; fp.ks_ticket = nullptr; fp.ks_stats = nullptr; fp.ks_tiles = nullptr;
     const int RB = (B + 15) / 16;
-    hipLaunchKernelGGL(bbb_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
-                       fr, fp);
+    if (a->x_dtype == BNN_BF16)
+      hipLaunchKernelGGL(bbb_final_rows_kernel<false>, dim3((unsigned)(S * (RB + 1))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                         fr, fp);
+    else
+      hipLaunchKernelGGL(bbb_final_rows_kernel<true>, dim3((unsigned)(S * (RB + 1))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                         fr, fp);
     const hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? BNN_OK : (int)e2;
   }

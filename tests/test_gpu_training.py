@@ -201,6 +201,38 @@ def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
         assert float(masked[4].abs().max()) > 0
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_narrow_output_layer_backward_equals_the_general_kernels(relu):
+    """bnn_bbb_linear_bwd over the step's sampled weights: an output layer of <= 16 features takes ONE launch
+    (bbb_out_layer_bwd_kernel, plain fp32 FMAs); the same call without w_sampled runs the general weight-gradient
+    kernel and the transposed-generator input gradient.  Same Philox elements, same bf16 rounding of gz and w in the
+    input gradient: they agree to summation order."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(21)
+    for S, B, K, N, prior in ((2, 128, 1200, 10, ops.PriorSpec(False, 1.0)), (3, 20, 72, 1, ops.PriorSpec(True, 1.0, 0.5, 1.0, 0.0025)),
+                              (1, 7, 40, 16, ops.PriorSpec(False, 0.7)), (5, 200, 56, 3, ops.PriorSpec(False, 1.0))):
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1))
+        gy = mk(S, B, N, lo=-1, hi=1)
+        y = mk(S, B, N, lo=-1, hi=1) if relu else None
+        w_mu, w_rho, b_mu, b_rho = mk(N, K), mk(N, K, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
+        glp, glq = mk(S, lo=-0.5, hi=-0.1), mk(S, lo=0.1, hi=0.5)
+        seed, layer_id, first = 11, 2, 40
+        eps = ops.philox_normal(seed, 4 * layer_id, first, S, N, K, dev)
+        w_s = (w_mu + torch.log1p(torch.exp(w_rho)) * eps).to(torch.bfloat16).contiguous()
+        kw = dict(n_samples=S, prior=prior, math_mode=L.MATH_BF16, relu=relu, eps_mode=L.EPS_PHILOX, seed=seed, layer_id=layer_id,
+                  sample_offset=first, g_log_prior=glp, g_log_q=glq, gx_relu_mask=True)
+        one = ops.bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, w_sampled=w_s, **kw)
+        ref = ops.bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, **kw)
+        for a, b in zip(one[:4], ref[:4]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (S, B, K, N)
+        # the generator's bf16(w) and the bf16 of the fp32 w formed here may differ by one ulp in a few elements
+        assert float((one[4] - ref[4]).norm()) <= 2e-3 * float(ref[4].norm()), (S, B, K, N)
+        assert float(ref[4].abs().max()) > 0
+        assert torch.equal(one[4] == 0, ref[4] == 0) or float(((one[4] == 0) != (ref[4] == 0)).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize("autograd", [False, True])
 @pytest.mark.parametrize("local_reparam", [False, True])
 def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
