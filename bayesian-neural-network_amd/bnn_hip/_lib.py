@@ -149,6 +149,11 @@ class AdamArgs(C.Structure):
     ]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("beta", C.c_void_p), ("total_samples", C.c_float), ("grad_scale", C.c_float), ("out4", C.c_void_p),
+                ("g_a", C.c_void_p), ("g_b", C.c_void_p), ("g_kl3", C.c_void_p), ("g_logits", C.c_void_p)]
+
+
 class FinalizeArgs(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_uint32),
@@ -162,6 +167,7 @@ class FinalizeArgs(C.Structure):
         ("sample_counter", C.c_void_p), ("sample_counter_inc", C.c_uint32), ("reserved", C.c_uint32),
         ("sums", C.c_void_p), ("ticket", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
         ("group_samples", C.c_int32), ("target_per_group", C.c_int32),
+        ("loss", C.POINTER(LossArgs)),
     ]
 
 

@@ -462,9 +462,11 @@ def gauss_kl(mu: torch.Tensor, rho: torch.Tensor, sigma_p: float) -> torch.Tenso
 def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: PriorSpec, n_samples: int,
                logits: Optional[torch.Tensor], target: Optional[torch.Tensor], mode: Optional[str],
                nll_sigma: float = 1.0, sample_counter=None, sample_counter_inc: int = 0, out=None, sums=None,
-               ticket=None, scratch=None, group_samples: int = 0):
+               ticket=None, scratch=None, group_samples: int = 0, loss=None):
     """`group_samples` g > 0: the n_samples are G = n_samples / g independent minibatches of g MC samples each;
-    `target` may then hold one target block per minibatch ([G, batch] / [G, batch, classes]) and `sums` is [G, 4]."""
+    `target` may then hold one target block per minibatch ([G, batch] / [G, batch, classes]) and `sums` is [G, 4].
+    `loss` = dict(beta=device scalar, total_samples=, grad_scale=): the training step's tail (bnn_loss_args); its
+    results come back as out["loss"] = (out4, g_a, g_b, g_kl3, g_logits)."""
     n_layers = len(workspaces)
     dev = logits.device if logits is not None else workspaces[0].device
     a = L.FinalizeArgs()
@@ -519,6 +521,19 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
     a.scratch_bytes = scratch.numel() * scratch.element_size() if scratch is not None else 0
     a.log_prior, a.log_q, a.kl, a.nll = _ptr(out["log_prior"]), _ptr(out["log_q"]), _ptr(out["kl"]), _ptr(out["nll"])
     keep += [sample_counter, sums, ticket, scratch] + list(workspaces)
+    if loss is not None:
+        if logits is None or group_samples:
+            raise BnnHipError("the loss tail needs the logits of ONE evaluation")
+        require_device(loss["beta"])
+        la = L.LossArgs()
+        res = (torch.empty(4, dtype=torch.float32, device=dev), torch.empty(n_samples, dtype=torch.float32, device=dev),
+               torch.empty(n_samples, dtype=torch.float32, device=dev), torch.empty(3, dtype=torch.float32, device=dev),
+               torch.empty_like(lg))
+        la.beta, la.total_samples, la.grad_scale = loss["beta"].data_ptr(), float(loss["total_samples"]), float(loss.get("grad_scale", 1.0))
+        la.out4, la.g_a, la.g_b, la.g_kl3, la.g_logits = (t.data_ptr() for t in res)
+        a.loss = C.pointer(la)
+        out["loss"] = res
+        keep += [la, loss["beta"]] + list(res)
     return a, out, keep
 
 

@@ -347,6 +347,21 @@ int bnn_gauss_kl(const float* mu, const float* rho, int64_t n, float sigma_p, vo
  * Philox sample index therefore has a device-resident part that the layer kernels read and
  * this kernel (the last of an evaluation, stream-ordered after them) advances.
  * ---------------------------------------------------------------------------------- */
+/* The tail of a training step's forward, optional in bnn_finalize_args: what bnn_elbo_loss_nll_bwd computes (loss
+ * assembly networks.py:205-208, the backward seeds, d nll / d logits), done by the launch that finalizes when that
+ * launch is bnn_bbb_final_fwd's row-split form (each row block differentiates its own rows' NLL, the last block to
+ * arrive assembles the loss), else by a follow-up launch.  Arguments as for bnn_elbo_loss_nll_bwd. */
+typedef struct bnn_loss_args {
+  const float* beta;                /* device scalar */
+  float total_samples;
+  float grad_scale;
+  float* out4;
+  float* g_a;                       /* [n_samples]: d loss / d log p[s] (zeros for LR) */
+  float* g_b;                       /* [n_samples]: d loss / d log q[s] */
+  float* g_kl3;                     /* float[3] or NULL */
+  float* g_logits;                  /* [n_samples,batch,classes] */
+} bnn_loss_args;
+
 typedef struct bnn_finalize_args {
   uint32_t struct_bytes;
   int32_t n_layers;                 /* 0..8 */
@@ -381,6 +396,8 @@ typedef struct bnn_finalize_args {
                                        minibatches of g MC samples each (see bnn_bbb_fwd_args): `sums` is then
                                        float[G][4], one 4-vector per minibatch */
   int32_t target_per_group;         /* with group_samples: 0 = one target for all, 1 = target[G][batch(,classes)] */
+  const bnn_loss_args* loss;        /* optional (host pointer, read during the call): see bnn_loss_args.  Honoured by
+                                       bnn_bbb_final_fwd; one evaluation only (group_samples == 0) */
 } bnn_finalize_args;
 
 int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);

@@ -201,6 +201,48 @@ def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
         assert float(masked[4].abs().max()) > 0
 
 
+@pytest.mark.parametrize("mode", ["classification", "regression"])
+def test_loss_tail_on_the_final_launch_equals_the_separate_launch(mode):
+    """bnn_finalize_args.loss: the row-split final launch (bnn_bbb_final_fwd over sampled weights) also differentiates
+    the rows' NLL and assembles the loss and the seeds; bnn_elbo_loss_nll_bwd on the same per-sample scalars and logits
+    is the reference.  fp32 activations (the training step's) and bf16 ones; a wide layer takes the follow-up launch."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(33)
+    shapes = ((1, 128, 1200, 10), (2, 128, 1200, 10), (5, 37, 64, 3), (2, 16, 64, 24)) if mode == "classification" else \
+        ((1, 128, 56, 1), (3, 50, 400, 1))
+    for S, B, K, N in shapes:
+        for xdt in (torch.float32, torch.bfloat16):
+            mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+            prior = ops.PriorSpec(False, 1.0)
+            w_mu, w_rho, b_mu, b_rho = mk(N, K), mk(N, K, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4)
+            wsamp = torch.empty((S, N, K), dtype=torch.bfloat16, device=dev)
+            bsamp = torch.empty((S, N), dtype=torch.float32, device=dev)
+            wstat = ops.sample_workspace(S, K, N, dev)
+            ops.bbb_sample_weights([dict(w_mu=w_mu, w_rho=w_rho, b_mu=b_mu, b_rho=b_rho, prior=prior, layer_id=2, workspace=wstat,
+                                         w_out=wsamp, b_out=bsamp)], n_samples=S, seed=5, sample_offset=9, sample_counter=None)
+            x = torch.relu(mk(S, B, K, lo=-1, hi=1)).to(xdt).contiguous()
+            y = (torch.from_numpy(rs.randint(0, N, B)).to(dev) if mode == "classification" else mk(B, N, lo=-1, hi=1))
+            beta = torch.full((), 0.37, dtype=torch.float32, device=dev)
+            fin_kw = dict(layer_in=[K], layer_out=[N], local_reparam=False, prior=prior, n_samples=S, target=y, mode=mode,
+                          nll_sigma=0.3, ticket=torch.zeros(1, dtype=torch.int32, device=dev) if S > 1 else None)
+            res, fin = ops.bbb_final_fwd((x, None, None, None, None),
+                                         dict(n_samples=S, prior=prior, math_mode=L.MATH_BF16, relu=False, y_dtype=torch.float32,
+                                              eps_mode=L.EPS_ZERO, want_stats=False, w_sampled=wsamp, b_sampled=bsamp),
+                                         dict(workspaces=[wstat], scratch=ops.final_scratch(S, dev),
+                                              loss=dict(beta=beta, total_samples=S, grad_scale=0.5), **fin_kw))
+            ref = ops.elbo_loss_nll_bwd(fin["log_prior"], fin["log_q"], fin["nll"], beta, S, False, res["y"], y, mode, 0.3,
+                                        grad_scale=0.5)
+            got = fin["loss"]
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(got, ref)):
+                assert torch.isfinite(b).all()
+                assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, (mode, S, B, K, N, xdt, i)
+            # the logits themselves: the matmul over the sampled weights, bf16-rounded activations
+            want = torch.einsum("sbk,snk->sbn", x.to(torch.bfloat16).float(), wsamp.float()) + bsamp[:, None, :]
+            assert float((res["y"] - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("relu", [False, True])
 def test_narrow_output_layer_backward_equals_the_general_kernels(relu):
     """bnn_bbb_linear_bwd over the step's sampled weights: an output layer of <= 16 features takes ONE launch

@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     pairs = [("bnn_bbb_fwd_args", _lib.BbbFwdArgs), ("bnn_lr_fwd_args", _lib.LrFwdArgs),
              ("bnn_finalize_args", _lib.FinalizeArgs), ("bnn_bbb_bwd_args", _lib.BbbBwdArgs),
              ("bnn_lr_bwd_args", _lib.LrBwdArgs), ("bnn_adam_args", _lib.AdamArgs), ("bnn_prior", _lib.Prior),
-             ("bnn_prepare_args", _lib.PrepareArgs)]
+             ("bnn_prepare_args", _lib.PrepareArgs), ("bnn_loss_args", _lib.LossArgs)]
     lines, want = [], []
     for cname, cls in pairs:
         lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
