@@ -22,7 +22,7 @@ EXPORTS = (
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_split_scratch_bytes", "bnn_bbb_split_scratch_zero_bytes", "bnn_bbb_linear_fwd",
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
-    "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
+    "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_stage_inputs_cast", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare", "bnn_bias_act",
@@ -93,6 +93,7 @@ class LrFwdArgs(C.Structure):
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
         ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
+        ("y_bf16_copy", C.c_void_p),
     ]
 
 
@@ -122,7 +123,7 @@ class LrBwdArgs(C.Structure):
         ("x", C.c_void_p), ("x_per_sample", C.c_int32), ("relu", C.c_int32),
         ("gy", C.c_void_p), ("y", C.c_void_p), ("v", C.c_void_p),
         ("w_mu", C.c_void_p), ("w_rho", C.c_void_p), ("b_mu", C.c_void_p), ("b_rho", C.c_void_p),
-        ("eps_mode", C.c_int32), ("reserved", C.c_int32),
+        ("eps_mode", C.c_int32), ("math", C.c_int32),
         ("eps_act", C.c_void_p), ("eps_b", C.c_void_p),
         ("seed", C.c_uint64), ("layer_id", C.c_uint32), ("sample_offset", C.c_uint32),
         ("sigma_p", C.c_float), ("gx_relu_mask", C.c_int32),
@@ -243,6 +244,9 @@ def load():
     lib.bnn_bbb_sample_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.bnn_bbb_sample_weights.restype = C.c_int
     lib.bnn_bbb_sample_weights.argtypes = [C.POINTER(SampleArgs), C.c_void_p]
+    lib.bnn_stage_inputs_cast.restype = C.c_int
+    lib.bnn_stage_inputs_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_float, C.c_void_p, C.c_void_p]
     lib.bnn_stage_inputs.restype = C.c_int
     lib.bnn_stage_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_float, C.c_void_p]

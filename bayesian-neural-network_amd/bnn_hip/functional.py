@@ -166,7 +166,7 @@ class LRLinearFn(torch.autograd.Function):
                 x, gy.float(), y, v, w_mu, w_rho, b_mu, b_rho, n_samples=S, sigma_p=call.prior.sigma_p, relu=call.relu,
                 eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b, seed=call.seed, layer_id=call.layer_id,
                 sample_offset=call.sample_offset, sample_counter=call.sample_counter,
-                g_kl=gkl3 if call.want_stats else None, want_gx=ctx.needs_input_grad[0])
+                g_kl=gkl3 if call.want_stats else None, want_gx=ctx.needs_input_grad[0], math_mode=call.math_mode)
             if gx is not None and x.dim() == 2:
                 gx = gx.sum(0)
             return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
@@ -290,7 +290,8 @@ class ElboFn(torch.autograd.Function):
                       sample_offset=call.sample_offset, sample_counter=call.sample_counter,
                       want_gx=(i > 0) or ctx.needs_input_grad[0])
             if lr:
-                out = ops.lr_linear_bwd(xin, g, y if relu else None, v, *p, sigma_p=prior.sigma_p, g_kl=g_kl3, **kw)
+                out = ops.lr_linear_bwd(xin, g, y if relu else None, v, *p, sigma_p=prior.sigma_p, g_kl=g_kl3,
+                                        math_mode=call.math_mode, **kw)
             else:
                 out = ops.bbb_linear_bwd(xin, g, y if relu else None, *p, prior=prior, math_mode=call.math_mode,
                                          g_log_prior=g_a, g_log_q=g_b, **kw)

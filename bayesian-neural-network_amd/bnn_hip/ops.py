@@ -356,7 +356,7 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None, w_frag=None, want_v: bool = False, form: int = 0, sample_group: int = 0,
+                  out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, form: int = 0, sample_group: int = 0,
                   sample_group_stride: int = 0):
     """Argument block of K3 + the result dict + the tensors it points at."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -409,7 +409,13 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     if want_v:                                       # the variance the kernel sampled from: saved for bnn_lr_linear_bwd
         v = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
         a.v_out = v.data_ptr()
-    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v)
+    y16 = None
+    if want_y16:                                     # fp32 y for the backward, bf16 y for the next layer's forward
+        if y.dtype != torch.float32:
+            raise BnnHipError("want_y16 goes with fp32 y")
+        y16 = torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+        a.y_bf16_copy = y16.data_ptr()
+    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16)
     keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace)
     return a, res, keep
 
@@ -669,7 +675,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
 
 def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
                   eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
-                  want_gx: bool = True, sample_counter=None, out=None, gx_relu_mask: bool = False):
+                  want_gx: bool = True, sample_counter=None, out=None, gx_relu_mask: bool = False, math_mode: int = L.MATH_F32):
     """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
     saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
     Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
@@ -692,7 +698,7 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
         y = _f32c(y, "y")
         a.y = y.data_ptr()
     a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
-    a.eps_mode = eps_mode
+    a.eps_mode, a.math = eps_mode, int(math_mode)
     if eps_mode == L.EPS_MEMORY:
         eps_act, eps_b = _f32c(eps_act, "eps_act"), _f32c(eps_b, "eps_b")
         a.eps_act, a.eps_b = eps_act.data_ptr(), eps_b.data_ptr()
@@ -780,9 +786,9 @@ def elbo_loss_nll_bwd(a, b, nll, beta, total_samples: int, local_reparam: bool, 
     return out4, g_a, g_b, g_kl3, g_logits
 
 
-def stage_inputs(src0, dst0, src1=None, dst1=None, word=None, value: float = 0.0):
+def stage_inputs(src0, dst0, src1=None, dst1=None, word=None, value: float = 0.0, cast0=None):
     """bnn_stage_inputs: dst0 <- src0, dst1 <- src1 (same dtype, shape; contiguous device tensors), *word = value,
-    one launch."""
+    one launch.  `cast0` (bf16, src0's shape, src0 fp32): also the bf16 copy of src0 (bnn_stage_inputs_cast)."""
     lib = L.load()
     require_device(src0, dst0, src1, dst1, word)
     for s_, d_ in ((src0, dst0), (src1, dst1)):
@@ -791,6 +797,13 @@ def stage_inputs(src0, dst0, src1=None, dst1=None, word=None, value: float = 0.0
         if s_.dtype != d_.dtype or s_.numel() != d_.numel() or not s_.is_contiguous() or not d_.is_contiguous():
             raise BnnHipError("stage_inputs: source and destination must be contiguous, same dtype and size")
     nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+    if cast0 is not None:
+        require_device(cast0)
+        if src0.dtype != torch.float32 or cast0.dtype != torch.bfloat16 or cast0.numel() != src0.numel() or not cast0.is_contiguous():
+            raise BnnHipError("stage_inputs: cast0 must be a contiguous bf16 tensor of the fp32 src0's size")
+        L.check(lib.bnn_stage_inputs_cast(_ptr(src0), _ptr(dst0), nb(src0), _ptr(src1), _ptr(dst1), nb(src1), _ptr(word),
+                                          float(value), cast0.data_ptr(), _stream()), "bnn_stage_inputs_cast")
+        return
     L.check(lib.bnn_stage_inputs(_ptr(src0), _ptr(dst0), nb(src0), _ptr(src1), _ptr(dst1), nb(src1), _ptr(word), float(value),
                                  _stream()), "bnn_stage_inputs")
 

@@ -32,6 +32,7 @@ from .runtime import state, take_samples
 # launches, which then need no generator either (the transposed generator draws a whole Philox group per weight).
 # The weight-gradient kernels still regenerate eps.  BNN_HIP_TRAIN_PRESAMPLE=0: sampling fused into every launch.
 TRAIN_PRESAMPLE = os.environ.get("BNN_HIP_TRAIN_PRESAMPLE", "1") != "0"
+TRAIN_BF16_FORWARD_INPUTS = True
 
 
 class GraphedTrainStep:
@@ -66,6 +67,10 @@ class GraphedTrainStep:
         self.dp = bool(data_parallel)
         dev = x.device
         self.x, self.y = x.clone(), y.clone()
+        # bf16 math: the forward launches read bf16 activations (the staging launch casts the minibatch, each hidden
+        # layer also writes its output in bf16), the backward the fp32 ones
+        self.x16 = (self.x.to(torch.bfloat16) if (TRAIN_BF16_FORWARD_INPUTS and not autograd and state.math == L.MATH_BF16 and
+                                                  x.dtype == torch.float32) else None)
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
@@ -162,6 +167,7 @@ class GraphedTrainStep:
         specs = net._specs()
         lr = bool(net.local_reparam)
         h = net._flat(self.x)
+        h16 = net._flat(self.x16) if self.x16 is not None else None     # what the forward launches read, when present
         first = take_samples(S * self.world) + self.rank * S
         saved, wss = [], []
         if self.presample:
@@ -179,7 +185,7 @@ class GraphedTrainStep:
             if not lr and i == len(specs) - 1 and self.presample:
                 # output layer + finalize in one launch over the weights the sampling launch drew: split by batch rows
                 # when it is a single feature tile (K1r), else matmul + finalize
-                res, fin = ops.bbb_final_fwd((h, None, None, None, None),
+                res, fin = ops.bbb_final_fwd((h16 if h16 is not None else h, None, None, None, None),
                                              dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math, relu=sp.relu,
                                                   y_dtype=torch.float32, eps_mode=L.EPS_ZERO, want_stats=False,
                                                   w_sampled=self.wsamp[i], b_sampled=self.bsamp[i]),
@@ -190,7 +196,7 @@ class GraphedTrainStep:
                 continue
             if not lr and i == len(specs) - 1:
                 # output layer + finalize in one launch (it samples its own few weights)
-                res, fin = ops.bbb_final_fwd((h,) + p, dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math,
+                res, fin = ops.bbb_final_fwd((h16 if h16 is not None else h,) + p, dict(n_samples=S, prior=sp.m._prior_spec, math_mode=state.math,
                                                             relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                                                             seed=state.seed, layer_id=sp.layer_id, sample_offset=first,
                                                             sample_counter=self.counter, want_stats=True),
@@ -199,20 +205,23 @@ class GraphedTrainStep:
                 h = res["y"]
                 continue
             if self.presample:
-                y = ops.bbb_sampled_matmul(h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu, y_dtype=torch.float32)
+                y = ops.bbb_sampled_matmul(h16 if h16 is not None else h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu,
+                                           y_dtype=torch.float32)
                 saved.append((h, y, None, p))
                 wss.append(self.wstat[i])
-                h = y
+                h, h16 = y, None
                 continue
             common = dict(n_samples=S, math_mode=state.math, relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                           seed=state.seed, layer_id=sp.layer_id, sample_offset=first, sample_counter=self.counter)
+            hin = h16 if h16 is not None else h
             if sp.lr:
-                out = ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True, **common)
+                out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
+                                        want_y16=self.x16 is not None and i < len(specs) - 1, **common)
             else:
-                out = ops.bbb_linear_fwd(h, *p, prior=sp.m._prior_spec, want_stats=True, **common)
+                out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True, **common)
             saved.append((h, out["y"], out.get("v"), p))
             wss.append(out["workspace"])
-            h = out["y"]
+            h, h16 = out["y"], out.get("y16")
         if fin is None:
             fin = ops.elbo_finalize(workspaces=wss, logits=h, **fin_kw)
         # loss, backward seeds and d nll / d logits in one launch (the NLL seed is the constant 1 / (S ranks))
@@ -248,7 +257,8 @@ class GraphedTrainStep:
                   sample_offset=first, sample_counter=self.counter, want_gx=i > 0, out=self.grad_views[4 * i:4 * i + 4],
                   gx_relu_mask=i > 0 and specs[i - 1].relu)
         if sp.lr:
-            grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3, **kw)
+            grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
+                                      math_mode=state.math, **kw)
         else:
             grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
                                        g_log_prior=g_a, g_log_q=g_b,
@@ -294,9 +304,15 @@ class GraphedTrainStep:
         sample_elbo* returns (static tensors: read them before the next call)."""
         if (x.is_cuda and y.is_cuda and x.dtype == self.x.dtype and y.dtype == self.y.dtype and x.is_contiguous()
                 and y.is_contiguous() and x.numel() == self.x.numel() and y.numel() == self.y.numel()):
-            ops.stage_inputs(x, self.x, y, self.y, self.beta, float(beta))       # one launch instead of three
+            cast = self.x16 if (self.x16 is not None and (x.numel() * 4) % 16 == 0 and (y.numel() * y.element_size()) % 16 == 0 and
+                                (x.data_ptr() | y.data_ptr()) % 16 == 0) else None
+            ops.stage_inputs(x, self.x, y, self.y, self.beta, float(beta), cast0=cast)       # one launch instead of three
+            if cast is None and self.x16 is not None:
+                self.x16.copy_(self.x)
         else:
             self.x.copy_(x, non_blocking=True)
+            if self.x16 is not None:
+                self.x16.copy_(x, non_blocking=True)
             self.y.copy_(y, non_blocking=True)
             self.beta.fill_(float(beta))
         self.opt.sync_lr()

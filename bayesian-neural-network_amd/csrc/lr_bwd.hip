@@ -320,17 +320,29 @@ __device__ __forceinline__ float4 load_quad(const float* row, int i, int len) {
   return r;
 }
 
-// grid (ceil(K/32), ceil(B/32), S), 8 waves.  Block tile 32 batch rows x 32 input features as
+// One block per (32-wide k tile, 32-row batch block, sample), 8 waves.  Block tile 32 batch rows x 32 input features as
 // 2 x 2 MFMA tiles for each of P = gz M^T and Q = h (sigma^2)^T; wave w takes the 16-wide
 // slices w, w + 8, ... of the out-feature range.  MFMA k-step t of a slice uses reduction
 // index n = 16 slice + 4 q + t on both operands, i.e. component t of one 16-byte load.
-template <bool VEC>
+// BF16 (bf16 math, N % 8 == 0, 16-byte aligned rows): the operands are rounded to bf16 in registers and the slices
+// are 32 wide (v_mfma_f32_16x16x32_bf16: lane (c, q) holds the 8 consecutive n = 32 slice + 8 q of its row), fp32
+// accumulation -- the arithmetic of the forward's bf16 mode.  The exact-fp32 form spends 64 matrix-core
+// instructions of 32 cycles per 32 n, this one 8 of 16: at 2 x 128 x 1200 x 1200 the kernel goes from the fp32 matrix
+// core's bound to that of its loads.
+template <bool VEC, bool BF16>
 __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
   __shared__ f32x4 red[4][8][64];                       // 32 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
-  const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, s = blockIdx.z;
+  // XCD-aware order: the (batch block, sample) blocks of one 32-wide k tile are consecutive items, and an XCD owns a
+  // contiguous range of items, so each XCD pulls ITS k tiles' (mu, rho) rows through its L2 once (a 3-D grid dealt the
+  // k tiles round-robin: every XCD streamed all of [K, N] mu and rho, 8 x 11.5 MB over the fabric at 1200 x 1200)
+  const int nbb = (B + 31) >> 5;
+  int item;
+  if (!xcd_work_item(((K + 31) >> 5) * nbb * p.S, item)) return;   // block-uniform, before any barrier
+  const int kt = item / (nbb * p.S), rest = item - kt * (nbb * p.S);
+  const int k0 = kt * 32, b0 = (rest % nbb) * 32, s = rest / nbb;
   const float* gzs = p.gz + (size_t)s * B * N;
   const float* hs = p.h + (size_t)s * B * N;
   const int nslices = (N + 15) >> 4;
@@ -377,12 +389,64 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
     LR_STEP(w)
 #undef LR_STEP
   };
-  // (issuing slice t + 1's loads ahead of slice t's MFMAs, or fencing the batch with a scheduling
-  // barrier, both measured slower here: 45 us and 34 us against 31 us at 2 x 128 x 1200 x 1200)
-  for (int sl = wave; sl < nslices; sl += 8) {
-    Frag f;
-    load_slice(sl, f);
-    mfma_slice(f);
+  if constexpr (BF16) {
+    struct Frag8 { float4 lo, hi; };
+    auto load8 = [&](const float* row, int n) {
+      Frag8 f;
+      f.lo = *reinterpret_cast<const float4*>(row + min(n, N - 8));
+      f.hi = *reinterpret_cast<const float4*>(row + min(n, N - 8) + 4);
+      return f;
+    };
+    auto to_bf16 = [](const Frag8& f, bool ok) {
+      const float v[8] = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)(ok ? v[j] : 0.f);
+      return o;
+    };
+    auto to_var_bf16 = [&](const Frag8& f, bool ok) {
+      const float v[8] = {f.lo.x, f.lo.y, f.lo.z, f.lo.w, f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)(ok ? sq_softplus(v[j]) : 0.f);
+      return o;
+    };
+    const int nsteps = (N + 31) >> 5;
+    struct Step { Frag8 g0, g1, h0, h1, m0, m1, r0, r1; };
+    auto load_step = [&](int st, Step& f) {
+      const int n = st * 32 + 8 * q;
+      f.g0 = load8(gzs + (size_t)ra0 * N, n); f.g1 = load8(gzs + (size_t)ra1 * N, n);
+      f.h0 = load8(hs + (size_t)ra0 * N, n); f.h1 = load8(hs + (size_t)ra1 * N, n);
+      f.m0 = load8(p.w_mu + (size_t)kc0 * N, n); f.m1 = load8(p.w_mu + (size_t)kc1 * N, n);
+      f.r0 = load8(p.w_rho + (size_t)kc0 * N, n); f.r1 = load8(p.w_rho + (size_t)kc1 * N, n);
+    };
+    auto mfma_step = [&](int st, const Step& f) {
+      const bool ok = st * 32 + 8 * q < N;                // N % 8 == 0: an 8-group is whole or absent (also a step past the end)
+      const bf16x8 ga0 = to_bf16(f.g0, ok), ga1 = to_bf16(f.g1, ok), ha0 = to_bf16(f.h0, ok), ha1 = to_bf16(f.h1, ok);
+      const bf16x8 mb0 = to_bf16(f.m0, ok), mb1 = to_bf16(f.m1, ok), sb0 = to_var_bf16(f.r0, ok), sb1 = to_var_bf16(f.r1, ok);
+      P[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, mb0, P[0][0], 0, 0, 0);
+      P[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, mb1, P[0][1], 0, 0, 0);
+      P[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, mb0, P[1][0], 0, 0, 0);
+      P[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, mb1, P[1][1], 0, 0, 0);
+      Q[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha0, sb0, Q[0][0], 0, 0, 0);
+      Q[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha0, sb1, Q[0][1], 0, 0, 0);
+      Q[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha1, sb0, Q[1][0], 0, 0, 0);
+      Q[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha1, sb1, Q[1][1], 0, 0, 0);
+    };
+    // (two steps' loads in flight per round measured slower: 36 against 30 us at 2 x 128 x 1200 x 1200)
+    for (int st = wave; st < nsteps; st += 8) {
+      Step f;
+      load_step(st, f);
+      mfma_step(st, f);
+    }
+  } else {
+    // (issuing slice t + 1's loads ahead of slice t's MFMAs, or fencing the batch with a scheduling
+    // barrier, both measured slower here: 45 us and 34 us against 31 us at 2 x 128 x 1200 x 1200)
+    for (int sl = wave; sl < nslices; sl += 8) {
+      Frag f;
+      load_slice(sl, f);
+      mfma_slice(f);
+    }
   }
 
   // ---- fold the 8 partial sums: waves 4..7 -> LDS -> waves 0..3 add; then 0..3 -> LDS -> wave `combo` sums
@@ -462,7 +526,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   if (!a->x || !a->gy || !a->v || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->g_w_mu || !a->g_w_rho ||
       !a->g_b_mu || !a->g_b_rho)
     return BNN_ERR_NULL;
-  if ((unsigned)a->eps_mode > 2u) return BNN_ERR_ENUM;
+  if ((unsigned)a->eps_mode > 2u || (unsigned)a->math > 1u) return BNN_ERR_ENUM;
   if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_act || !a->eps_b)) return BNN_ERR_NULL;
   if (a->relu && !a->y) return BNN_ERR_NULL;
   if (!(a->sigma_p > 0.f)) return BNN_ERR_SHAPE;
@@ -510,9 +574,12 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   if (a->g_x) {
-    const dim3 igrid((K + 31) / 32, (B + 31) / 32, S);
-    if ((N & 3) == 0) hipLaunchKernelGGL(lr_bwd_input_kernel<true>, igrid, dim3(512), 0, stream, k);
-    else hipLaunchKernelGGL(lr_bwd_input_kernel<false>, igrid, dim3(512), 0, stream, k);
+    const long items = (long)((K + 31) / 32) * ((B + 31) / 32) * S;
+    if (items > (1L << 30)) return BNN_ERR_SHAPE;
+    const dim3 igrid((unsigned)(((items + 7) / 8) * 8));
+    if (a->math == BNN_MATH_BF16 && (N & 7) == 0) hipLaunchKernelGGL((lr_bwd_input_kernel<true, true>), igrid, dim3(512), 0, stream, k);
+    else if ((N & 3) == 0) hipLaunchKernelGGL((lr_bwd_input_kernel<true, false>), igrid, dim3(512), 0, stream, k);
+    else hipLaunchKernelGGL((lr_bwd_input_kernel<false, false>), igrid, dim3(512), 0, stream, k);
     err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }

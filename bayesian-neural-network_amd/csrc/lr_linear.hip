@@ -46,6 +46,7 @@ struct LrK {
   int tune;              // tuning build only: 1 = no MFMAs, 2 = no LDS reads, 4 = no loads in the k loop
 #endif
   void* y_sq;       // optional bf16 y*y
+  __bf16* y16;      // optional bf16 copy of an fp32 y (K3a)
   float* v_out;     // optional fp32 variance
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
@@ -390,6 +391,19 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (nb + i < N) p.v_out[yoff + i] = vv[ii][i];
+    }
+    if (p.y16) {
+      __bf16* cp = p.y16 + yoff;
+      if (vec_ok) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+        *reinterpret_cast<bf16x4*>(cp) = o;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (nb + i < N) cp[i] = (__bf16)v[i];
+      }
     }
     if (p.y_bf16) {
       __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
@@ -1292,6 +1306,8 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
   k.x_sq = a->x_sq; k.y_sq = a->y_sq; k.v_out = a->v_out;
+  k.y16 = reinterpret_cast<__bf16*>(a->y_bf16_copy);
+  if (a->y_bf16_copy && (a->y_dtype != BNN_F32 || a->form == BNN_FORM_GEMM)) return BNN_ERR_ENUM;
   k.w_frag = reinterpret_cast<const float4*>(a->w_frag);
   k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
@@ -1319,7 +1335,7 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
   const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
   // K3b needs bf16 x AND x^2 streams; the saved variance (v_out) is a K3a epilogue
-  const bool can = !a->v_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+  const bool can = !a->v_out && !a->y_bf16_copy && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
   // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
   if (can && (a->form == BNN_FORM_GEMM || (a->form == BNN_FORM_AUTO && gemm_blocks >= 300))) {
@@ -1337,6 +1353,9 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   }
   int R = 1;
   while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
+#ifdef BNN_TUNE
+  if (const char* v = getenv("BNN_TUNE_LRR")) { const int f = atoi(v); if (f == 1 || f == 2 || f == 4) R = f; }
+#endif
   const int F = 16 / R;
   const int ssteps = (K + 32 * R - 1) / (32 * R);
   // a narrow layer in few samples: 32-row blocks (MT = 2), so that more than a handful of blocks exist
@@ -1472,7 +1491,7 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features, nl = f->n_layers;
   const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 16 &&
                     (K % 8) == 0 && K <= 2048 && !(reinterpret_cast<uintptr_t>(a->x) & 15) && a->eps_mode == BNN_EPS_PHILOX &&
-                    !a->eps_act_dump && !a->eps_b_dump && !a->v_out && !a->y_sq && !a->kl_out && a->form == BNN_FORM_AUTO &&
+                    !a->eps_act_dump && !a->eps_b_dump && !a->v_out && !a->y_sq && !a->y_bf16_copy && !a->kl_out && a->form == BNN_FORM_AUTO &&
                     f->local_reparam && nl >= 1 && nl <= 8 && f->n_samples == S && f->classes == N && f->batch == B &&
                     f->logits == a->y && f->nll && f->kl && f->layer_in[nl - 1] == K && f->layer_out[nl - 1] == N &&
                     f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&

@@ -412,11 +412,20 @@ __global__ __launch_bounds__(256) void elbo_loss_nll_bwd_kernel(
 // copies (16-byte words when everything is aligned) and one float word (the step's KL weight).
 __global__ __launch_bounds__(256) void stage_inputs_kernel(const char* __restrict__ s0, char* __restrict__ d0, size_t n0,
                                                            const char* __restrict__ s1, char* __restrict__ d1, size_t n1,
-                                                           int vec, float* __restrict__ word, float value) {
+                                                           int vec, float* __restrict__ word, float value,
+                                                           __bf16* __restrict__ cast0) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
   if (tid == 0 && word) *word = value;
   if (vec) {
-    for (size_t i = tid; i < (n0 >> 4); i += nt) reinterpret_cast<float4*>(d0)[i] = reinterpret_cast<const float4*>(s0)[i];
+    for (size_t i = tid; i < (n0 >> 4); i += nt) {
+      const float4 v = reinterpret_cast<const float4*>(s0)[i];
+      reinterpret_cast<float4*>(d0)[i] = v;
+      if (cast0) {                                          // src0 is fp32: also its bf16 copy (vec only)
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4*>(cast0)[i] = o;
+      }
+    }
     for (size_t i = tid; i < (n1 >> 4); i += nt) reinterpret_cast<float4*>(d1)[i] = reinterpret_cast<const float4*>(s1)[i];
   } else {
     for (size_t i = tid; i < n0; i += nt) d0[i] = s0[i];
@@ -525,19 +534,29 @@ extern "C" int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 
+extern "C" int bnn_stage_inputs_cast(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
+                                     float* word, float value, void* cast0_bf16, void* stream_);
+
 extern "C" int bnn_stage_inputs(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
                                 float* word, float value, void* stream_) {
+  return bnn_stage_inputs_cast(src0, dst0, bytes0, src1, dst1, bytes1, word, value, nullptr, stream_);
+}
+
+extern "C" int bnn_stage_inputs_cast(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
+                                     float* word, float value, void* cast0_bf16, void* stream_) {
   if ((bytes0 && (!src0 || !dst0)) || (bytes1 && (!src1 || !dst1))) return BNN_ERR_NULL;
   if (!bytes0 && !bytes1 && !word) return BNN_OK;
   const uintptr_t al = reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(dst0) | (uintptr_t)bytes0 |
                        reinterpret_cast<uintptr_t>(src1) | reinterpret_cast<uintptr_t>(dst1) | (uintptr_t)bytes1;
   const int vec = (al & 15) == 0;
+  if (cast0_bf16 && (!vec || (reinterpret_cast<uintptr_t>(cast0_bf16) & 7))) return BNN_ERR_ALIGN;
   const size_t words = vec ? ((bytes0 > bytes1 ? bytes0 : bytes1) >> 4) : (bytes0 > bytes1 ? bytes0 : bytes1);
   size_t nb = (words + 255) / 256;
   nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
   hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                      reinterpret_cast<const char*>(src0), reinterpret_cast<char*>(dst0), bytes0,
-                     reinterpret_cast<const char*>(src1), reinterpret_cast<char*>(dst1), bytes1, vec, word, value);
+                     reinterpret_cast<const char*>(src1), reinterpret_cast<char*>(dst1), bytes1, vec, word, value,
+                     reinterpret_cast<__bf16*>(cast0_bf16));
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

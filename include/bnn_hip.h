@@ -305,6 +305,10 @@ typedef struct bnn_lr_fwd_args {
   float* v_out;             /* optional fp32 [n_samples,batch,out]: the pre-activation variance v
                                (networks.py:121) as the kernel computed it; bnn_lr_linear_bwd needs
                                it.  Selects the latency form of the kernel. */
+  void* y_bf16_copy;        /* optional bf16 [n_samples,batch,out], with y_dtype == BNN_F32: y also in bf16.  A training
+                               step keeps fp32 activations for the backward and feeds the next layer's forward
+                               the bf16 ones (half the bytes through the CU, no conversion in its k loop).
+                               Selects the latency form of the kernel. */
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
@@ -508,7 +512,9 @@ typedef struct bnn_lr_bwd_args {
   const float* b_mu;
   const float* b_rho;
   int32_t eps_mode;
-  int32_t reserved;
+  int32_t math;               /* bnn_math.  BNN_MATH_BF16: the input gradient's two products take bf16-rounded operands
+                                 (fp32 accumulation), as the forward of that mode does; the weight gradients stay on
+                                 the exact-fp32 matrix core */
   const float* eps_act;       /* BNN_EPS_MEMORY */
   const float* eps_b;
   uint64_t seed;
@@ -601,6 +607,10 @@ int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float* nll, cons
  * empty (bytes = 0 / word = NULL). */
 int bnn_stage_inputs(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
                      float* word, float value, void* stream);
+/* The same with src0 an fp32 tensor whose bf16 copy (bytes0 / 2 bytes) is also written to cast0_bf16: the first layer's
+ * forward of a bf16-math step reads that one.  16-byte aligned pointers and sizes. */
+int bnn_stage_inputs_cast(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
+                          float* word, float value, void* cast0_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * F3  bnn_mc_softmax_mean — the MC-averaged prediction of classification/class_task.py:81-87:

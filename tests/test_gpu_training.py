@@ -201,6 +201,34 @@ def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
         assert float(masked[4].abs().max()) > 0
 
 
+def test_lr_input_gradient_in_bf16_math():
+    """bnn_lr_bwd_args.math = BNN_MATH_BF16: g_x = gz M^T + 2 x (h (sigma^2)^T) with the four operands rounded to bf16
+    (fp32 accumulation) -- checked against that arithmetic in torch and against the exact-fp32 form; the weight
+    gradients do not depend on the mode."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(12)
+    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 40), (1, 7, 33, 16)):
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1))
+        gy, v = mk(S, B, N, lo=-1, hi=1), mk(S, B, N, lo=0.1, hi=1.0)
+        w_mu, w_rho, b_mu, b_rho = mk(K, N), mk(K, N, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
+        kw = dict(n_samples=S, relu=False, eps_mode=L.EPS_PHILOX, seed=3, layer_id=1, sample_offset=5, sigma_p=1.0, gx_relu_mask=True)
+        f32 = ops.lr_linear_bwd(x, gy, None, v, w_mu, w_rho, b_mu, b_rho, math_mode=L.MATH_F32, **kw)
+        b16 = ops.lr_linear_bwd(x, gy, None, v, w_mu, w_rho, b_mu, b_rho, math_mode=L.MATH_BF16, **kw)
+        for a, b in zip(f32[:4], b16[:4]):
+            assert torch.equal(a, b)
+        eps = ops.philox_normal(3, 4 * 1 + 2, 5, S, B, N, dev)
+        h = gy * eps / (2 * torch.sqrt(v))
+        r = lambda t: t.to(torch.bfloat16).float()
+        sig2 = torch.log1p(torch.exp(w_rho)) ** 2
+        want = (r(gy) @ r(w_mu).T + 2 * x * (r(h) @ r(sig2).T)) * (x > 0)
+        nrm = lambda t: float(t.double().norm())
+        assert nrm(b16[4] - want) <= 2e-3 * nrm(want), (S, B, K, N)      # (a bf16 ulp of sigma^2 here and there: softplus forms differ)
+        assert nrm(b16[4] - f32[4]) <= 2e-2 * nrm(f32[4]), (S, B, K, N)
+        assert torch.equal(b16[4] == 0, f32[4] == 0) or nrm(((b16[4] == 0) != (f32[4] == 0)).float()) ** 2 < 1e-3 * x.numel()
+
+
 @pytest.mark.parametrize("mode", ["classification", "regression"])
 def test_loss_tail_on_the_final_launch_equals_the_separate_launch(mode):
     """bnn_finalize_args.loss: the row-split final launch (bnn_bbb_final_fwd over sampled weights) also differentiates
