@@ -52,7 +52,7 @@ class BbbFwdArgs(C.Structure):
         ("log_prior", C.c_void_p), ("log_q", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("form", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
-        ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p), ("rider", C.c_void_p),
+        ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p), ("rider", C.c_void_p), ("y_bf16_copy", C.c_void_p),
     ]
 
 

@@ -125,12 +125,21 @@ def lr_workspace(out_features: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
+def _y16(a, y: torch.Tensor) -> torch.Tensor:
+    """y_bf16_copy of a layer call: fp32 y for the backward, bf16 y for the next layer's forward (tile forms)."""
+    if y.dtype != torch.float32:
+        raise BnnHipError("want_y16 goes with fp32 y")
+    y16 = torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+    a.y_bf16_copy = y16.data_ptr()
+    return y16
+
+
 def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int,
                relu: bool, y_dtype: torch.dtype, eps_mode: int, eps_w=None, eps_b=None, seed: int = 0,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
                out=None, split_scratch=None, w_sigma=None, form: int = 0, sample_group: int = 0,
-               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None):
+               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None, want_y16: bool = False):
     """Argument block of K1 + the tensors it points at (kept alive by the caller).  `w_sampled` / `b_sampled` (bf16
     [S,out,in] / fp32 [S,out] from bbb_sample_weights): the matmul-only form, the parameter tensors may then be None.
     `rider` = the (args, results, keep) of build_sample_job: an independent sampling job carried by the launch."""
@@ -155,7 +164,8 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
         a.y, a.y_dtype = y.data_ptr(), _dt(y)
         a.w_sampled, a.b_sampled = w_sampled.data_ptr(), b_sampled.data_ptr()
         a.form = int(form)
-        return a, dict(y=y, workspace=None, log_prior=None, log_q=None, eps_w=None, eps_b=None), (xs, w_sampled, b_sampled, y)
+        y16 = _y16(a, y) if want_y16 else None
+        return a, dict(y=y, y16=y16, workspace=None, log_prior=None, log_q=None, eps_w=None, eps_b=None), (xs, w_sampled, b_sampled, y)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     N, K = w_mu.shape
@@ -199,7 +209,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
     if rider is not None:
         a.rider = C.addressof(rider[0])
-    res = dict(y=y, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
+    res = dict(y=y, y16=_y16(a, y) if want_y16 else None, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
     keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma, rider)
     return a, res, keep
 
@@ -293,12 +303,14 @@ def bbb_sample_weights(layers, **kw):
     return res
 
 
-def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):
-    """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s])."""
+def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, want_y16: bool = False):
+    """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s]).  `want_y16`:
+    returns (y fp32, y in bf16)."""
     a, res, keep = _bbb_build(x, None, None, None, None, n_samples=n_samples, prior=PriorSpec(), math_mode=L.MATH_BF16, relu=relu,
-                              y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=out, w_sampled=w, b_sampled=b)
+                              y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=out, w_sampled=w, b_sampled=b,
+                              want_y16=want_y16)
     L.check(L.load().bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
-    return res["y"]
+    return (res["y"], res["y16"]) if want_y16 else res["y"]
 
 
 def bbb_library_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):

@@ -206,10 +206,11 @@ class GraphedTrainStep:
                 continue
             if self.presample:
                 y = ops.bbb_sampled_matmul(h16 if h16 is not None else h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu,
-                                           y_dtype=torch.float32)
+                                           y_dtype=torch.float32, want_y16=self.x16 is not None)
+                y, y16 = y if self.x16 is not None else (y, None)
                 saved.append((h, y, None, p))
                 wss.append(self.wstat[i])
-                h, h16 = y, None
+                h, h16 = y, y16
                 continue
             common = dict(n_samples=S, math_mode=state.math, relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                           seed=state.seed, layer_id=sp.layer_id, sample_offset=first, sample_counter=self.counter)
@@ -218,7 +219,8 @@ class GraphedTrainStep:
                 out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
                                         want_y16=self.x16 is not None and i < len(specs) - 1, **common)
             else:
-                out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True, **common)
+                out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True,
+                                         want_y16=self.x16 is not None and i < len(specs) - 1, **common)
             saved.append((h, out["y"], out.get("v"), p))
             wss.append(out["workspace"])
             h, h16 = out["y"], out.get("y16")

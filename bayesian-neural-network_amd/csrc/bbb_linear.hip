@@ -53,6 +53,7 @@ struct BbbK {
   void* y;
   float4* ws;       // stats workspace (see above) or nullptr
   int S, B, K, N;
+  __bf16* y16;      // optional bf16 copy of an fp32 y (tile forms)
   int eps_mode, prior_kind, want_stats, relu, y_bf16, spb;
   int ksl;          // GEMM form: K-range slices per (tile group, sample, batch block) unit; 1 = none
   float4* ks_part;  // GEMM form, ksl > 1: fp32 partial tiles [unit][ksl][wave][batch tile][lane] (bias in slice 0)
@@ -259,6 +260,19 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (nb + i < N) yp[i] = v[i];
+      }
+      if (p.y16) {                                 // fp32 y for the backward, bf16 y for the next layer's forward
+        __bf16* cp = p.y16 + yoff;
+        if (vec_ok) {
+          bf16x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          *reinterpret_cast<bf16x4*>(cp) = o;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < N) cp[i] = (__bf16)v[i];
+        }
       }
     }
   }
@@ -1405,6 +1419,7 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
   // a->form is a preference: taken when the arguments allow that form, otherwise the plan's own choice
   int form = a->form;
   if ((form == BNN_FORM_GEMM && !gemm_ok) || (form == BNN_FORM_GEMM_KSLICE && ksl <= 1)) form = BNN_FORM_AUTO;
+  if (a->y_bf16_copy) form = BNN_FORM_TILE;             // an epilogue of the tile forms
   if (form == BNN_FORM_AUTO) {
     if (ksl > 1 && (long)K * N >= kSliceMinWeights && S >= kSliceMinSamples) form = BNN_FORM_GEMM_KSLICE;
     else if (gemm_ok && gemm_blocks >= kGemmMinBlocks) form = BNN_FORM_GEMM;
@@ -1464,6 +1479,8 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.ws = a->want_stats ? reinterpret_cast<float4*>(a->workspace) : nullptr;
   k.S = a->n_samples; k.B = a->batch; k.K = a->in_features; k.N = a->out_features;
   k.eps_mode = a->eps_mode; k.prior_kind = a->prior.kind; k.want_stats = a->want_stats ? 1 : 0;
+  k.y16 = reinterpret_cast<__bf16*>(a->y_bf16_copy);
+  if (a->y_bf16_copy && a->y_dtype != BNN_F32) return BNN_ERR_ENUM;
   k.relu = a->relu ? 1 : 0; k.y_bf16 = a->y_dtype == BNN_BF16; k.spb = 1; k.ksl = 1; k.ks_part = nullptr; k.ks_ticket = nullptr; k.ldw = 0;
   k.k0 = (uint32_t)a->seed; k.k1 = (uint32_t)(a->seed >> 32);
   k.layer_id = a->layer_id; k.sample_offset = a->sample_offset; k.sample_counter = a->sample_counter;

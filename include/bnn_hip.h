@@ -195,6 +195,9 @@ typedef struct bnn_bbb_fwd_args {
                                ahead of the layer otherwise: same results).  Sampling depends on no activation: the
                                output layer's weights are drawn beside the layer before it, and the output layer of a
                                few-sample evaluation becomes a matmul-only launch (bnn_bbb_final_fwd, w_sampled) */
+  void* y_bf16_copy;        /* optional bf16 [n_samples,batch,out], with y_dtype == BNN_F32: y also in bf16 (for the next
+                               layer's forward of a training step, whose backward reads the fp32 y).  Tile form only:
+                               selects it */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
