@@ -504,6 +504,194 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
   }
 }
 
+
+// Backward of a NARROW LR output layer (N <= 16: the 10 classes / the 1 regression output, batch <= 128) in ONE launch,
+// plain fp32 FMAs: the three general launches (prep, weights, input) are built for wide layers and cost 4.7 + 12 + 5.3 us
+// at 1200 -> 10, mostly their launch and latency chains.  Every block forms the gz / h rows it needs itself (eps_act
+// regenerated, as lr_bwd_prep_kernel does), so nothing passes through memory between the roles:
+//   weight role (blocks < wblocks): 16 k rows of [K, N].  Thread (kc, bg) accumulates the batch rows b = bg (mod 16) of
+//     g_M[k][n] = sum_{s,b} x gz and g_S[k][n] = sum_{s,b} x^2 h over all samples (the KL terms enter once, so no
+//     per-sample epilogue), one LDS round adds the 16 row classes, thread (n, kc) applies the parameter terms; block 0
+//     also takes the bias (column sums of gz, times eps_b for rho).
+//   input role: a block owns 64 k x 32 (sample, row) pairs: M and sigma^2 of its k rows parked in LDS, thread (kc, rg)
+//     walks 8 rows: g_x = (x > 0) * (sum_n gz[n] M[k][n] + 2 x sum_n h[n] sigma^2[k][n]).
+struct LrOutBwd {
+  const float* gy;      // [S, B, N] upstream gradient
+  const float* y;       // forward output (ReLU mask) or nullptr
+  const float* v;       // [S, B, N] the forward's variance
+  int wblocks, kchunks, rchunks;
+};
+
+__device__ __forceinline__ void lr_out_rows(const LrBwdK& p, const LrOutBwd& o, int s, int b0, int nrows, uint32_t gs,
+                                            float* gzs, float* hs) {
+  // gz / h of rows b0 .. b0 + nrows - 1 of sample s into LDS as [row][16] (features padded with zeros); a thread takes
+  // one (row, group of 4 features)
+  const int N = p.N, B = p.B;
+  const int gpr = (N + 3) >> 2;
+  for (int i = threadIdx.x; i < nrows * 4; i += blockDim.x) {
+    const int r = i >> 2, g = i & 3;
+    const int b = b0 + r;
+    float gz4[4] = {0.f, 0.f, 0.f, 0.f}, h4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (b < B && g < gpr) {
+      const size_t row = ((size_t)s * B + b) * N;
+      float e4[4];
+      philox_normal4((uint32_t)b * (uint32_t)gpr + (uint32_t)g, gs, p.layer_id * 4u + 2u, p.k0, p.k1, e4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = g * 4 + j;
+        if (n < N) {
+          const float gyv = o.gy[row + n], vv = o.v[row + n];
+          const float g_ = (!o.y || o.y[row + n] > 0.f) ? gyv : 0.f;
+          const float sd = __builtin_sqrtf(vv);
+          gz4[j] = g_;
+          h4[j] = sd > 0.f ? g_ * e4[j] / (2.f * sd) : 0.f;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(gzs + r * 16 + g * 4) = make_float4(gz4[0], gz4[1], gz4[2], gz4[3]);
+    *reinterpret_cast<float4*>(hs + r * 16 + g * 4) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void lr_out_layer_bwd_kernel(const LrBwdK p, const LrOutBwd o) {
+  __shared__ __attribute__((aligned(16))) float gzs[128 * 16], hs[128 * 16];
+  __shared__ __attribute__((aligned(16))) float red[2][16 * 16 * 16];      // weight role: [M | S][bg][n][kc]; input role: M, sigma^2 rows
+  const int K = p.K, N = p.N, B = p.B, S = p.S;
+  const int tid = threadIdx.x;
+  const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
+  if ((int)blockIdx.x >= o.wblocks) {
+    // ---- input gradient: 64 k x 32 rows of the flattened (sample, row) list
+    const int bi = (int)blockIdx.x - o.wblocks;
+    const int kch = bi % o.kchunks, rch = bi / o.kchunks;
+    const int k0 = kch * 64;
+    float* Ms = red[0];                                     // [64][16]
+    float* Vs = red[1];
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int kk = i >> 4, n = i & 15;
+      const int k = k0 + kk;
+      const bool ok = k < K && n < N;
+      const float m = p.w_mu[(size_t)min(k, K - 1) * N + min(n, N - 1)], r = p.w_rho[(size_t)min(k, K - 1) * N + min(n, N - 1)];
+      const float sg = softplus(r);
+      Ms[i] = ok ? m : 0.f;
+      Vs[i] = ok ? sg * sg : 0.f;
+    }
+    const int row0 = rch * 32;                              // rows of one sample (B is split into whole 32-row chunks per sample)
+    const int cps = (B + 31) >> 5;                          // chunks per sample
+    const int s = rch / cps, b0 = (rch - s * cps) * 32;
+    lr_out_rows(p, o, s, b0, 32, sample_base + (uint32_t)s, gzs, hs);
+    (void)row0;
+    __syncthreads();
+    const int kc = tid & 63, rg = tid >> 6;
+    const int k = k0 + kc;
+    if (k >= K) return;
+    float mrow[16], vrow[16];
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) {
+      const float4 a = *reinterpret_cast<const float4*>(Ms + kc * 16 + n4 * 4), c = *reinterpret_cast<const float4*>(Vs + kc * 16 + n4 * 4);
+      mrow[n4 * 4 + 0] = a.x; mrow[n4 * 4 + 1] = a.y; mrow[n4 * 4 + 2] = a.z; mrow[n4 * 4 + 3] = a.w;
+      vrow[n4 * 4 + 0] = c.x; vrow[n4 * 4 + 1] = c.y; vrow[n4 * 4 + 2] = c.z; vrow[n4 * 4 + 3] = c.w;
+    }
+    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = xs[(size_t)min(b0 + rg + 4 * j, B - 1) * K + k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = rg + 4 * j, b = b0 + r;
+      float pm = 0.f, qv = 0.f;
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) {
+        const float4 g = *reinterpret_cast<const float4*>(gzs + r * 16 + n4 * 4), h = *reinterpret_cast<const float4*>(hs + r * 16 + n4 * 4);
+        pm = __builtin_fmaf(g.x, mrow[n4 * 4 + 0], pm); pm = __builtin_fmaf(g.y, mrow[n4 * 4 + 1], pm);
+        pm = __builtin_fmaf(g.z, mrow[n4 * 4 + 2], pm); pm = __builtin_fmaf(g.w, mrow[n4 * 4 + 3], pm);
+        qv = __builtin_fmaf(h.x, vrow[n4 * 4 + 0], qv); qv = __builtin_fmaf(h.y, vrow[n4 * 4 + 1], qv);
+        qv = __builtin_fmaf(h.z, vrow[n4 * 4 + 2], qv); qv = __builtin_fmaf(h.w, vrow[n4 * 4 + 3], qv);
+      }
+      const float gx = __builtin_fmaf(2.f * xv[j], qv, pm);
+      if (b < B) p.g_x[((size_t)s * B + b) * K + k] = (p.gx_mask && !(xv[j] > 0.f)) ? 0.f : gx;
+    }
+    return;
+  }
+  // ---- weight (and bias) gradients of 16 k rows
+  const int k0 = (int)blockIdx.x * 16;
+  const int kc = tid & 15, bg = tid >> 4;
+  const int kx = min(k0 + kc, K - 1);
+  const bool k_ok = k0 + kc < K;
+  const bool b_ok = blockIdx.x == 0 && tid < N;            // bias: thread n
+  float accM[16], accS[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) accM[n] = accS[n] = 0.f;
+  float Gb = 0.f, Hb = 0.f;
+  const int J = (B + 15) >> 4;                              // rows per thread (<= 8)
+  for (int s = 0; s < S; ++s) {
+    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = bg + 16 * j;
+      const float v = xs[(size_t)min(b, B - 1) * K + kx];
+      xv[j] = (j < J && b < B && k_ok) ? v : 0.f;
+    }
+    __syncthreads();                                        // the previous sample's readers of gzs / hs are done
+    lr_out_rows(p, o, s, 0, B, sample_base + (uint32_t)s, gzs, hs);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < J) {
+        const int b = min(bg + 16 * j, B - 1);
+        const float x1 = xv[j], x2 = xv[j] * xv[j];
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) {
+          const float4 g = *reinterpret_cast<const float4*>(gzs + b * 16 + n4 * 4), h = *reinterpret_cast<const float4*>(hs + b * 16 + n4 * 4);
+          accM[n4 * 4 + 0] = __builtin_fmaf(x1, g.x, accM[n4 * 4 + 0]); accM[n4 * 4 + 1] = __builtin_fmaf(x1, g.y, accM[n4 * 4 + 1]);
+          accM[n4 * 4 + 2] = __builtin_fmaf(x1, g.z, accM[n4 * 4 + 2]); accM[n4 * 4 + 3] = __builtin_fmaf(x1, g.w, accM[n4 * 4 + 3]);
+          accS[n4 * 4 + 0] = __builtin_fmaf(x2, h.x, accS[n4 * 4 + 0]); accS[n4 * 4 + 1] = __builtin_fmaf(x2, h.y, accS[n4 * 4 + 1]);
+          accS[n4 * 4 + 2] = __builtin_fmaf(x2, h.z, accS[n4 * 4 + 2]); accS[n4 * 4 + 3] = __builtin_fmaf(x2, h.w, accS[n4 * 4 + 3]);
+        }
+      }
+    }
+    if (b_ok) {
+      float cs = 0.f;
+      for (int b = 0; b < B; ++b) cs += gzs[b * 16 + tid];
+      float e4[4];
+      philox_normal4((uint32_t)(tid >> 2), sample_base + (uint32_t)s, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+      const float e = (tid & 3) == 0 ? e4[0] : (tid & 3) == 1 ? e4[1] : (tid & 3) == 2 ? e4[2] : e4[3];
+      Gb += cs;
+      Hb = __builtin_fmaf(cs, e, Hb);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    red[0][(bg * 16 + n) * 16 + kc] = accM[n];
+    red[1][(bg * 16 + n) * 16 + kc] = accS[n];
+  }
+  __syncthreads();
+  {
+    const int n = tid >> 4, c = tid & 15;
+    const int k = k0 + c;
+    if (n < N && k < K) {
+      float gm = 0.f, gsv = 0.f;
+      for (int g = 0; g < 16; ++g) {
+        gm += red[0][(g * 16 + n) * 16 + c];
+        gsv += red[1][(g * 16 + n) * 16 + c];
+      }
+      const float cw = p.gkl ? p.gkl[0] + p.gkl[1] : 0.f;
+      const size_t off = (size_t)k * N + n;
+      const float m = p.w_mu[off], r = p.w_rho[off];
+      const float sg = softplus(r);
+      p.g_wmu[off] = gm + cw * m * p.inv_var_p;
+      p.g_wrho[off] = (2.f * sg * gsv + cw * (sg * p.inv_var_p - __builtin_amdgcn_rcpf(sg))) * lr_sigmoid(r);
+    }
+  }
+  if (b_ok) {
+    const float cb = p.gkl ? p.gkl[0] + p.gkl[2] : 0.f;
+    const float bm = p.b_mu[tid], br = p.b_rho[tid];
+    const float sb = softplus(br);
+    p.g_bmu[tid] = Gb + cb * bm * p.inv_var_p;
+    p.g_brho[tid] = (Hb + cb * (sb * p.inv_var_p - __builtin_amdgcn_rcpf(sb))) * lr_sigmoid(br);
+  }
+}
+
 }  // namespace bnn
 
 using namespace bnn;
@@ -547,6 +735,32 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   float* h = reinterpret_cast<float*>(base + act);
 
   const uint32_t k0 = (uint32_t)a->seed, k1 = (uint32_t)(a->seed >> 32);
+  if (N <= 16 && B <= 128 && a->g_x && a->eps_mode == BNN_EPS_PHILOX) {
+    // narrow output layer: prep, both weight gradients and the input gradient in one launch
+    LrBwdK kk;
+    kk.x = a->x;
+    kk.x_sstride = a->x_per_sample ? (long)B * K : 0;
+    kk.gz = nullptr; kk.h = nullptr;
+    kk.w_mu = a->w_mu; kk.w_rho = a->w_rho; kk.b_mu = a->b_mu; kk.b_rho = a->b_rho;
+    kk.eps_b = nullptr; kk.gkl = a->g_kl;
+    kk.g_wmu = a->g_w_mu; kk.g_wrho = a->g_w_rho; kk.g_bmu = a->g_b_mu; kk.g_brho = a->g_b_rho; kk.g_x = a->g_x;
+    kk.S = S; kk.B = B; kk.K = K; kk.N = N;
+    kk.eps_mode = a->eps_mode; kk.k0 = k0; kk.k1 = k1; kk.layer_id = a->layer_id; kk.sample_offset = a->sample_offset;
+    kk.sample_counter = a->sample_counter;
+    kk.gx_mask = a->gx_relu_mask ? 1 : 0;
+    kk.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
+    LrOutBwd o;
+    o.gy = a->gy; o.y = a->relu ? a->y : nullptr; o.v = a->v;
+    o.wblocks = (K + 15) / 16;
+    o.kchunks = (K + 63) / 64;
+    o.rchunks = S * ((B + 31) / 32);
+    const long nblk = (long)o.wblocks + (long)o.kchunks * o.rchunks;
+    if (nblk < (1L << 30)) {
+      hipLaunchKernelGGL(lr_out_layer_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, kk, o);
+      const hipError_t e1 = hipGetLastError();
+      return e1 == hipSuccess ? BNN_OK : (int)e1;
+    }
+  }
   const long groups = (long)S * B * ((N + 3) / 4);
   long nb = (groups + 255) / 256;
   nb = nb > 4096 ? 4096 : nb;

@@ -516,8 +516,10 @@ typedef struct bnn_lr_bwd_args {
   const float* b_rho;
   int32_t eps_mode;
   int32_t math;               /* bnn_math.  BNN_MATH_BF16: the input gradient's two products take bf16-rounded operands
-                                 (fp32 accumulation), as the forward of that mode does; the weight gradients stay on
-                                 the exact-fp32 matrix core */
+                                 (fp32 accumulation), as the forward of that mode does (out_features % 8 == 0); the
+                                 weight gradients stay on the exact-fp32 matrix core.  A narrow output layer
+                                 (<= 16 outputs, batch <= 128, on-chip eps, g_x wanted) is one launch of plain fp32
+                                 FMAs in either mode */
   const float* eps_act;       /* BNN_EPS_MEMORY */
   const float* eps_b;
   uint64_t seed;

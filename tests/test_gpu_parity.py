@@ -515,7 +515,9 @@ def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape, eps_m
 
 @pytest.mark.parametrize("eps_mode", ["philox", "memory"])
 @pytest.mark.parametrize("shape", [(3, 20, 72, 38, True), (2, 128, 1200, 1200, True), (2, 128, 784, 1200, True),
-                                   (1, 8, 50, 1, False), (2, 5, 33, 65, False), (1, 7, 1, 50, True)])
+                                   (1, 8, 50, 1, False), (2, 5, 33, 65, False), (1, 7, 1, 50, True),
+                                   # narrow output layers (on-chip eps: one launch, lr_out_layer_bwd_kernel)
+                                   (2, 128, 1200, 10, False), (3, 100, 72, 16, True), (5, 20, 33, 3, True)])
 def test_lr_backward_kernels_match_tensor_op_gradients(dev, shape, eps_mode):
     """F1: bnn_lr_linear_bwd (eps regenerated on chip, v saved by the forward, fp32 matrix core)
     against the closed-form gradients evaluated with tensor ops on the same eps (the path golden

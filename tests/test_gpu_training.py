@@ -208,7 +208,7 @@ def test_lr_input_gradient_in_bf16_math():
     from bnn_hip import ops, _lib as L
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(12)
-    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 40), (1, 7, 33, 16)):
+    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 40), (1, 7, 33, 24)):     # (<= 16 outputs: the fp32 one-launch form)
         mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
         x = torch.relu(mk(S, B, K, lo=-1, hi=1))
         gy, v = mk(S, B, N, lo=-1, hi=1), mk(S, B, N, lo=0.1, hi=1.0)
