@@ -74,7 +74,7 @@ class GraphedTrainStep:
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
-        self.fin_scratch = None if net.local_reparam else ops.final_scratch(self.samples, dev)   # K-slices of the fused output layer
+        self.fin_scratch = ops.final_scratch(self.samples, dev)   # hand-off words of the row-split / K-sliced output layer
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
         self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
         offs, tot = [], 0
@@ -215,6 +215,17 @@ class GraphedTrainStep:
             common = dict(n_samples=S, math_mode=state.math, relu=sp.relu, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
                           seed=state.seed, layer_id=sp.layer_id, sample_offset=first, sample_counter=self.counter)
             hin = h16 if h16 is not None else h
+            if sp.lr and i == len(specs) - 1:
+                # output layer + finalize + loss tail through bnn_lr_final_fwd: one launch when the layer is narrow and its
+                # input is bf16 (K3r; it also saves the variance for the backward), else layer, finalize, loss launches
+                ws_last = ops.lr_workspace(sp.in_out[1], h.device)
+                out, fin = ops.lr_final_fwd((hin,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
+                                                             workspace=ws_last, **common),
+                                            dict(workspaces=wss + [ws_last], scratch=self.fin_scratch,
+                                                 loss=dict(beta=self.beta, total_samples=S, grad_scale=1.0 / self.world), **fin_kw))
+                saved.append((h, out["y"], out.get("v"), p))
+                h = out["y"]
+                continue
             if sp.lr:
                 out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
                                         want_y16=self.x16 is not None and i < len(specs) - 1, **common)

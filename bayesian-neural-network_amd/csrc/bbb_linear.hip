@@ -741,40 +741,6 @@ struct FinRows {
   float* parts;         // [S][16]: 0..7 the row blocks' NLL, 8 / 9 log p (KL) / log q
 };
 
-// The training step's tail riding on K1r (bnn_loss_args): each row block differentiates its rows' NLL
-// (elbo_loss_nll_bwd_kernel's arithmetic), the block that finishes the evaluation assembles the loss and the seeds
-// (elbo_loss_block's arithmetic, fp64 sums in sample order).  out4 == nullptr: no tail.
-struct FinLoss {
-  const float* beta;
-  float total, grad_scale, inv_var;
-  float* out4;
-  float* g_a;
-  float* g_b;
-  float* g_kl3;
-  float* g_logits;
-};
-
-__device__ __forceinline__ void fin_loss_assemble(const FinK& fk, const FinLoss& tr) {
-  double x = 0, y = 0, z = 0;
-  for (int i = 0; i < fk.S; ++i) {
-    x += __hip_atomic_load(fk.log_prior + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    y += __hip_atomic_load(fk.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    z += __hip_atomic_load(fk.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const float beta = *tr.beta;
-  const float inv = tr.grad_scale / tr.total;
-  for (int i = 0; i < fk.S; ++i) {
-    if (tr.g_a) tr.g_a[i] = -beta * inv;
-    if (tr.g_b) tr.g_b[i] = beta * inv;
-  }
-  const float am = (float)x / tr.total, bm = (float)y / tr.total, nm = (float)z / tr.total;
-  tr.out4[0] = beta * bm - beta * am + nm;
-  tr.out4[1] = am;
-  tr.out4[2] = bm;
-  tr.out4[3] = nm;
-  if (tr.g_kl3) { tr.g_kl3[0] = beta * tr.grad_scale; tr.g_kl3[1] = 0.f; tr.g_kl3[2] = 0.f; }
-}
-
 template <bool XF32>
 __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, const FinPack fp, const FinLoss tr) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4][64];
@@ -879,26 +845,14 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
           for (int c = 0; c < C; ++c) se += __expf(lg[lane][c] - mx);
           const float picked = (tc >= 0 && tc < C) ? lg[lane][(int)tc] : __builtin_nanf("");
           acc_n = (mx + __logf(se)) - picked;
-          if (tr.out4) {
-            float* go = tr.g_logits + ((size_t)s * p.B + brow) * C;
-            const float gs = tr.grad_scale / tr.total;
-            float se2 = 0.f;
-            for (int c = 0; c < C; ++c) se2 += expf(lg[lane][c] - mx);
-            const float inv = (tc >= 0 && tc < C) ? 1.0f / se2 : __builtin_nanf("");
-            for (int c = 0; c < C; ++c) go[c] = (expf(lg[lane][c] - mx) * inv - (c == tc ? 1.f : 0.f)) * gs;
-          }
         } else {
           const float* tgt = reinterpret_cast<const float*>(fk.target) + (fk.group > 0 ? (s / fk.group) * fk.tgt_stride : 0);
           for (int c = 0; c < C; ++c) {
             const float d = tgt[(size_t)brow * C + c] - lg[lane][c];
             acc_n += (float)((double)(d * d) * fp.c.reg_inv2var + fp.c.reg_const);
           }
-          if (tr.out4) {
-            float* go = tr.g_logits + ((size_t)s * p.B + brow) * C;
-            const float gs = tr.grad_scale / tr.total;
-            for (int c = 0; c < C; ++c) go[c] = (lg[lane][c] - tgt[(size_t)brow * C + c]) * tr.inv_var * gs;
-          }
         }
+        if (tr.out4) fin_loss_row_grad(fk, tr, s, p.B, brow, lg[lane]);
       }
       pub0 = wave_sum(acc_n);
     }
@@ -1681,20 +1635,9 @@ extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples) {
 // Last layer + ELBO finalize.  Fused into ONE launch when the layer is a single 16-feature
 // tile over a single 128-row batch block (MNIST: 10 classes; regression: 1 output); otherwise
 // the two launches of bnn_bbb_linear_fwd + bnn_elbo_finalize.
-// reduce.hip
-extern "C" int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float* nll, const float* beta, int32_t n_samples,
-                                     float total_samples, float grad_scale, int32_t local_reparam, float* out4, float* g_a,
-                                     float* g_b, float* g_kl3, const float* logits, const void* target, float* g_logits,
-                                     int32_t batch, int32_t classes, int32_t nll_mode, float nll_sigma, void* stream_);
-
-// the training step's tail as its own launch (f->loss set, and the launch that finalized did not carry it)
-static int loss_tail(const bnn_finalize_args* f, void* stream_) {
-  const bnn_loss_args* t = f->loss;
-  if (!t) return BNN_OK;
-  return bnn_elbo_loss_nll_bwd(f->local_reparam ? f->kl : f->log_prior, f->local_reparam ? nullptr : f->log_q, f->nll, t->beta,
-                               f->n_samples, t->total_samples, t->grad_scale, f->local_reparam, t->out4, t->g_a, t->g_b, t->g_kl3,
-                               f->logits, f->target, t->g_logits, f->batch, f->classes, f->nll_mode, f->nll_sigma, stream_);
-}
+// reduce.hip: the training step's tail as its own launch (f->loss set, and the launch that finalized did not carry it)
+extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_);
+static int loss_tail(const bnn_finalize_args* f, void* stream_) { return bnn_loss_tail_(f, stream_); }
 
 extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
   BbbK k;
@@ -1705,11 +1648,8 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   rc = make_fin(f, fp.k, fp.c);
   if (rc != BNN_OK) return rc;
   const int nl = f->n_layers;
-  if (f->loss) {
-    const bnn_loss_args* t = f->loss;
-    if (!t->beta || !t->out4 || !t->g_logits || !f->logits || !f->target || !f->nll || !(t->total_samples > 0.f)) return BNN_ERR_NULL;
-    if (f->group_samples > 0 || (!f->local_reparam && (!f->log_prior || !f->log_q))) return BNN_ERR_SHAPE;
-  }
+  rc = check_fin_loss(f);
+  if (rc != BNN_OK) return rc;
   if (a->w_sampled) {
     // ---- pre-sampled output layer: the row-split form (K1r) when the shapes allow it, else matmul-only K1 + K4
     const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features;
@@ -1723,13 +1663,7 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
       if (rc == BNN_OK) rc = bnn_elbo_finalize(f, stream_);
       return rc != BNN_OK ? rc : loss_tail(f, stream_);
     }
-    FinLoss tr{};
-    if (f->loss) {
-      const bnn_loss_args* t = f->loss;
-      tr.beta = t->beta; tr.total = t->total_samples; tr.grad_scale = t->grad_scale;
-      tr.inv_var = f->nll_mode == BNN_NLL_REGRESSION ? (float)(1.0 / ((double)f->nll_sigma * f->nll_sigma)) : 0.f;
-      tr.out4 = t->out4; tr.g_a = t->g_a; tr.g_b = t->g_b; tr.g_kl3 = t->g_kl3; tr.g_logits = t->g_logits;
-    }
+    const FinLoss tr = make_fin_loss(f);
     FinRows fr;
     fr.x = a->x;
     fr.x_sstride = k.x_sstride; fr.xg = k.xg;

@@ -326,4 +326,80 @@ __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b
   if (p.nll) p.nll[s] = nll;
 }
 
+// The training step's tail riding on the row-split final kernels K1r / K3r (bnn_loss_args): each row block
+// differentiates its rows' NLL (elbo_loss_nll_bwd_kernel's arithmetic), the block that finishes the evaluation assembles
+// the loss and the seeds (elbo_loss_block's arithmetic, fp64 sums in sample order).  out4 == nullptr: no tail.
+struct FinLoss {
+  const float* beta;
+  float total, grad_scale, inv_var;
+  float* out4;
+  float* g_a;
+  float* g_b;
+  float* g_kl3;
+  float* g_logits;
+};
+
+__device__ __forceinline__ void fin_loss_assemble(const FinK& fk, const FinLoss& tr) {
+  const float* pa = fk.local_reparam ? fk.kl : fk.log_prior;
+  double x = 0, y = 0, z = 0;
+  for (int i = 0; i < fk.S; ++i) {
+    x += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!fk.local_reparam) y += __hip_atomic_load(fk.log_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    z += __hip_atomic_load(fk.nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const float beta = *tr.beta;
+  const float inv = tr.grad_scale / tr.total;
+  for (int i = 0; i < fk.S; ++i) {
+    if (tr.g_a) tr.g_a[i] = fk.local_reparam ? 0.f : -beta * inv;
+    if (tr.g_b) tr.g_b[i] = beta * inv;
+  }
+  const float am = (float)x / tr.total, bm = (float)y / tr.total, nm = (float)z / tr.total;
+  tr.out4[0] = fk.local_reparam ? beta * am + nm : beta * bm - beta * am + nm;
+  tr.out4[1] = am;
+  tr.out4[2] = bm;
+  tr.out4[3] = nm;
+  if (tr.g_kl3) { tr.g_kl3[0] = beta * tr.grad_scale; tr.g_kl3[1] = 0.f; tr.g_kl3[2] = 0.f; }
+}
+
+// d (summed NLL of row `brow` of sample s) / d logits, scaled by grad_scale / total, from the block's logits in LDS
+// (`lgrow`: the row's C logits)
+__device__ __forceinline__ void fin_loss_row_grad(const FinK& fk, const FinLoss& tr, int s, int B, int brow, const float* lgrow) {
+  const int C = fk.C;
+  float* go = tr.g_logits + ((size_t)s * B + brow) * C;
+  const float gs = tr.grad_scale / tr.total;
+  if (fk.nll_mode == BNN_NLL_CLASSIFICATION) {
+    const long long tc = reinterpret_cast<const long long*>(fk.target)[brow];
+    float mx = lgrow[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lgrow[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lgrow[c] - mx);
+    const float inv = (tc >= 0 && tc < C) ? 1.0f / se : __builtin_nanf("");   // bad label: NaN, as in nll_bwd_kernel
+    for (int c = 0; c < C; ++c) go[c] = (expf(lgrow[c] - mx) * inv - (c == tc ? 1.f : 0.f)) * gs;
+  } else {
+    const float* tg = reinterpret_cast<const float*>(fk.target) + (size_t)brow * C;
+    for (int c = 0; c < C; ++c) go[c] = (lgrow[c] - tg[c]) * tr.inv_var * gs;
+  }
+}
+
+static inline FinLoss make_fin_loss(const bnn_finalize_args* f) {
+  FinLoss tr{};
+  if (f->loss) {
+    const bnn_loss_args* t = f->loss;
+    tr.beta = t->beta; tr.total = t->total_samples; tr.grad_scale = t->grad_scale;
+    tr.inv_var = f->nll_mode == BNN_NLL_REGRESSION ? (float)(1.0 / ((double)f->nll_sigma * f->nll_sigma)) : 0.f;
+    tr.out4 = t->out4; tr.g_a = t->g_a; tr.g_b = t->g_b; tr.g_kl3 = t->g_kl3; tr.g_logits = t->g_logits;
+  }
+  return tr;
+}
+
+// validation of f->loss for the launch functions that honour it
+static inline int check_fin_loss(const bnn_finalize_args* f) {
+  if (!f->loss) return BNN_OK;
+  const bnn_loss_args* t = f->loss;
+  if (!t->beta || !t->out4 || !t->g_logits || !f->logits || !f->target || !f->nll || !(t->total_samples > 0.f)) return BNN_ERR_NULL;
+  if (f->group_samples > 0) return BNN_ERR_SHAPE;
+  if (f->local_reparam ? !f->kl : (!f->log_prior || !f->log_q)) return BNN_ERR_SHAPE;
+  return BNN_OK;
+}
+
 }  // namespace bnn

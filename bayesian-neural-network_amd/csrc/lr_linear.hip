@@ -926,6 +926,7 @@ struct LrRows {
   int xg;
   const float *w_mu, *w_rho, *b_mu, *b_rho;   // [K, N], [N]
   float* y;             // [S, B, N]
+  float* v_out;         // optional [S, B, N]: the variance the rows were sampled from (a training step's backward reads it)
   int S, B, K, N, relu;
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
@@ -942,7 +943,7 @@ struct LrFin {
   uint32_t* ticket;
 };
 
-__global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, const LrFin fp) {
+__global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, const LrFin fp, const FinLoss tr) {
   __shared__ __attribute__((aligned(16))) f32x4 red_m[4][64], red_v[4][64];
   __shared__ float lg[16][17];
   __shared__ __attribute__((aligned(8))) float part[4 * kFinNV];
@@ -1138,6 +1139,12 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
           for (int i = 0; i < 4; ++i)
             if (q * 4 + i < N) yp[i] = o4[i];
         }
+        if (p.v_out) {
+          float* vp = p.v_out + ((size_t)s * B + brow) * N + q * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < N) vp[i] = v[i];
+        }
       }
     }
     __syncthreads();
@@ -1162,6 +1169,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
             acc_n += (float)((double)(d * d) * fp.c.reg_inv2var + fp.c.reg_const);
           }
         }
+        if (tr.out4) fin_loss_row_grad(fk, tr, s, B, brow, lg[lane]);
       }
       pub0 = wave_sum(acc_n);
     }
@@ -1188,6 +1196,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
     if (fp.sums) {
       fp.sums[0] = a; fp.sums[1] = 0.f; fp.sums[2] = nll; fp.sums[3] = 1.f;
     }
+    if (tr.out4) fin_loss_assemble(fk, tr);
     if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
     return;
   }
@@ -1195,6 +1204,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
   const uint32_t t2 = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t2 != (uint32_t)fk.S - 1u) return;
   if (fp.sums) fin_fold_sums(fk, fp.sums);
+  if (tr.out4) fin_loss_assemble(fk, tr);
   __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
 }
@@ -1478,6 +1488,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
 }
 
 extern "C" size_t bnn_bbb_final_scratch_bytes(int32_t n_samples);   // bbb_linear.hip: the same scratch layout serves K3r
+extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_);   // reduce.hip
 
 // Last LR layer + ELBO finalize: ONE launch (K3r) for a few-sample evaluation with a narrow output layer, else
 // bnn_lr_linear_fwd followed by bnn_elbo_finalize.
@@ -1488,10 +1499,12 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   LrFin fp;
   rc = make_fin(f, fp.k, fp.c);
   if (rc != BNN_OK) return rc;
+  rc = check_fin_loss(f);
+  if (rc != BNN_OK) return rc;
   const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features, nl = f->n_layers;
   const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 16 &&
                     (K % 8) == 0 && K <= 2048 && !(reinterpret_cast<uintptr_t>(a->x) & 15) && a->eps_mode == BNN_EPS_PHILOX &&
-                    !a->eps_act_dump && !a->eps_b_dump && !a->v_out && !a->y_sq && !a->y_bf16_copy && !a->kl_out && a->form == BNN_FORM_AUTO &&
+                    !a->eps_act_dump && !a->eps_b_dump && !a->y_sq && !a->y_bf16_copy && !a->kl_out && a->form == BNN_FORM_AUTO &&
                     f->local_reparam && nl >= 1 && nl <= 8 && f->n_samples == S && f->classes == N && f->batch == B &&
                     f->logits == a->y && f->nll && f->kl && f->layer_in[nl - 1] == K && f->layer_out[nl - 1] == N &&
                     f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
@@ -1499,13 +1512,16 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
                     (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(a->y) & 15));
   if (!rows) {
     rc = bnn_lr_linear_fwd(a, stream_);
-    return rc != BNN_OK ? rc : bnn_elbo_finalize(f, stream_);
+    if (rc == BNN_OK) rc = bnn_elbo_finalize(f, stream_);
+    return rc != BNN_OK ? rc : bnn_loss_tail_(f, stream_);
   }
+  const FinLoss tr = make_fin_loss(f);
   LrRows r;
   r.x = reinterpret_cast<const __bf16*>(a->x);
   r.x_sstride = k.x_sstride; r.xg = k.xg;
   r.w_mu = a->w_mu; r.w_rho = a->w_rho; r.b_mu = a->b_mu; r.b_rho = a->b_rho;
   r.y = reinterpret_cast<float*>(a->y);
+  r.v_out = a->v_out;
   r.S = S; r.B = B; r.K = K; r.N = N; r.relu = a->relu ? 1 : 0;
   r.k0 = k.k0; r.k1 = k.k1; r.layer_id = k.layer_id; r.sample_offset = k.sample_offset; r.sample_counter = k.sample_counter;
   r.sgrp = k.sgrp; r.sgrp_stride = k.sgrp_stride;
@@ -1521,7 +1537,7 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e0 != hipSuccess) return (int)e0;
   }
-  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp);
+  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

@@ -534,6 +534,16 @@ extern "C" int bnn_elbo_loss_nll_bwd(const float* a, const float* b, const float
   return err == hipSuccess ? BNN_OK : (int)err;
 }
 
+// the training step's tail (bnn_finalize_args.loss) as its own launch, for the launch functions whose finalizing
+// launch did not carry it
+extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_) {
+  const bnn_loss_args* t = f->loss;
+  if (!t) return BNN_OK;
+  return bnn_elbo_loss_nll_bwd(f->local_reparam ? f->kl : f->log_prior, f->local_reparam ? nullptr : f->log_q, f->nll, t->beta,
+                               f->n_samples, t->total_samples, t->grad_scale, f->local_reparam, t->out4, t->g_a, t->g_b, t->g_kl3,
+                               f->logits, f->target, t->g_logits, f->batch, f->classes, f->nll_mode, f->nll_sigma, stream_);
+}
+
 extern "C" int bnn_stage_inputs_cast(const void* src0, void* dst0, size_t bytes0, const void* src1, void* dst1, size_t bytes1,
                                      float* word, float value, void* cast0_bf16, void* stream_);
 

@@ -230,6 +230,44 @@ def test_lr_input_gradient_in_bf16_math():
 
 
 @pytest.mark.parametrize("mode", ["classification", "regression"])
+def test_lr_final_launch_with_loss_tail_and_saved_variance(mode):
+    """bnn_lr_final_fwd as the training step calls it: the row-split launch (K3r) also saves the variance for the backward
+    and carries the loss tail (bnn_finalize_args.loss); reference = bnn_lr_linear_fwd (K3a, want_v) + bnn_elbo_finalize +
+    bnn_elbo_loss_nll_bwd on the same Philox elements.  The two forms sum the k range in different orders."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(41)
+    shapes = ((1, 128, 1200, 10), (2, 128, 1200, 10), (3, 37, 64, 3), (2, 16, 64, 24)) if mode == "classification" else \
+        ((1, 128, 56, 1), (3, 50, 400, 1))
+    for S, B, K, N in shapes:
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        p = (mk(K, N), mk(K, N, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4))
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1)).to(torch.bfloat16).contiguous()
+        y = (torch.from_numpy(rs.randint(0, N, B)).to(dev) if mode == "classification" else mk(B, N, lo=-1, hi=1))
+        beta = torch.full((), 0.37, dtype=torch.float32, device=dev)
+        kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=False, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX,
+                  seed=7, layer_id=2, sample_offset=11, want_kl=True, want_v=True)
+        fin_kw = dict(layer_in=[K], layer_out=[N], local_reparam=True, prior=ops.PriorSpec(False, 1.0), n_samples=S, target=y,
+                      mode=mode, nll_sigma=0.3)
+        ws = ops.lr_workspace(N, dev)
+        one, fin = ops.lr_final_fwd((x,) + p, dict(workspace=ws, **kw),
+                                    dict(workspaces=[ws], scratch=ops.final_scratch(S, dev),
+                                         ticket=torch.zeros(1, dtype=torch.int32, device=dev) if S > 1 else None,
+                                         loss=dict(beta=beta, total_samples=S, grad_scale=0.5), **fin_kw))
+        ws2 = ops.lr_workspace(N, dev)
+        ref = ops.lr_linear_fwd(x, *p, workspace=ws2, **kw)
+        fin2 = ops.elbo_finalize(workspaces=[ws2], logits=ref["y"], **fin_kw)
+        loss2 = ops.elbo_loss_nll_bwd(fin2["kl"], None, fin2["nll"], beta, S, True, ref["y"], y, mode, 0.3, grad_scale=0.5)
+        torch.cuda.synchronize()
+        close = lambda a, b, tol: float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-12
+        assert close(one["y"], ref["y"], 1e-4) and close(one["v"], ref["v"], 1e-4), (mode, S, B, K, N)
+        assert close(fin["kl"], fin2["kl"], 1e-5) and close(fin["nll"], fin2["nll"], 1e-4), (mode, S, B, K, N)
+        for i, (a, b) in enumerate(zip(fin["loss"], loss2)):
+            assert torch.isfinite(b).all()
+            assert close(a, b, 2e-4), (mode, S, B, K, N, i)
+
+
+@pytest.mark.parametrize("mode", ["classification", "regression"])
 def test_loss_tail_on_the_final_launch_equals_the_separate_launch(mode):
     """bnn_finalize_args.loss: the row-split final launch (bnn_bbb_final_fwd over sampled weights) also differentiates
     the rows' NLL and assembles the loss and the seeds; bnn_elbo_loss_nll_bwd on the same per-sample scalars and logits
