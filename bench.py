@@ -363,6 +363,30 @@ def timed_config(engine, net, x, y, S_global, G, steps, dist=None, every_eval=Fa
     return ev, S_global * full * g / dt, dt * 1e6 / (full * g)
 
 
+def training_step_ms(dims, lr, batch, dev, mode, samples=2, steps=300):
+    """One optimiser step of bnn_hip.train.GraphedTrainStep (forward of `samples` MC samples, backward, fused Adam) in the
+    math mode of the run, HIP events around `steps` replays on fresh synthetic minibatches."""
+    import torch
+    from bnn_hip.optim import FusedAdam
+    from bnn_hip.train import GraphedTrainStep
+    net, x, y = build_net(dims, lr, batch, dev, mode, n_minibatches=1)
+    x, y = x[0].contiguous(), y[0].contiguous()                 # build_net stacks the minibatches: [1, batch, ...]
+    opt = FusedAdam(net.parameters(), lr=1e-4, capturable=True)
+    g = GraphedTrainStep(net, opt, x, y, samples)
+    for _ in range(5):
+        g.step(x, y, 0.5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        g.step(x, y, 0.5)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"variant": "LR" if lr else "BBB", "mc_samples": samples, "batch": batch, "ms_per_step": ms, "steps_per_s": 1e3 / ms,
+            "what": "stage minibatch + forward + backward + fused Adam, one hipGraph replay per step"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -496,6 +520,9 @@ def main():
                              "kl_elements_per_s": rate * n_stochastic(DIMS["wide"]), "roofline": r5})
                 del e5, wnet, wx, wy
             extras["wide_4096"] = wide
+            # F1 / F2: the body of the reference's training loop (class_task.py:66-79: zero_grad, sample_elbo with
+            # train_samples = 2, backward, Adam) as one captured graph, BBB and the reference's own default (local_reparam)
+            extras["training_step"] = [training_step_ms(dims, lr_, args.batch, dev, mode) for lr_ in (False, True)]
         # C4 as SURVEY 8(e) words it: ONE minibatch, 64 / 512 MC samples over the ranks, one all-reduce per evaluation
         c4 = []
         for S_tot in (64, 512):

@@ -16,3 +16,5 @@ for w in e.get("wide_4096", []):
     print("  wide B=%d S=4: %.0f samples/s %.0f us/eval, [%s] %s %.1f us frac %.3f %s" % (w["batch"], w["samples_per_s"], w["us_per_evaluation"], r["bound"], r["kernel"][:40], r["avg_launch_us"], r["frac"], ("sampling %.1f us hbm %.3f" % (r["sampling"]["avg_launch_us"], r["sampling"]["hbm_frac"])) if "sampling" in r else ""))
 for c in e.get("c4", []):
     print("  c4 S=%d: %.0f samples/s %.1f us/eval" % (c["mc_samples_per_evaluation"], c["samples_per_s"], c["us_per_evaluation"]))
+for t in e.get("training_step", []):
+    print("  train step %s S=%d: %.3f ms" % (t["variant"], t["mc_samples"], t["ms_per_step"]))
