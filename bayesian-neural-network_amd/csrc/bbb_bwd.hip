@@ -317,6 +317,144 @@ __global__ __launch_bounds__(256, 3) void bbb_bwd_weights_kernel(const BwdK p) {
   BWD_STAMP_RT(9);
 }
 
+// weight (and bias) gradients of 16 k columns: the weight role of bbb_out_layer_bwd_kernel
+template <bool PAIR>
+__device__ __forceinline__ void out_bwd_weight_role(const BwdK& p, float* gzs, float* red) {
+  const int K = p.K, N = p.N, B = p.B, S = p.S;
+  const int tid = threadIdx.x;
+  const int k0 = (int)blockIdx.x * 16;
+  const int kc = tid & 15, bg = tid >> 4;
+  const int kx = min(k0 + kc, K - 1);
+  const bool k_ok = k0 + kc < K;
+  // epilogue threads: (feature, group of 4 k)
+  const int en = tid >> 2, eg = tid & 3;
+  const int ekb = k0 + eg * 4;
+  const bool e_ok = tid < 64 && en < N && ekb < K;          // K % 4 == 0: a group is whole or absent
+  const bool b_ok = blockIdx.x == 0 && tid >= 64 && tid < 64 + N;   // bias: thread 64 + n
+  const int bn = min(max(tid - 64, 0), N - 1);
+  const int gpr = (K + 3) >> 2;
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {1.f, 1.f, 1.f, 1.f}, rh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e_ok) {
+    const float4 m4 = *reinterpret_cast<const float4*>(p.w_mu + (size_t)en * K + ekb);
+    const float4 r4 = *reinterpret_cast<const float4*>(p.w_rho + (size_t)en * K + ekb);
+    mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+    rh[0] = r4.x; rh[1] = r4.y; rh[2] = r4.z; rh[3] = r4.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg[i] = softplus(rh[i]);
+  }
+  const float bmu = p.b_mu[bn], brh = p.b_rho[bn];
+  const float bsg = softplus(brh);
+  float G[4] = {0.f, 0.f, 0.f, 0.f}, H[4] = {0.f, 0.f, 0.f, 0.f}, Gb = 0.f, Hb = 0.f, cq = 0.f;
+  const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
+  // PAIR (112 < batch <= 128, the MNIST shape: J = 8 rows per thread and sample, known at compile time): samples go
+  // through in ROUNDS of two -- the x loads and the gz staging of both are one memory round trip, the per-sample
+  // epilogues that follow touch LDS only.
+  const int J = PAIR ? 8 : (B + 15) >> 4;                   // rows per thread and sample
+  constexpr int SP = PAIR ? 2 : 1;
+  for (int s0 = 0; s0 < S; s0 += SP) {
+    float xv[16], glp2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int sp = PAIR ? (j >> 3) : 0;
+      const int b = bg + 16 * (j - sp * J);
+      const int sm = min(s0 + sp, S - 1);
+      const float v = p.x[(size_t)sm * (size_t)p.x_sstride + (size_t)min(b, B - 1) * K + kx];
+      xv[j] = (j < J * SP && s0 + sp < S && b < B && k_ok) ? v : 0.f;
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const int sm = min(s0 + sp, S - 1);
+      glp2[sp] = p.glp ? p.glp[sm] : 0.f;
+      if (sp < SP && s0 + sp < S) cq += p.glq ? p.glq[sm] : 0.f;
+    }
+    __syncthreads();                                        // the previous round's readers of gzs / red are done
+    for (int sp = 0; sp < SP; ++sp) {
+      const float* gzg = p.gz + (size_t)min(s0 + sp, S - 1) * B * N;
+      for (int i = tid; i < B * 16; i += 256) {
+        const int b = i >> 4, n = i & 15;
+        gzs[sp * 128 * 16 + i] = n < N ? gzg[(size_t)b * N + n] : 0.f;
+      }
+    }
+    __syncthreads();
+    float acc[2][16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) acc[0][n] = acc[1][n] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < J * SP) {
+        const int sp = PAIR ? (j >> 3) : 0;
+        const int b = min(bg + 16 * (j - sp * J), B - 1);
+        const float4* g4 = reinterpret_cast<const float4*>(gzs + (sp * 128 + b) * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float4 g = g4[v];
+          if (sp == 0) {
+            acc[0][4 * v + 0] = __builtin_fmaf(xv[j], g.x, acc[0][4 * v + 0]);
+            acc[0][4 * v + 1] = __builtin_fmaf(xv[j], g.y, acc[0][4 * v + 1]);
+            acc[0][4 * v + 2] = __builtin_fmaf(xv[j], g.z, acc[0][4 * v + 2]);
+            acc[0][4 * v + 3] = __builtin_fmaf(xv[j], g.w, acc[0][4 * v + 3]);
+          } else {
+            acc[1][4 * v + 0] = __builtin_fmaf(xv[j], g.x, acc[1][4 * v + 0]);
+            acc[1][4 * v + 1] = __builtin_fmaf(xv[j], g.y, acc[1][4 * v + 1]);
+            acc[1][4 * v + 2] = __builtin_fmaf(xv[j], g.z, acc[1][4 * v + 2]);
+            acc[1][4 * v + 3] = __builtin_fmaf(xv[j], g.w, acc[1][4 * v + 3]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      red[(bg * 16 + n) * 16 + kc] = acc[0][n];
+      red[4096 + (bg * 16 + n) * 16 + kc] = acc[1][n];
+    }
+    __syncthreads();
+    for (int sp = 0; sp < SP && s0 + sp < S; ++sp) {
+      const float glp = glp2[sp];
+      const uint32_t gs = sample_base + (uint32_t)(s0 + sp);
+      const float* rd = red + sp * 4096;
+      if (e_ok) {
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tot[i] += rd[(g * 16 + en) * 16 + eg * 4 + i];
+        }
+        float e[4];
+        philox_normal4((uint32_t)en * (uint32_t)gpr + (uint32_t)(ekb >> 2), gs, p.layer_id * 4u, p.k0, p.k1, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float w = __builtin_fmaf(sg[i], e[i], mu[i]);
+          const float t = tot[i] + glp * dlogp(p, w);
+          G[i] += t;
+          H[i] = __builtin_fmaf(t, e[i], H[i]);
+        }
+      }
+      if (b_ok) {
+        float colsum = 0.f;
+        for (int b = 0; b < B; ++b) colsum += gzs[(sp * 128 + b) * 16 + bn];
+        float e4[4];
+        philox_normal4((uint32_t)(bn >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+        const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
+        const float bw = __builtin_fmaf(bsg, e, bmu);
+        const float t = colsum + glp * dlogp(p, bw);
+        Gb += t;
+        Hb = __builtin_fmaf(t, e, Hb);
+      }
+    }
+  }
+  if (e_ok) {
+    float gr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gr[i] = (H[i] - cq * __builtin_amdgcn_rcpf(sg[i])) * sigmoidf(rh[i]);
+    const size_t off = (size_t)en * K + ekb;
+    *reinterpret_cast<float4*>(p.g_wmu + off) = make_float4(G[0], G[1], G[2], G[3]);
+    *reinterpret_cast<float4*>(p.g_wrho + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+  }
+  if (b_ok) {
+    p.g_bmu[bn] = Gb;
+    p.g_brho[bn] = (Hb - cq * __builtin_amdgcn_rcpf(bsg)) * sigmoidf(brh);
+  }
+}
+
 // Backward of a NARROW output layer (N <= 16: the 10 classes / the 1 regression output) over the step's pre-sampled
 // weights, weight gradients and input gradient in ONE launch.  The general kernels above and the K-split input
 // gradient are built for wide layers: at 1200 -> 10 they are 19 and 152 one-or-four-wave blocks walking the batch
@@ -335,9 +473,10 @@ struct OutBwd {
   int wblocks;
 };
 
+template <bool PAIR>
 __global__ __launch_bounds__(256) void bbb_out_layer_bwd_kernel(const BwdK p, const OutBwd o) {
   __shared__ __attribute__((aligned(16))) float gzs[256 * 16];     // [b][n] of the current sample, features padded to 16
-  __shared__ float red[16 * 16 * 16];                              // [bg][n][kc]
+  __shared__ float red[2 * 16 * 16 * 16];                          // [sample of the round][bg][n][kc]
   const int K = p.K, N = p.N, B = p.B, S = p.S;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= o.wblocks) {
@@ -378,111 +517,7 @@ __global__ __launch_bounds__(256) void bbb_out_layer_bwd_kernel(const BwdK p, co
     return;
   }
   // ---- weight (and bias) gradients of 16 k columns
-  const int k0 = (int)blockIdx.x * 16;
-  const int kc = tid & 15, bg = tid >> 4;
-  const int kx = min(k0 + kc, K - 1);
-  const bool k_ok = k0 + kc < K;
-  // epilogue threads: (feature, group of 4 k)
-  const int en = tid >> 2, eg = tid & 3;
-  const int ekb = k0 + eg * 4;
-  const bool e_ok = tid < 64 && en < N && ekb < K;          // K % 4 == 0: a group is whole or absent
-  const bool b_ok = blockIdx.x == 0 && tid >= 64 && tid < 64 + N;   // bias: thread 64 + n
-  const int bn = min(max(tid - 64, 0), N - 1);
-  const int gpr = (K + 3) >> 2;
-  float mu[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {1.f, 1.f, 1.f, 1.f}, rh[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e_ok) {
-    const float4 m4 = *reinterpret_cast<const float4*>(p.w_mu + (size_t)en * K + ekb);
-    const float4 r4 = *reinterpret_cast<const float4*>(p.w_rho + (size_t)en * K + ekb);
-    mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
-    rh[0] = r4.x; rh[1] = r4.y; rh[2] = r4.z; rh[3] = r4.w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sg[i] = softplus(rh[i]);
-  }
-  const float bmu = p.b_mu[bn], brh = p.b_rho[bn];
-  const float bsg = softplus(brh);
-  float G[4] = {0.f, 0.f, 0.f, 0.f}, H[4] = {0.f, 0.f, 0.f, 0.f}, Gb = 0.f, Hb = 0.f, cq = 0.f;
-  const uint32_t sample_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
-  const int J = (B + 15) >> 4;                              // rows per thread
-  for (int s = 0; s < S; ++s) {
-    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
-    const float* gzg = p.gz + (size_t)s * B * N;
-    float xv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int b = bg + 16 * j;
-      const float v = xs[(size_t)min(b, B - 1) * K + kx];
-      xv[j] = (j < J && b < B && k_ok) ? v : 0.f;
-    }
-    __syncthreads();                                        // the previous sample's readers of gzs / red are done
-    for (int i = tid; i < B * 16; i += 256) {
-      const int b = i >> 4, n = i & 15;
-      gzs[i] = n < N ? gzg[(size_t)b * N + n] : 0.f;
-    }
-    __syncthreads();
-    float acc[16];
-#pragma unroll
-    for (int n = 0; n < 16; ++n) acc[n] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j < J) {
-        const int b = min(bg + 16 * j, B - 1);
-        const float4* g4 = reinterpret_cast<const float4*>(gzs + b * 16);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const float4 g = g4[v];
-          acc[4 * v + 0] = __builtin_fmaf(xv[j], g.x, acc[4 * v + 0]);
-          acc[4 * v + 1] = __builtin_fmaf(xv[j], g.y, acc[4 * v + 1]);
-          acc[4 * v + 2] = __builtin_fmaf(xv[j], g.z, acc[4 * v + 2]);
-          acc[4 * v + 3] = __builtin_fmaf(xv[j], g.w, acc[4 * v + 3]);
-        }
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < 16; ++n) red[(bg * 16 + n) * 16 + kc] = acc[n];
-    __syncthreads();
-    const float glp = p.glp ? p.glp[s] : 0.f;
-    cq += p.glq ? p.glq[s] : 0.f;
-    const uint32_t gs = sample_base + (uint32_t)s;
-    if (e_ok) {
-      float tot[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int g = 0; g < 16; ++g) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tot[i] += red[(g * 16 + en) * 16 + eg * 4 + i];
-      }
-      float e[4];
-      philox_normal4((uint32_t)en * (uint32_t)gpr + (uint32_t)(ekb >> 2), gs, p.layer_id * 4u, p.k0, p.k1, e);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float w = __builtin_fmaf(sg[i], e[i], mu[i]);
-        const float t = tot[i] + glp * dlogp(p, w);
-        G[i] += t;
-        H[i] = __builtin_fmaf(t, e[i], H[i]);
-      }
-    }
-    if (b_ok) {
-      float colsum = 0.f;
-      for (int b = 0; b < B; ++b) colsum += gzs[b * 16 + bn];
-      float e4[4];
-      philox_normal4((uint32_t)(bn >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
-      const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
-      const float bw = __builtin_fmaf(bsg, e, bmu);
-      const float t = colsum + glp * dlogp(p, bw);
-      Gb += t;
-      Hb = __builtin_fmaf(t, e, Hb);
-    }
-  }
-  if (e_ok) {
-    float gr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gr[i] = (H[i] - cq * __builtin_amdgcn_rcpf(sg[i])) * sigmoidf(rh[i]);
-    const size_t off = (size_t)en * K + ekb;
-    *reinterpret_cast<float4*>(p.g_wmu + off) = make_float4(G[0], G[1], G[2], G[3]);
-    *reinterpret_cast<float4*>(p.g_wrho + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
-  }
-  if (b_ok) {
-    p.g_bmu[bn] = Gb;
-    p.g_brho[bn] = (Hb - cq * __builtin_amdgcn_rcpf(bsg)) * sigmoidf(brh);
-  }
+  out_bwd_weight_role<PAIR>(p, gzs, red);
 }
 
 // gz = gy * (y > 0)  (or a plain copy when there was no ReLU)
@@ -579,7 +614,10 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
     const long xthreads = (long)a->n_samples * a->batch * (a->in_features / 8);
     const long xblocks = (xthreads + 255) / 256;
     if (xblocks + o.wblocks < (1L << 30)) {
-      hipLaunchKernelGGL(bbb_out_layer_bwd_kernel, dim3((unsigned)(o.wblocks + xblocks)), dim3(256), 0, stream, k, o);
+      if (a->batch > 112 && a->batch <= 128 && a->n_samples > 1)
+        hipLaunchKernelGGL(bbb_out_layer_bwd_kernel<true>, dim3((unsigned)(o.wblocks + xblocks)), dim3(256), 0, stream, k, o);
+      else
+        hipLaunchKernelGGL(bbb_out_layer_bwd_kernel<false>, dim3((unsigned)(o.wblocks + xblocks)), dim3(256), 0, stream, k, o);
       err = hipGetLastError();
       return err == hipSuccess ? BNN_OK : (int)err;
     }
