@@ -341,6 +341,50 @@ def test_narrow_output_layer_backward_equals_the_general_kernels(relu):
         assert torch.equal(one[4] == 0, ref[4] == 0) or float(((one[4] == 0) != (ref[4] == 0)).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("math_mode", ["bf16", "f32"])
+@pytest.mark.parametrize("local_reparam", [False, True])
+def test_graphed_train_step_on_the_regression_config(local_reparam, math_mode):
+    """The captured step on the regression network (1-50-1, reg_task.py:60-73: 5 MC samples, sigma 0.1): none of the
+    MNIST shortcuts apply as they stand (in_features 1 and 50: no 16-byte rows, no pre-sampled weights; one output) and
+    every one of the step's forms must still agree with the eager loop on the same Philox elements -- first step to
+    fp32 / bf16 rounding, then the loss must go down."""
+    import networks
+    from bnn_hip.optim import FusedAdam
+    from bnn_hip.train import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    bnn_hip.set_math(math_mode)
+    mp = dict(input_shape=1, classes=1, batch_size=128, hidden_units=50, mode="regression", mu_init=[-0.2, 0.2],
+              rho_init=[-5, -4], prior_init=[1.0], mixture_prior=False, local_reparam=local_reparam)
+    torch.manual_seed(4)
+    net_a = networks.BayesianNetwork(mp).to(dev).train()
+    net_b = networks.BayesianNetwork(mp).to(dev).train()
+    net_b.load_state_dict(net_a.state_dict())
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.uniform(0, 0.6, (128, 1)).astype(np.float32)).to(dev)
+    y = (x + 0.3 * torch.sin(2 * np.pi * x)).contiguous()
+    S = 5
+    oa = FusedAdam(net_a.parameters(), lr=1e-3)
+    ob = FusedAdam(net_b.parameters(), lr=1e-3, capturable=True)
+    bnn_hip.manual_seed(31, counter=200)
+    g = GraphedTrainStep(net_b, ob, x, y, S, sigma=0.1)
+    first = [o.clone() for o in g.step(x, y, 0.01)]
+    grads_b = [p.grad.clone() for p in g.params]
+    bnn_hip.manual_seed(31, counter=200)
+    oa.zero_grad()
+    out = (net_a.sample_elbo_lr if local_reparam else net_a.sample_elbo)(x, y, 0.01, S, 0.1)
+    out[0].backward()
+    tol = 1e-5 if math_mode == "f32" else 2e-3
+    for got, want in zip(first, out):
+        assert float((got - want.detach()).abs().max()) <= tol * (float(want.detach().abs().max()) + 1e-6)
+    specs = net_a._specs()
+    grads_a = [p.grad for sp in specs for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
+    for ga, gb in zip(grads_a, grads_b):
+        assert float((ga - gb).norm()) <= (1e-4 if math_mode == "f32" else 2e-2) * (float(ga.norm()) + 1e-9)
+    losses = [float(first[0])] + [float(g.step(x, y, 0.01)[0]) for _ in range(150)]
+    assert np.isfinite(losses).all() and np.mean(losses[-10:]) < 0.7 * np.mean(losses[:10])
+    bnn_hip.set_math("f32")
+
+
 @pytest.mark.parametrize("autograd", [False, True])
 @pytest.mark.parametrize("local_reparam", [False, True])
 def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
