@@ -93,7 +93,7 @@ class LrFwdArgs(C.Structure):
         ("kl_out", C.c_void_p),
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
         ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
-        ("y_bf16_copy", C.c_void_p),
+        ("hfac_out", C.c_void_p), ("y_bf16_copy", C.c_void_p),
     ]
 
 
@@ -130,7 +130,7 @@ class LrBwdArgs(C.Structure):
         ("g_kl", C.c_void_p),
         ("g_w_mu", C.c_void_p), ("g_w_rho", C.c_void_p), ("g_b_mu", C.c_void_p), ("g_b_rho", C.c_void_p),
         ("g_x", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("sample_counter", C.c_void_p),
+        ("sample_counter", C.c_void_p), ("hfac", C.c_void_p),
     ]
 
 

@@ -368,7 +368,8 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   y_dtype: torch.dtype, eps_mode: int, eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0,
                   sample_offset: int = 0, want_kl: bool = True, want_scalars: bool = False,
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
-                  out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, form: int = 0, sample_group: int = 0,
+                  out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, want_hfac: bool = False, form: int = 0,
+                  sample_group: int = 0,
                   sample_group_stride: int = 0):
     """Argument block of K3 + the result dict + the tensors it points at."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
@@ -421,13 +422,17 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     if want_v:                                       # the variance the kernel sampled from: saved for bnn_lr_linear_bwd
         v = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
         a.v_out = v.data_ptr()
+    hfac = None
+    if want_hfac:                                    # eps_act / (2 sqrt(v)): lets bnn_lr_linear_bwd skip its preparation launch
+        hfac = torch.empty(tuple(y.shape), dtype=torch.float32, device=y.device)
+        a.hfac_out = hfac.data_ptr()
     y16 = None
     if want_y16:                                     # fp32 y for the backward, bf16 y for the next layer's forward
         if y.dtype != torch.float32:
             raise BnnHipError("want_y16 goes with fp32 y")
         y16 = torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=y.device)
         a.y_bf16_copy = y16.data_ptr()
-    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16)
+    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac)
     keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace)
     return a, res, keep
 
@@ -687,25 +692,31 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
 
 def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, relu: bool, eps_mode: int,
                   eps_act=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0, g_kl=None,
-                  want_gx: bool = True, sample_counter=None, out=None, gx_relu_mask: bool = False, math_mode: int = L.MATH_F32):
+                  want_gx: bool = True, sample_counter=None, out=None, gx_relu_mask: bool = False, math_mode: int = L.MATH_F32,
+                  hfac=None):
     """F1: backward of K3 (bnn_lr_linear_bwd).  All tensors fp32; `v` is the variance the forward
-    saved (lr_linear_fwd(want_v=True)); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
+    saved (lr_linear_fwd(want_v=True)), or None with `hfac` (lr_linear_fwd(want_hfac=True); relu must be False: no
+    preparation launch then); g_kl float[3] = upstream grads of (kl, weight_kl, bias_kl).
     Returns (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
     lib = L.load()
-    require_device(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, g_kl)
+    require_device(x, gy, y, v, hfac, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, g_kl)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     K, N = w_mu.shape
     xs, B, Kx, per_sample = _x3(_f32c(x, "x"), n_samples)
-    gy, v = _f32c(gy, "gy"), _f32c(v, "v")
-    if Kx != K or gy.numel() != n_samples * B * N or v.numel() != gy.numel():
+    gy = _f32c(gy, "gy")
+    v = _f32c(v, "v") if v is not None else None
+    hfac = _f32c(hfac, "hfac") if hfac is not None else None
+    if v is None and (hfac is None or relu):
+        raise BnnHipError("lr_linear_bwd: needs the forward's v (or its hfac for a layer without a fused ReLU)")
+    if Kx != K or gy.numel() != n_samples * B * N or any(t_ is not None and t_.numel() != gy.numel() for t_ in (v, hfac)):
         raise BnnHipError("lr_linear_bwd: shape mismatch")
     dev = xs.device
     a = L.LrBwdArgs()
     a.struct_bytes = C.sizeof(L.LrBwdArgs)
     a.n_samples, a.batch, a.in_features, a.out_features = n_samples, B, K, N
     a.x, a.x_per_sample, a.relu = xs.data_ptr(), per_sample, int(relu)
-    a.gy, a.v = gy.data_ptr(), v.data_ptr()
+    a.gy, a.v, a.hfac = gy.data_ptr(), _ptr(v), _ptr(hfac)
     if relu:
         y = _f32c(y, "y")
         a.y = y.data_ptr()

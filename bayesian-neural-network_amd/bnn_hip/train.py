@@ -227,12 +227,15 @@ class GraphedTrainStep:
                 h = out["y"]
                 continue
             if sp.lr:
-                out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
+                # a hidden layer's ReLU mask is applied by the input-gradient launch of the layer above, so its backward needs
+                # no mask pass: the forward saves eps / (2 sqrt(v)) instead of v and the backward no preparation launch
+                hf = i < len(specs) - 1
+                out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=not hf, want_hfac=hf,
                                         want_y16=self.x16 is not None and i < len(specs) - 1, **common)
             else:
                 out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True,
                                          want_y16=self.x16 is not None and i < len(specs) - 1, **common)
-            saved.append((h, out["y"], out.get("v"), p))
+            saved.append((h, out["y"], out.get("v"), p, out.get("hfac")))
             wss.append(out["workspace"])
             h, h16 = out["y"], out.get("y16")
         if fin is None:
@@ -262,7 +265,8 @@ class GraphedTrainStep:
         """Backward of layer i (weight gradients into the bucket; input gradient for the layer below)."""
         specs, saved, g_a, g_b, g_kl3, first, lr, top = self._bwd_state
         S, g, sp = self.samples, self._bwd_g, specs[i]
-        xin, y, v, p = saved[i]
+        xin, y, v, p = saved[i][:4]
+        hfac = saved[i][4] if len(saved[i]) > 4 else None
         # layer i's ReLU mask is applied by layer i+1's input-gradient kernel (its x IS layer i's output),
         # so only a top layer with a ReLU masks its own gy
         own_relu = sp.relu and i == top
@@ -271,7 +275,7 @@ class GraphedTrainStep:
                   gx_relu_mask=i > 0 and specs[i - 1].relu)
         if sp.lr:
             grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
-                                      math_mode=state.math, **kw)
+                                      math_mode=state.math, hfac=None if own_relu else hfac, **kw)
         else:
             grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
                                        g_log_prior=g_a, g_log_q=g_b,

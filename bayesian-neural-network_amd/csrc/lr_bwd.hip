@@ -46,6 +46,7 @@ struct LrBwdK {
   int S, B, K, N;
   int eps_mode;
   int gx_mask;           // g_x *= (x > 0): the ReLU of the layer below
+  int h_factor;          // h holds the forward's hfac (eps_act / (2 sqrt(v))), gz the upstream gradient itself: h = gz * hfac on load
   uint32_t k0, k1, layer_id, sample_offset;
   const uint32_t* sample_counter;
   float inv_var_p;
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(256, 3) void lr_bwd_weights_kernel(const LrBwdK p) 
           gv[u].y = mine ? gv[u].y : 0.f;
           hv[u].x = mine ? hv[u].x : 0.f;
           hv[u].y = mine ? hv[u].y : 0.f;
+          if (p.h_factor) {
+            hv[u].x *= gv[u].x;
+            hv[u].y *= gv[u].y;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);                // the loads stay one batch ahead of the MFMAs
 #pragma unroll
@@ -368,6 +373,10 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
     f.m1 = load_quad<VEC>(p.w_mu + (size_t)kc1 * N, n, N);
     f.s0 = load_quad<VEC>(p.w_rho + (size_t)kc0 * N, n, N);
     f.s1 = load_quad<VEC>(p.w_rho + (size_t)kc1 * N, n, N);
+    if (p.h_factor) {
+      f.ha0.x *= f.ga0.x; f.ha0.y *= f.ga0.y; f.ha0.z *= f.ga0.z; f.ha0.w *= f.ga0.w;
+      f.ha1.x *= f.ga1.x; f.ha1.y *= f.ga1.y; f.ha1.z *= f.ga1.z; f.ha1.w *= f.ga1.w;
+    }
   };
   auto sq_softplus = [](float r) { const float sg = softplus(r); return sg * sg; };
   auto mfma_slice = [&](Frag& f) {
@@ -420,9 +429,16 @@ __global__ __launch_bounds__(512) void lr_bwd_input_kernel(const LrBwdK p) {
       f.m0 = load8(p.w_mu + (size_t)kc0 * N, n); f.m1 = load8(p.w_mu + (size_t)kc1 * N, n);
       f.r0 = load8(p.w_rho + (size_t)kc0 * N, n); f.r1 = load8(p.w_rho + (size_t)kc1 * N, n);
     };
+    auto times = [](const Frag8& a, const Frag8& b) {
+      Frag8 r;
+      r.lo = make_float4(a.lo.x * b.lo.x, a.lo.y * b.lo.y, a.lo.z * b.lo.z, a.lo.w * b.lo.w);
+      r.hi = make_float4(a.hi.x * b.hi.x, a.hi.y * b.hi.y, a.hi.z * b.hi.z, a.hi.w * b.hi.w);
+      return r;
+    };
     auto mfma_step = [&](int st, const Step& f) {
       const bool ok = st * 32 + 8 * q < N;                // N % 8 == 0: an 8-group is whole or absent (also a step past the end)
-      const bf16x8 ga0 = to_bf16(f.g0, ok), ga1 = to_bf16(f.g1, ok), ha0 = to_bf16(f.h0, ok), ha1 = to_bf16(f.h1, ok);
+      const bf16x8 ga0 = to_bf16(f.g0, ok), ga1 = to_bf16(f.g1, ok);
+      const bf16x8 ha0 = to_bf16(p.h_factor ? times(f.h0, f.g0) : f.h0, ok), ha1 = to_bf16(p.h_factor ? times(f.h1, f.g1) : f.h1, ok);
       const bf16x8 mb0 = to_bf16(f.m0, ok), mb1 = to_bf16(f.m1, ok), sb0 = to_var_bf16(f.r0, ok), sb1 = to_var_bf16(f.r1, ok);
       P[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, mb0, P[0][0], 0, 0, 0);
       P[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, mb1, P[0][1], 0, 0, 0);
@@ -737,7 +753,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   if (a->struct_bytes != sizeof(bnn_lr_bwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
   if (a->n_samples > 65535) return BNN_ERR_SHAPE;
-  if (!a->x || !a->gy || !a->v || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->g_w_mu || !a->g_w_rho ||
+  if (!a->x || !a->gy || (!a->v && !a->hfac) || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->g_w_mu || !a->g_w_rho ||
       !a->g_b_mu || !a->g_b_rho)
     return BNN_ERR_NULL;
   if ((unsigned)a->eps_mode > 2u || (unsigned)a->math > 1u) return BNN_ERR_ENUM;
@@ -745,13 +761,17 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   if (a->relu && !a->y) return BNN_ERR_NULL;
   if (!(a->sigma_p > 0.f)) return BNN_ERR_SHAPE;
   const int S = a->n_samples, B = a->batch, K = a->in_features, N = a->out_features;
-  if (!a->workspace || a->workspace_bytes < bnn_lr_linear_bwd_workspace_bytes(S, B, K, N, a->g_x ? 1 : 0))
-    return BNN_ERR_WORKSPACE;
-  if (reinterpret_cast<uintptr_t>(a->workspace) & 15) return BNN_ERR_ALIGN;
+  const bool factor = a->hfac && !a->relu;               // no preparation launch, no workspace
+  if (a->hfac && a->relu && !a->v) return BNN_ERR_NULL;  // a fused ReLU needs the mask pass, and that pass v
+  if (!factor) {
+    if (!a->workspace || a->workspace_bytes < bnn_lr_linear_bwd_workspace_bytes(S, B, K, N, a->g_x ? 1 : 0))
+      return BNN_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(a->workspace) & 15) return BNN_ERR_ALIGN;
+  }
   const uintptr_t al = reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->w_mu) |
                        reinterpret_cast<uintptr_t>(a->w_rho) | reinterpret_cast<uintptr_t>(a->g_w_mu) |
                        reinterpret_cast<uintptr_t>(a->g_w_rho) | reinterpret_cast<uintptr_t>(a->gy) |
-                       reinterpret_cast<uintptr_t>(a->v) | reinterpret_cast<uintptr_t>(a->y) |
+                       reinterpret_cast<uintptr_t>(a->v) | reinterpret_cast<uintptr_t>(a->y) | reinterpret_cast<uintptr_t>(a->hfac) |
                        reinterpret_cast<uintptr_t>(a->eps_act);
   if (al & 15) return BNN_ERR_ALIGN;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -761,7 +781,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   float* h = reinterpret_cast<float*>(base + act);
 
   const uint32_t k0 = (uint32_t)a->seed, k1 = (uint32_t)(a->seed >> 32);
-  if (N <= 16 && B <= 128 && a->g_x && a->eps_mode == BNN_EPS_PHILOX) {
+  if (N <= 16 && B <= 128 && a->g_x && a->eps_mode == BNN_EPS_PHILOX && a->v) {
     // narrow output layer: prep, both weight gradients and the input gradient in one launch
     LrBwdK kk;
     kk.x = a->x;
@@ -774,6 +794,7 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
     kk.eps_mode = a->eps_mode; kk.k0 = k0; kk.k1 = k1; kk.layer_id = a->layer_id; kk.sample_offset = a->sample_offset;
     kk.sample_counter = a->sample_counter;
     kk.gx_mask = a->gx_relu_mask ? 1 : 0;
+    kk.h_factor = 0;
     kk.inv_var_p = (float)(1.0 / ((double)a->sigma_p * a->sigma_p));
     LrOutBwd o;
     o.gy = a->gy; o.y = a->relu ? a->y : nullptr; o.v = a->v;
@@ -792,15 +813,21 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
   const long groups = (long)S * B * ((N + 3) / 4);
   long nb = (groups + 255) / 256;
   nb = nb > 4096 ? 4096 : nb;
-  hipLaunchKernelGGL(lr_bwd_prep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a->gy, a->y, a->v, a->eps_act, gz, h, S, B,
-                     N, a->relu ? 1 : 0, a->eps_mode, k0, k1, a->layer_id, a->sample_offset, a->sample_counter);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
+  hipError_t err = hipSuccess;
+  if (!factor) {
+    if (!a->v) return BNN_ERR_NULL;
+    hipLaunchKernelGGL(lr_bwd_prep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a->gy, a->y, a->v, a->eps_act, gz, h, S, B,
+                       N, a->relu ? 1 : 0, a->eps_mode, k0, k1, a->layer_id, a->sample_offset, a->sample_counter);
+    err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+  }
 
   LrBwdK k;
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)B * K : 0;
-  k.gz = gz; k.h = h;
+  k.gz = factor ? a->gy : gz;
+  k.h = factor ? a->hfac : h;
+  k.h_factor = factor ? 1 : 0;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_b = a->eps_b; k.gkl = a->g_kl;
   k.g_wmu = a->g_w_mu; k.g_wrho = a->g_w_rho; k.g_bmu = a->g_b_mu; k.g_brho = a->g_b_rho; k.g_x = a->g_x;

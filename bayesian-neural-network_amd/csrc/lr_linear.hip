@@ -47,6 +47,7 @@ struct LrK {
 #endif
   void* y_sq;       // optional bf16 y*y
   __bf16* y16;      // optional bf16 copy of an fp32 y (K3a)
+  float* hfac;      // optional eps_act / (2 sqrt(v)) (K3a): what the backward multiplies gz with
   float* v_out;     // optional fp32 variance
   float4* ws;       // float4 ws[1 + T]: header {T}, then {sum log sigma, sum sigma^2, sum mu^2, 0} per tile
   int S, B, K, N;
@@ -391,6 +392,14 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (nb + i < N) p.v_out[yoff + i] = vv[ii][i];
+    }
+    if (p.hfac) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) {
+          const float sd = __builtin_sqrtf(vv[ii][i]);
+          p.hfac[yoff + i] = sd > 0.f ? e4[i] / (2.f * sd) : 0.f;
+        }
     }
     if (p.y16) {
       __bf16* cp = p.y16 + yoff;
@@ -1317,6 +1326,8 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   k.y = a->y;
   k.x_sq = a->x_sq; k.y_sq = a->y_sq; k.v_out = a->v_out;
   k.y16 = reinterpret_cast<__bf16*>(a->y_bf16_copy);
+  k.hfac = a->hfac_out;
+  if (a->hfac_out && a->form == BNN_FORM_GEMM) return BNN_ERR_ENUM;
   if (a->y_bf16_copy && (a->y_dtype != BNN_F32 || a->form == BNN_FORM_GEMM)) return BNN_ERR_ENUM;
   k.w_frag = reinterpret_cast<const float4*>(a->w_frag);
   k.ws = a->want_kl ? reinterpret_cast<float4*>(a->workspace) : nullptr;
@@ -1345,7 +1356,7 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
   const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
   // K3b needs bf16 x AND x^2 streams; the saved variance (v_out) is a K3a epilogue
-  const bool can = !a->v_out && !a->y_bf16_copy && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+  const bool can = !a->v_out && !a->y_bf16_copy && !a->hfac_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
   // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
   if (can && (a->form == BNN_FORM_GEMM || (a->form == BNN_FORM_AUTO && gemm_blocks >= 300))) {
@@ -1504,7 +1515,7 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features, nl = f->n_layers;
   const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 16 &&
                     (K % 8) == 0 && K <= 2048 && !(reinterpret_cast<uintptr_t>(a->x) & 15) && a->eps_mode == BNN_EPS_PHILOX &&
-                    !a->eps_act_dump && !a->eps_b_dump && !a->y_sq && !a->y_bf16_copy && !a->kl_out && a->form == BNN_FORM_AUTO &&
+                    !a->eps_act_dump && !a->eps_b_dump && !a->y_sq && !a->y_bf16_copy && !a->hfac_out && !a->kl_out && a->form == BNN_FORM_AUTO &&
                     f->local_reparam && nl >= 1 && nl <= 8 && f->n_samples == S && f->classes == N && f->batch == B &&
                     f->logits == a->y && f->nll && f->kl && f->layer_in[nl - 1] == K && f->layer_out[nl - 1] == N &&
                     f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&

@@ -308,6 +308,10 @@ typedef struct bnn_lr_fwd_args {
   float* v_out;             /* optional fp32 [n_samples,batch,out]: the pre-activation variance v
                                (networks.py:121) as the kernel computed it; bnn_lr_linear_bwd needs
                                it.  Selects the latency form of the kernel. */
+  float* hfac_out;          /* optional fp32 [n_samples,batch,out]: eps_act / (2 sqrt(v)) (0 where v == 0), the factor
+                               the backward multiplies the upstream gradient with (h = gz * hfac, see bnn_lr_bwd_args):
+                               a hidden layer of a training step saves THIS instead of v and its backward needs no
+                               preparation launch.  Selects the latency form of the kernel. */
   void* y_bf16_copy;        /* optional bf16 [n_samples,batch,out], with y_dtype == BNN_F32: y also in bf16.  A training
                                step keeps fp32 activations for the backward and feeds the next layer's forward
                                the bf16 ones (half the bytes through the CU, no conversion in its k loop).
@@ -536,6 +540,9 @@ typedef struct bnn_lr_bwd_args {
   void* workspace;
   size_t workspace_bytes;
   const uint32_t* sample_counter; /* optional device word, as in bnn_bbb_bwd_args */
+  const float* hfac;              /* optional, instead of v (which may then be NULL), with relu == 0: the forward's
+                                     hfac_out.  gz = gy and h = gy * hfac are formed as the kernels load them: no
+                                     preparation launch, eps_act is not regenerated, the workspace is not used */
 } bnn_lr_bwd_args;
 
 size_t bnn_lr_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t in_features,

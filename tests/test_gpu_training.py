@@ -201,6 +201,33 @@ def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
         assert float(masked[4].abs().max()) > 0
 
 
+def test_lr_backward_from_the_saved_factor_equals_the_prepared_form():
+    """bnn_lr_fwd_args.hfac_out / bnn_lr_bwd_args.hfac: a hidden layer of a training step saves eps_act / (2 sqrt(v)) in
+    its forward and its backward forms h = gz * hfac as it loads the operands -- no preparation launch; the reference is
+    the same backward from the saved v (eps regenerated by the preparation launch)."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(14)
+    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 40), (1, 7, 33, 24), (2, 9, 31, 21)):
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1))
+        p = (mk(K, N), mk(K, N, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2))
+        fw = ops.lr_linear_fwd(x, *p, n_samples=S, sigma_p=1.0, math_mode=L.MATH_F32, relu=True, y_dtype=torch.float32,
+                               eps_mode=L.EPS_PHILOX, seed=3, layer_id=1, sample_offset=5, want_kl=True, want_v=True, want_hfac=True)
+        eps = ops.philox_normal(3, 4 * 1 + 2, 5, S, B, N, dev)
+        want = eps / (2 * torch.sqrt(fw["v"]))
+        assert float((fw["hfac"] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        gy = mk(S, B, N, lo=-1, hi=1)
+        kw = dict(n_samples=S, relu=False, eps_mode=L.EPS_PHILOX, seed=3, layer_id=1, sample_offset=5, sigma_p=1.0, gx_relu_mask=True,
+                  g_kl=mk(3, lo=0.1, hi=0.5))
+        for mm in (L.MATH_F32, L.MATH_BF16):
+            ref = ops.lr_linear_bwd(x, gy, None, fw["v"], *p, math_mode=mm, **kw)
+            got = ops.lr_linear_bwd(x, gy, None, None, *p, math_mode=mm, hfac=fw["hfac"], **kw)
+            for i, (a, b) in enumerate(zip(got, ref)):
+                tol = 2e-3 if (mm == L.MATH_BF16 and i == 4 and N % 8 == 0) else 2e-5     # (a bf16 ulp of h here and there)
+                assert float((a - b).double().norm()) <= tol * float(b.double().norm()), (S, B, K, N, mm, i)
+
+
 def test_lr_input_gradient_in_bf16_math():
     """bnn_lr_bwd_args.math = BNN_MATH_BF16: g_x = gz M^T + 2 x (h (sigma^2)^T) with the four operands rounded to bf16
     (fp32 accumulation) -- checked against that arithmetic in torch and against the exact-fp32 form; the weight
