@@ -191,7 +191,7 @@ class GraphedTrainStep:
                                                   w_sampled=self.wsamp[i], b_sampled=self.bsamp[i]),
                                              dict(workspaces=wss + [self.wstat[i]], scratch=self.fin_scratch,
                                                   loss=dict(beta=self.beta, total_samples=S, grad_scale=1.0 / self.world), **fin_kw))
-                saved.append((h, res["y"], None, p))
+                saved.append((h, res["y"], None, p, None))
                 h = res["y"]
                 continue
             if not lr and i == len(specs) - 1:
@@ -201,14 +201,14 @@ class GraphedTrainStep:
                                                             seed=state.seed, layer_id=sp.layer_id, sample_offset=first,
                                                             sample_counter=self.counter, want_stats=True),
                                              dict(workspaces=wss, scratch=self.fin_scratch, **fin_kw))
-                saved.append((h, res["y"], None, p))
+                saved.append((h, res["y"], None, p, None))
                 h = res["y"]
                 continue
             if self.presample:
                 y = ops.bbb_sampled_matmul(h16 if h16 is not None else h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu,
                                            y_dtype=torch.float32, want_y16=self.x16 is not None)
                 y, y16 = y if self.x16 is not None else (y, None)
-                saved.append((h, y, None, p))
+                saved.append((h, y, None, p, None))
                 wss.append(self.wstat[i])
                 h, h16 = y, y16
                 continue
@@ -223,7 +223,7 @@ class GraphedTrainStep:
                                                              workspace=ws_last, **common),
                                             dict(workspaces=wss + [ws_last], scratch=self.fin_scratch,
                                                  loss=dict(beta=self.beta, total_samples=S, grad_scale=1.0 / self.world), **fin_kw))
-                saved.append((h, out["y"], out.get("v"), p))
+                saved.append((h, out["y"], out.get("v"), p, None))
                 h = out["y"]
                 continue
             if sp.lr:
@@ -265,8 +265,7 @@ class GraphedTrainStep:
         """Backward of layer i (weight gradients into the bucket; input gradient for the layer below)."""
         specs, saved, g_a, g_b, g_kl3, first, lr, top = self._bwd_state
         S, g, sp = self.samples, self._bwd_g, specs[i]
-        xin, y, v, p = saved[i][:4]
-        hfac = saved[i][4] if len(saved[i]) > 4 else None
+        xin, y, v, p, hfac = saved[i]       # (layer input, output, LR: saved variance | saved eps / (2 sqrt(v)))
         # layer i's ReLU mask is applied by layer i+1's input-gradient kernel (its x IS layer i's output),
         # so only a top layer with a ReLU masks its own gy
         own_relu = sp.relu and i == top
