@@ -78,6 +78,22 @@ def test_argument_validation_without_a_device():
     assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -5
     lb.struct_bytes = C.sizeof(L.LrBwdArgs)
     assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -2
+    # the training step's optional arguments are validated on the host too (fake non-NULL device addresses: nothing
+    # is dereferenced before the checks)
+    fake = 0x1000
+    lb.n_samples, lb.batch, lb.in_features, lb.out_features = 2, 4, 8, 24
+    for fld in ("x", "gy", "w_mu", "w_rho", "b_mu", "b_rho", "g_w_mu", "g_w_rho", "g_b_mu", "g_b_rho"):
+        setattr(lb, fld, fake)
+    assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -1          # neither the forward's v nor its hfac
+    lb.hfac, lb.relu, lb.y, lb.sigma_p = fake, 1, fake, 1.0
+    assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == -1          # a fused ReLU needs the mask pass, and that pass v
+    lb.relu, lb.math = 0, 7
+    assert lib.bnn_lr_linear_bwd(C.byref(lb), None) == L.load().bnn_lr_linear_bwd(C.byref(lb), None) < 0   # bad enum
+    lf = L.LrFwdArgs()
+    lf.struct_bytes = C.sizeof(L.LrFwdArgs)
+    assert lib.bnn_lr_linear_fwd(C.byref(lf), None) == -2
+    assert lib.bnn_stage_inputs_cast(fake, fake, 64, None, None, 0, None, 0.0, fake + 2, None) < 0      # misaligned bf16 copy
+    assert lib.bnn_stage_inputs_cast(fake, fake, 60, None, None, 0, None, 0.0, fake, None) < 0         # the cast needs 16-byte sizes
     ad = L.AdamArgs()
     assert lib.bnn_adam_step(C.byref(ad), None) == -5
     ad.struct_bytes = C.sizeof(L.AdamArgs)
