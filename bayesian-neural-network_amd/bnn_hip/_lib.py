@@ -53,6 +53,7 @@ class BbbFwdArgs(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("form", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
         ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p), ("rider", C.c_void_p), ("y_bf16_copy", C.c_void_p),
+        ("w_sampled_t_out", C.c_void_p),
     ]
 
 
@@ -113,6 +114,7 @@ class BbbBwdArgs(C.Structure):
         ("g_x", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("sample_counter", C.c_void_p), ("w_sampled", C.c_void_p),
+        ("w_sampled_t", C.c_void_p), ("gy_bf16", C.c_void_p), ("g_x_bf16", C.c_void_p),
     ]
 
 

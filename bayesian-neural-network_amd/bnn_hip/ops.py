@@ -139,7 +139,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
                out=None, split_scratch=None, w_sigma=None, form: int = 0, sample_group: int = 0,
-               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None, want_y16: bool = False):
+               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None, want_y16: bool = False, wt_out=None):
     """Argument block of K1 + the tensors it points at (kept alive by the caller).  `w_sampled` / `b_sampled` (bf16
     [S,out,in] / fp32 [S,out] from bbb_sample_weights): the matmul-only form, the parameter tensors may then be None.
     `rider` = the (args, results, keep) of build_sample_job: an independent sampling job carried by the launch."""
@@ -163,6 +163,11 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
         a.want_stats, a.relu = 0, int(relu)
         a.y, a.y_dtype = y.data_ptr(), _dt(y)
         a.w_sampled, a.b_sampled = w_sampled.data_ptr(), b_sampled.data_ptr()
+        if wt_out is not None:                       # the same weights once more, transposed (for the layer's input gradient)
+            require_device(wt_out)
+            if wt_out.dtype != torch.bfloat16 or not wt_out.is_contiguous() or tuple(wt_out.shape) != (n_samples, K, N):
+                raise BnnHipError("wt_out must be a contiguous bf16 [samples,in,out] tensor")
+            a.w_sampled_t_out = wt_out.data_ptr()
         a.form = int(form)
         y16 = _y16(a, y) if want_y16 else None
         return a, dict(y=y, y16=y16, workspace=None, log_prior=None, log_q=None, eps_w=None, eps_b=None), (xs, w_sampled, b_sampled, y)
@@ -303,12 +308,12 @@ def bbb_sample_weights(layers, **kw):
     return res
 
 
-def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, want_y16: bool = False):
+def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, want_y16: bool = False, wt_out=None):
     """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s]).  `want_y16`:
-    returns (y fp32, y in bf16)."""
+    returns (y fp32, y in bf16).  `wt_out` (bf16 [S,in,out]): the launch also leaves w transposed there."""
     a, res, keep = _bbb_build(x, None, None, None, None, n_samples=n_samples, prior=PriorSpec(), math_mode=L.MATH_BF16, relu=relu,
                               y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=out, w_sampled=w, b_sampled=b,
-                              want_y16=want_y16)
+                              want_y16=want_y16, wt_out=wt_out)
     L.check(L.load().bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
     return (res["y"], res["y16"]) if want_y16 else res["y"]
 
@@ -642,9 +647,11 @@ def _grad_outputs(out, w_mu, w_rho, b_mu, b_rho):
 def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec, math_mode: int, relu: bool,
                    eps_mode: int, eps_w=None, eps_b=None, seed: int = 0, layer_id: int = 0, sample_offset: int = 0,
                    g_log_prior=None, g_log_q=None, want_gx: bool = True, sample_counter=None, out=None,
-                   gx_relu_mask: bool = False, w_sampled=None):
+                   gx_relu_mask: bool = False, w_sampled=None, w_sampled_t=None, gy16=None, want_gx16: bool = False):
     """F1: backward of K1 (bnn_bbb_linear_bwd).  All tensors fp32.  Returns
-    (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None)."""
+    (g_w_mu, g_w_rho, g_b_mu, g_b_rho, g_x[S,B,K] | None), with `want_gx16` also g_x in bf16 as a sixth element.
+    `w_sampled_t` (bf16 [S,in,out], the forward's wt_out) / `gy16` (bf16 copy of gy): the input gradient as the
+    forward's matmul-only launch."""
     lib = L.load()
     require_device(x, gy, y, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, g_log_prior, g_log_q)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -683,10 +690,25 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
         if w_sampled.dtype != torch.bfloat16 or not w_sampled.is_contiguous() or w_sampled.numel() != n_samples * N * K:
             raise BnnHipError("bbb_linear_bwd: w_sampled must be contiguous bf16 [samples,out,in]")
         a.w_sampled = w_sampled.data_ptr()
+    if w_sampled_t is not None and want_gx:
+        require_device(w_sampled_t, gy16)
+        if w_sampled_t.dtype != torch.bfloat16 or not w_sampled_t.is_contiguous() or tuple(w_sampled_t.shape) != (n_samples, K, N):
+            raise BnnHipError("bbb_linear_bwd: w_sampled_t must be contiguous bf16 [samples,in,out]")
+        a.w_sampled_t = w_sampled_t.data_ptr()
+        if gy16 is not None:
+            if gy16.dtype != torch.bfloat16 or not gy16.is_contiguous() or gy16.numel() != gy.numel():
+                raise BnnHipError("bbb_linear_bwd: gy16 must be a contiguous bf16 copy of gy")
+            a.gy_bf16 = gy16.data_ptr()
+    gx16 = None
+    if want_gx16 and want_gx:
+        gx16 = torch.empty((n_samples, B, K), dtype=torch.bfloat16, device=dev)
+        a.g_x_bf16 = gx16.data_ptr()
     ws = torch.empty(lib.bnn_bbb_linear_bwd_workspace_bytes(n_samples, B, N) // 4, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     a.sample_counter = _ptr(sample_counter)
     L.check(lib.bnn_bbb_linear_bwd(C.byref(a), _stream()), "bnn_bbb_linear_bwd")
+    if want_gx16:
+        return g_wmu, g_wrho, g_bmu, g_brho, gx, gx16
     return g_wmu, g_wrho, g_bmu, g_brho, gx
 
 

@@ -33,6 +33,7 @@ from .runtime import state, take_samples
 # The weight-gradient kernels still regenerate eps.  BNN_HIP_TRAIN_PRESAMPLE=0: sampling fused into every launch.
 TRAIN_PRESAMPLE = os.environ.get("BNN_HIP_TRAIN_PRESAMPLE", "1") != "0"
 TRAIN_BF16_FORWARD_INPUTS = True
+TRAIN_TRANSPOSED_INPUT_GRAD = True
 
 
 class GraphedTrainStep:
@@ -93,6 +94,11 @@ class GraphedTrainStep:
             self.wsamp = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) for sp in specs]
             self.bsamp = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) for sp in specs]
             self.wstat = [ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev) for sp in specs]
+            # hidden layers above the first: their forward launch also leaves the sampled weights transposed, and their
+            # input gradient runs as that same matmul-only launch over them (no 2-byte gathers along the reduction)
+            self.wsamp_t = [torch.empty((S, sp.in_out[0], sp.in_out[1]), dtype=torch.bfloat16, device=dev)
+                            if (TRAIN_TRANSPOSED_INPUT_GRAD and 0 < i < len(specs) - 1 and sp.in_out[1] % 8 == 0) else None
+                            for i, sp in enumerate(specs)]
         self.first = take_samples(0)
         # the step's MC-sample counter advances inside Adam's launch (after the backward re-read it)
         optimizer.bump_after_step(self.counter, self.samples * self.world)
@@ -170,6 +176,7 @@ class GraphedTrainStep:
         h16 = net._flat(self.x16) if self.x16 is not None else None     # what the forward launches read, when present
         first = take_samples(S * self.world) + self.rank * S
         saved, wss = [], []
+        self._wt_ready = {}                        # layers whose forward launch of this step left transposed weights
         if self.presample:
             ops.bbb_sample_weights(
                 [dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
@@ -206,7 +213,9 @@ class GraphedTrainStep:
                 continue
             if self.presample:
                 y = ops.bbb_sampled_matmul(h16 if h16 is not None else h, self.wsamp[i], self.bsamp[i], n_samples=S, relu=sp.relu,
-                                           y_dtype=torch.float32, want_y16=self.x16 is not None)
+                                           y_dtype=torch.float32, want_y16=self.x16 is not None,
+                                           wt_out=self.wsamp_t[i] if h16 is not None else None)
+                self._wt_ready[i] = h16 is not None and self.wsamp_t[i] is not None
                 y, y16 = y if self.x16 is not None else (y, None)
                 saved.append((h, y, None, p, None))
                 wss.append(self.wstat[i])
@@ -250,6 +259,7 @@ class GraphedTrainStep:
         top = len(specs) - 1
         self._bwd_state = (specs, saved, g_a, g_b, g_kl3, first, lr, top)
         self._bwd_g = g
+        self._bwd_g16 = None
         for i in reversed(range(1 if stop_above_layer0 else 0, len(specs))):
             self._backward_layer(i)
         if lr:
@@ -276,9 +286,13 @@ class GraphedTrainStep:
             grads = ops.lr_linear_bwd(xin, g, y if own_relu else None, v, *p, sigma_p=sp.m._prior_spec.sigma_p, g_kl=g_kl3,
                                       math_mode=state.math, hfac=None if own_relu else hfac, **kw)
         else:
+            wt = self.wsamp_t[i] if (self.presample and i > 0 and self._wt_ready.get(i)) else None
+            below_t = bool(self.presample and i > 1 and self._wt_ready.get(i - 1))     # the layer below reads g_x in bf16
             grads = ops.bbb_linear_bwd(xin, g, y if own_relu else None, *p, prior=sp.m._prior_spec, math_mode=state.math,
                                        g_log_prior=g_a, g_log_q=g_b,
-                                       w_sampled=self.wsamp[i] if (self.presample and i > 0) else None, **kw)
+                                       w_sampled=self.wsamp[i] if (self.presample and i > 0) else None,
+                                       w_sampled_t=wt, gy16=self._bwd_g16 if wt is not None else None, want_gx16=below_t, **kw)
+            self._bwd_g16 = grads[5] if below_t else None
         sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
         self._bwd_g = grads[4]
 

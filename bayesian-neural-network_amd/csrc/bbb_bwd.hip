@@ -469,6 +469,7 @@ __device__ __forceinline__ void out_bwd_weight_role(const BwdK& p, float* gzs, f
 struct OutBwd {
   const __bf16* w;      // [S, N, K] the forward's sampled weights
   float* gx;            // [S, B, K]
+  __bf16* gx16;         // optional bf16 copy of gx (the layer below's input-gradient launch reads it)
   int relu_mask;        // gx *= (x > 0)
   int wblocks;
 };
@@ -514,6 +515,12 @@ __global__ __launch_bounds__(256) void bbb_out_layer_bwd_kernel(const BwdK p, co
     float* out = o.gx + (size_t)row * K + kch * 8;
     *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *reinterpret_cast<float4*>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    if (o.gx16) {
+      bf16x8 ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ob[j] = (__bf16)acc[j];
+      *reinterpret_cast<bf16x8*>(o.gx16 + (size_t)row * K + kch * 8) = ob;
+    }
     return;
   }
   // ---- weight (and bias) gradients of 16 k columns
@@ -602,6 +609,7 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
     if (!(a->prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
     k.inv_var_p = (float)(1.0 / ((double)a->prior.sigma_p * a->prior.sigma_p));
   }
+  if (a->g_x_bf16 && (!a->g_x || (reinterpret_cast<uintptr_t>(a->g_x_bf16) & 15))) return BNN_ERR_ALIGN;
   if (a->w_sampled && a->g_x && a->out_features <= 16 && a->batch <= 256 && (a->in_features & 7) == 0 &&
       a->eps_mode == BNN_EPS_PHILOX && a->math == BNN_MATH_BF16 &&
       !((reinterpret_cast<uintptr_t>(a->w_sampled) | reinterpret_cast<uintptr_t>(a->g_x)) & 15)) {
@@ -609,6 +617,7 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
     OutBwd o;
     o.w = reinterpret_cast<const __bf16*>(a->w_sampled);
     o.gx = a->g_x;
+    o.gx16 = reinterpret_cast<__bf16*>(a->g_x_bf16);
     o.relu_mask = a->gx_relu_mask ? 1 : 0;
     o.wblocks = (a->in_features + 15) / 16;
     const long xthreads = (long)a->n_samples * a->batch * (a->in_features / 8);
@@ -634,6 +643,10 @@ extern "C" int bnn_bbb_linear_bwd(const bnn_bbb_bwd_args* a, void* stream_) {
   }
   err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  if (a->g_x) return bnn_bbb_input_grad_(a, gz, stream_);
+  if (a->g_x) {
+    const int rc = bnn_bbb_input_grad_(a, gz, stream_);
+    if (rc != BNN_OK || !a->g_x_bf16 || a->w_sampled_t) return rc;     // (the matmul form over w_sampled_t writes the copy itself)
+    return bnn_cast_bf16(a->g_x, a->g_x_bf16, nullptr, (int64_t)a->n_samples * a->batch * a->in_features, stream_);
+  }
   return BNN_OK;
 }

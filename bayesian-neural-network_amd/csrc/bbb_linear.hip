@@ -64,7 +64,8 @@ struct BbbK {
   Xcd2D xc;             // GEMM form: work order (feature group x (sample, batch block) x K slice), see bnn_device.h
   int ldw;          // TRANS only: leading dimension of the [out,in] weight matrix (= original in_features)
   const __bf16* w_pre;  // PRE only: sampled weights bf16 [S, N, K] (bnn_bbb_sample_weights); no sampling in the launch
-  const float* b_pre;   // PRE only: sampled biases [S, N]
+  const float* b_pre;   // PRE only: sampled biases [S, N] (nullptr: none -- the input-gradient use of the matmul)
+  __bf16* wt_out;       // PRE only, optional: the sampled weights written once more TRANSPOSED, [S, K, N] (bnn_bbb_fwd_args.w_sampled_t_out)
   const float* mask;  // TRANS only, optional: [S|1, B, N] the layer's input; the stored gx is multiplied by (mask > 0)
   long mask_sstride;
   uint32_t k0, k1, layer_id, sample_offset;
@@ -304,7 +305,7 @@ struct FinPack {
 // MT: 16-row batch tiles per block (8 = 128 rows).  The matmul-only forms use 2: without generator work a block's
 // cost is the x it pulls through its CU's L1 (all of K for its rows), so four times the blocks each ingest a quarter;
 // with sampling fused every batch block would redo the tile's sampling, hence 8 there.
-template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8>
+template <int MATH, int XDT, int R, bool ALIGNED, bool FINAL, bool TRANS = false, bool PRE = false, int MT = 8, bool WT = false>
 __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   constexpr int F = 16 / R;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -385,7 +386,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   // bias parameters of the tile (used after the k-loop): fetched now, off the critical path
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
   if (PRE) {
-    if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) bmu_pre = p.b_pre[(size_t)s * N + n];
+    if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0 && p.b_pre) bmu_pre = p.b_pre[(size_t)s * N + n];
   } else if (!TRANS && wave == nw - 1 && lane < F && n_ok && ks == 0) {   // the last wave owns the fewest k-steps
     bmu_pre = p.b_mu[n];
     brho_pre = p.b_rho[n];
@@ -520,6 +521,16 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
         wz[j] = (__bf16)0.f;
       }
       if (PRE && (TRANS || valid > 0)) wa = __builtin_bit_cast(bf16x8, wraw);   // padding (k >= K, n >= N) is zero
+      if (WT && valid > 0 && n_ok) {
+        // the row blocks of a (tile, sample) leave the tile's weights transposed between them (block mb takes the k rows
+        // j = mb mod mbs of every lane's eight): 2-byte stores, 32 contiguous bytes per k row and 16-lane group -- the
+        // input gradient of a training step then runs as THIS matmul over [S, K, N] instead of gathering 2-byte elements
+        // along the reduction (all eight rows on the first row block made it the launch's long pole: +3.6 us)
+        __bf16* dst = p.wt_out + ((size_t)s * K + k) * N + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j % mbs == mb) dst[(size_t)j * N] = wa[j];
+      }
     }
 #pragma unroll
     for (int ch = 0; ch < MT / MC; ++ch) {
@@ -893,9 +904,9 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
 }
 
 // matmul half over pre-sampled bf16 weights (bnn_bbb_sample_weights): no generator work in the launch
-template <int XDT, int R, int MT>
+template <int XDT, int R, int MT, bool WT = false>
 __global__ __launch_bounds__(768) void bbb_fwd_pre_kernel(const BbbK p) {
-  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false, false, true, MT>(p, nullptr);
+  bbb_fwd_body<BNN_MATH_BF16, XDT, R, true, false, false, true, MT, WT>(p, nullptr);
 }
 
 // input gradient over the bf16 weights the forward sampled (no generator work: the transposed generator draws a
@@ -1395,7 +1406,8 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
 // applies (K % 8 == 0, aligned bases).
 static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   k.mask = nullptr; k.mask_sstride = 0;      // input-gradient form only
-  k.w_pre = nullptr; k.b_pre = nullptr;      // set below for the matmul-only form
+  k.w_pre = nullptr; k.b_pre = nullptr; k.wt_out = nullptr;     // set below for the matmul-only form
+  if (a && a->w_sampled_t_out && !a->w_sampled) return BNN_ERR_NULL;
   if (!a) return BNN_ERR_NULL;
   if (a->struct_bytes != sizeof(bnn_bbb_fwd_args)) return BNN_ERR_ABI;
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
@@ -1461,6 +1473,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
   if (pre) {
     k.w_pre = reinterpret_cast<const __bf16*>(a->w_sampled);
     k.b_pre = a->b_sampled;
+    k.wt_out = reinterpret_cast<__bf16*>(a->w_sampled_t_out);
     k.eps_mode = BNN_EPS_ZERO;
     al = true;
   } else if (a->eps_mode == BNN_EPS_MEMORY) al = al && aligned16(a->eps_w);
@@ -1490,11 +1503,18 @@ extern "C" int bnn_bbb_plan(const bnn_bbb_fwd_args* a, bnn_plan* out) {
   return BNN_OK;
 }
 
-extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
+// `grad_mask` != nullptr: the launch is the INPUT GRADIENT of a layer as the matmul gz . w over that layer's transposed
+// sampled weights (bnn_bbb_input_grad_): no bias, the output masked by (grad_mask > 0)
+static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no_bias, const float* grad_mask, long mask_sstride) {
   BbbK k;
   bool al = false;
   int rc = prepare(a, k, al);
   if (rc != BNN_OK) return rc;
+  if (no_bias) k.b_pre = nullptr;
+  if (grad_mask) {
+    k.mask = grad_mask;
+    k.mask_sstride = mask_sstride;
+  }
   BbbPlan pl{};
   rc = bbb_plan(a, al, pl);
   if (rc != BNN_OK) return rc;
@@ -1524,7 +1544,11 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (err == hipSuccess)                                                                        \
       hipLaunchKernelGGL((bbb_fwd_pre_kernel<XDT, 1, 2>), grid, block, pl.lds, stream, k);        \
   } while (0)
-    if (xdt == BNN_F32) BNN_PRE(BNN_F32); else BNN_PRE(BNN_BF16);
+    if (k.wt_out) {                                  // the same launch also leaves w transposed
+      err = allow_big_lds(bbb_fwd_pre_kernel<BNN_BF16, 1, 2, true>, pl.lds);
+      if (xdt != BNN_BF16) return BNN_ERR_ENUM;
+      if (err == hipSuccess) hipLaunchKernelGGL((bbb_fwd_pre_kernel<BNN_BF16, 1, 2, true>), grid, block, pl.lds, stream, k);
+    } else if (xdt == BNN_F32) BNN_PRE(BNN_F32); else BNN_PRE(BNN_BF16);
 #undef BNN_PRE
     if (err != hipSuccess) return (int)err;
     err = hipGetLastError();
@@ -1614,6 +1638,10 @@ extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
     if (err != hipSuccess) return (int)err;
   }
   return BNN_OK;
+}
+
+extern "C" int bnn_bbb_linear_fwd(const bnn_bbb_fwd_args* a, void* stream_) {
+  return bbb_linear_fwd_impl(a, stream_, false, nullptr, 0);
 }
 
 static constexpr int kFinalMaxSlices = 8;
@@ -1761,6 +1789,28 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
 // bnn_bbb_linear_bwd (bbb_bwd.hip).
 extern "C" int bnn_bbb_input_grad_(const bnn_bbb_bwd_args* a, const float* gz, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (a->w_sampled_t) {
+    // the forward left the sampled weights transposed ([S, in, out]): the input gradient is the forward's matmul-only
+    // launch with the roles of the dimensions exchanged, gx[s] = gz[s] . wT[s]^T, no bias, masked by (x > 0)
+    if (a->math != BNN_MATH_BF16) return BNN_ERR_ENUM;
+    bnn_bbb_fwd_args fa{};
+    fa.struct_bytes = sizeof(bnn_bbb_fwd_args);
+    fa.n_samples = a->n_samples; fa.batch = a->batch;
+    fa.in_features = a->out_features;             // reduction length
+    fa.out_features = a->in_features;             // produced features
+    const bool g16 = a->gy_bf16 && gz == a->gy;   // (a masked gz lives in the fp32 workspace)
+    fa.x = g16 ? a->gy_bf16 : static_cast<const void*>(gz);
+    fa.x_dtype = g16 ? BNN_BF16 : BNN_F32;
+    fa.x_per_sample = 1;
+    fa.math = BNN_MATH_BF16; fa.eps_mode = BNN_EPS_ZERO;
+    fa.y = a->g_x; fa.y_dtype = BNN_F32;
+    fa.y_bf16_copy = a->g_x_bf16;
+    fa.w_sampled = a->w_sampled_t;
+    fa.b_sampled = a->b_mu;                        // (non-NULL for the argument check; the launch takes no bias)
+    fa.prior = a->prior;
+    return bbb_linear_fwd_impl(&fa, stream_, true, a->gx_relu_mask ? a->x : nullptr,
+                               a->x_per_sample ? (long)a->batch * a->in_features : 0);
+  }
   BbbK k{};
   k.x = gz;
   k.x_sstride = (long)a->batch * a->out_features;

@@ -198,6 +198,9 @@ typedef struct bnn_bbb_fwd_args {
   void* y_bf16_copy;        /* optional bf16 [n_samples,batch,out], with y_dtype == BNN_F32: y also in bf16 (for the next
                                layer's forward of a training step, whose backward reads the fp32 y).  Tile form only:
                                selects it */
+  void* w_sampled_t_out;    /* optional, with w_sampled and bf16 x: bf16 [n_samples,in,out], the same weights TRANSPOSED,
+                               written by this launch.  The layer's backward (bnn_bbb_bwd_args.w_sampled_t) then computes its input
+                               gradient as this same matmul-only launch instead of gathering along the reduction */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
@@ -486,6 +489,10 @@ typedef struct bnn_bbb_bwd_args {
                                  (bnn_bbb_sample_weights).  g_x = gz . w_sampled is then a plain matmul instead of
                                  regenerating w through the transposed generator (bf16 math only); the weight
                                  gradients still regenerate eps */
+  const void* w_sampled_t;    /* optional bf16 [n_samples,in,out] (the forward's w_sampled_t_out), with g_x: the input
+                                 gradient is then the forward's matmul-only launch over it (bf16 math) */
+  const void* gy_bf16;        /* optional bf16 copy of gy (the layer above's g_x_bf16): read by that launch when relu == 0 */
+  void* g_x_bf16;             /* optional bf16 [n_samples,batch,in]: g_x also in bf16, for the layer below's gy_bf16 */
 } bnn_bbb_bwd_args;
 
 size_t bnn_bbb_linear_bwd_workspace_bytes(int32_t n_samples, int32_t batch, int32_t out_features);

@@ -201,6 +201,38 @@ def test_input_gradient_applies_the_relu_mask_of_the_layer_below(variant):
         assert float(masked[4].abs().max()) > 0
 
 
+def test_input_gradient_over_transposed_sampled_weights():
+    """bnn_bbb_fwd_args.w_sampled_t_out / bnn_bbb_bwd_args.w_sampled_t: the forward's matmul-only launch leaves the
+    sampled weights transposed, the backward computes g_x as that same launch over them (bf16 gy copy in, bf16 g_x copy
+    out) -- against the transposed-gather form over w_sampled: same bf16 products, fp32 sums in another order."""
+    from bnn_hip import ops, _lib as L
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(23)
+    for S, B, K, N in ((2, 128, 1200, 1200), (3, 20, 72, 40), (1, 7, 40, 24), (2, 100, 784, 400)):
+        mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        x = torch.relu(mk(S, B, K, lo=-1, hi=1))
+        w_mu, w_rho, b_mu, b_rho = mk(N, K), mk(N, K, lo=-5, hi=-2), mk(N), mk(N, lo=-5, hi=-2)
+        w_s = (w_mu + 0.01 * mk(S, N, K)).to(torch.bfloat16).contiguous()
+        b_s = mk(S, N)
+        wt = torch.zeros((S, K, N), dtype=torch.bfloat16, device=dev)
+        y = ops.bbb_sampled_matmul(x.to(torch.bfloat16), w_s, b_s, n_samples=S, relu=True, y_dtype=torch.float32, wt_out=wt)
+        assert torch.equal(wt, w_s.transpose(1, 2).contiguous()), (S, B, K, N)
+        want = torch.relu(torch.einsum("sbk,snk->sbn", x.to(torch.bfloat16).float(), w_s.float()) + b_s[:, None, :])
+        assert float((y - want).abs().max()) <= 1e-4 * float(want.abs().max())
+        gy = mk(S, B, N, lo=-1, hi=1)
+        kw = dict(n_samples=S, prior=ops.PriorSpec(False, 1.0), math_mode=L.MATH_BF16, relu=False, eps_mode=L.EPS_PHILOX, seed=11,
+                  layer_id=1, sample_offset=40, gx_relu_mask=True)
+        ref = ops.bbb_linear_bwd(x, gy, None, w_mu, w_rho, b_mu, b_rho, w_sampled=w_s, **kw)
+        for gy16 in (None, gy.to(torch.bfloat16)):
+            got = ops.bbb_linear_bwd(x, gy, None, w_mu, w_rho, b_mu, b_rho, w_sampled=w_s, w_sampled_t=wt, gy16=gy16,
+                                     want_gx16=True, **kw)
+            for a, b in zip(got[:4], ref[:4]):
+                assert torch.equal(a, b)
+            assert float((got[4] - ref[4]).double().norm()) <= 1e-5 * float(ref[4].double().norm()), (S, B, K, N)
+            assert torch.equal(got[5], got[4].to(torch.bfloat16))
+            assert torch.equal(got[4] == 0, ref[4] == 0)
+
+
 def test_lr_backward_from_the_saved_factor_equals_the_prepared_form():
     """bnn_lr_fwd_args.hfac_out / bnn_lr_bwd_args.hfac: a hidden layer of a training step saves eps_act / (2 sqrt(v)) in
     its forward and its backward forms h = gz * hfac as it loads the operands -- no preparation launch; the reference is
