@@ -43,6 +43,22 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
   const float* __restrict__ g = k.g[t];
   float* __restrict__ m = k.m[t];
   float* __restrict__ v = k.v[t];
+  // a whole chunk (all but the last block of a tensor): its 16 loads go out before anything else -- the double-precision
+  // bias corrections below are a few hundred instructions per thread, and behind them the first load round trip of every
+  // wave was exposed at the head of the launch
+  constexpr int kIt = kAdamChunk / (256 * 4);
+  const bool whole = base + kAdamChunk <= n;
+  float4 qa[kIt], qb[kIt], qc[kIt], qd[kIt];
+  if (whole) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+      qa[it] = *reinterpret_cast<const float4*>(p + i);
+      qb[it] = *reinterpret_cast<const float4*>(g + i);
+      qc[it] = *reinterpret_cast<const float4*>(m + i);
+      qd[it] = *reinterpret_cast<const float4*>(v + i);
+    }
+  }
   const double lr = k.lr_dev ? (double)*k.lr_dev : k.lr;
   // with a ticket word every block reads the old step and uses step + 1; the block that arrives last (all have
   // read it by then) stores it: the optimiser step is ONE launch, nobody waits
@@ -53,6 +69,25 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
   const float step_size = (float)(lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
   const float omb1 = k.omb1, omb2 = k.omb2;
+  if (whole) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+      float pv[4] = {qa[it].x, qa[it].y, qa[it].z, qa[it].w}, gv[4] = {qb[it].x, qb[it].y, qb[it].z, qb[it].w};
+      float mv[4] = {qc[it].x, qc[it].y, qc[it].z, qc[it].w}, vv[4] = {qd[it].x, qd[it].y, qd[it].z, qd[it].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gg = k.wd != 0.f ? __builtin_fmaf(k.wd, pv[j], gv[j]) : gv[j];
+        mv[j] = mv[j] + (gg - mv[j]) * omb1;                       // the arithmetic of the general loop below
+        vv[j] = vv[j] * k.beta2f + omb2 * gg * gg;
+        const float denom = __builtin_sqrtf(vv[j]) / sqrt_bc2 + k.eps;
+        pv[j] = pv[j] - step_size * (mv[j] / denom);
+      }
+      *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+  } else
 #pragma unroll
   for (int it = 0; it < kAdamChunk / (256 * 4); ++it) {
     const long i = base + ((long)it * 256 + threadIdx.x) * 4;
