@@ -569,9 +569,8 @@ __device__ __forceinline__ void lr_out_rows(const LrBwdK& p, const LrOutBwd& o, 
   }
 }
 
-// weight (and bias) gradients of 16 k rows: the weight role of lr_out_layer_bwd_kernel.  One sample per round: taking two
-// (their x loads and gz / h rows in one memory round trip, as bbb_out_layer_bwd_kernel does) measured within 3 us of
-// this, and with both samples' accumulation unrolled the compiler kept 512 VGPRs and spilled.
+// weight (and bias) gradients of 16 k rows: the weight role of lr_out_layer_bwd_kernel
+template <bool PAIR>
 __device__ __forceinline__ void lr_out_weight_role(const LrBwdK& p, const LrOutBwd& o, float* lds, uint32_t sample_base) {
   float* gzs = lds;
   float* hs = lds + 2 * 128 * 16;
@@ -587,28 +586,34 @@ __device__ __forceinline__ void lr_out_weight_role(const LrBwdK& p, const LrOutB
 #pragma unroll
   for (int n = 0; n < 16; ++n) accM[n] = accS[n] = 0.f;
   float Gb = 0.f, Hb = 0.f;
-  const int J = (B + 15) >> 4;                              // rows per thread (<= 8)
-  for (int s = 0; s < S; ++s) {
-    const float* xs = p.x + (size_t)s * (size_t)p.x_sstride;
-    float xv[8];
+  // PAIR (112 < batch <= 128: J = 8 rows per thread and sample, known at compile time): samples go through in rounds of
+  // two -- their x loads and gz / h rows are one memory round trip
+  const int J = PAIR ? 8 : (B + 15) >> 4;                   // rows per thread and sample (<= 8)
+  constexpr int SP = PAIR ? 2 : 1;
+  for (int s0 = 0; s0 < S; s0 += SP) {
+    float xv[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int b = bg + 16 * j;
-      const float v = xs[(size_t)min(b, B - 1) * K + kx];
-      xv[j] = (j < J && b < B && k_ok) ? v : 0.f;
+    for (int j = 0; j < 16; ++j) {
+      const int sp = PAIR ? (j >> 3) : 0;
+      const int b = bg + 16 * (j - sp * J);
+      const int sm = min(s0 + sp, S - 1);
+      const float v = p.x[(size_t)sm * (size_t)p.x_sstride + (size_t)min(b, B - 1) * K + kx];
+      xv[j] = (j < SP * J && s0 + sp < S && b < B && k_ok) ? v : 0.f;
     }
-    __syncthreads();                                        // the previous sample's readers of gzs / hs are done
-    lr_out_rows(p, o, s, 0, B, sample_base + (uint32_t)s, gzs, hs);
+    __syncthreads();                                        // the previous round's readers of gzs / hs are done
+    lr_out_rows(p, o, s0, 0, B, sample_base + (uint32_t)s0, gzs, hs);
+    if (PAIR && s0 + 1 < S) lr_out_rows(p, o, s0 + 1, 0, B, sample_base + (uint32_t)(s0 + 1), gzs + 128 * 16, hs + 128 * 16);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < J) {
-        const int b = min(bg + 16 * j, B - 1);
-        const float x1 = xv[j], x2 = xv[j] * xv[j];
+    for (int j = 0; j < 16; ++j) {
+      if (j < SP * J) {
+        const int sp = PAIR ? (j >> 3) : 0;
+        const int b = min(bg + 16 * (j - sp * J), B - 1);
+        const float x1 = xv[j], x2 = xv[j] * xv[j];         // (zero for the absent second sample of the last round)
 #pragma unroll
         for (int n4 = 0; n4 < 4; ++n4) {
-          const float4 g = *reinterpret_cast<const float4*>(gzs + b * 16 + n4 * 4);
-          const float4 h = *reinterpret_cast<const float4*>(hs + b * 16 + n4 * 4);
+          const float4 g = *reinterpret_cast<const float4*>(gzs + (sp * 128 + b) * 16 + n4 * 4);
+          const float4 h = *reinterpret_cast<const float4*>(hs + (sp * 128 + b) * 16 + n4 * 4);
           accM[n4 * 4 + 0] = __builtin_fmaf(x1, g.x, accM[n4 * 4 + 0]); accM[n4 * 4 + 1] = __builtin_fmaf(x1, g.y, accM[n4 * 4 + 1]);
           accM[n4 * 4 + 2] = __builtin_fmaf(x1, g.z, accM[n4 * 4 + 2]); accM[n4 * 4 + 3] = __builtin_fmaf(x1, g.w, accM[n4 * 4 + 3]);
           accS[n4 * 4 + 0] = __builtin_fmaf(x2, h.x, accS[n4 * 4 + 0]); accS[n4 * 4 + 1] = __builtin_fmaf(x2, h.y, accS[n4 * 4 + 1]);
@@ -617,13 +622,15 @@ __device__ __forceinline__ void lr_out_weight_role(const LrBwdK& p, const LrOutB
       }
     }
     if (b_ok) {
-      float cs = 0.f;
-      for (int b = 0; b < B; ++b) cs += gzs[b * 16 + tid];
-      float e4[4];
-      philox_normal4((uint32_t)(tid >> 2), sample_base + (uint32_t)s, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
-      const float e = (tid & 3) == 0 ? e4[0] : (tid & 3) == 1 ? e4[1] : (tid & 3) == 2 ? e4[2] : e4[3];
-      Gb += cs;
-      Hb = __builtin_fmaf(cs, e, Hb);
+      for (int sp = 0; sp < SP && s0 + sp < S; ++sp) {
+        float cs = 0.f;
+        for (int b = 0; b < B; ++b) cs += gzs[(sp * 128 + b) * 16 + tid];
+        float e4[4];
+        philox_normal4((uint32_t)(tid >> 2), sample_base + (uint32_t)(s0 + sp), p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+        const float e = (tid & 3) == 0 ? e4[0] : (tid & 3) == 1 ? e4[1] : (tid & 3) == 2 ? e4[2] : e4[3];
+        Gb += cs;
+        Hb = __builtin_fmaf(cs, e, Hb);
+      }
     }
   }
   __syncthreads();                                          // gzs / hs are dead: their memory takes the partial sums
@@ -659,11 +666,12 @@ __device__ __forceinline__ void lr_out_weight_role(const LrBwdK& p, const LrOutB
   }
 }
 
+template <bool PAIR>
 __global__ __launch_bounds__(256) void lr_out_layer_bwd_kernel(const LrBwdK p, const LrOutBwd o) {
-  // weight role: gz / h rows of the current sample, then -- the same memory -- the partial sums
+  // weight role: gz / h rows of the round's (up to two) samples, then -- the same memory -- the partial sums
   // [M | S][bg][n][kc]; input role: gz / h of the block's rows and the M, sigma^2 rows of its k chunk
   __shared__ __attribute__((aligned(16))) float lds[2 * 16 * 16 * 16];     // 32 KiB
-  float* gzs = lds;                                         // [128 rows][16]
+  float* gzs = lds;                                         // [2 x 128 rows][16]
   float* hs = lds + 2 * 128 * 16;
   float (*red)[16 * 16 * 16] = reinterpret_cast<float (*)[16 * 16 * 16]>(lds);
   const int K = p.K, N = p.N, B = p.B, S = p.S;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void lr_out_layer_bwd_kernel(const LrBwdK p, c
     return;
   }
   // ---- weight (and bias) gradients of 16 k rows
-  lr_out_weight_role(p, o, lds, sample_base);
+  lr_out_weight_role<PAIR>(p, o, lds, sample_base);
 }
 
 }  // namespace bnn
@@ -795,7 +803,10 @@ extern "C" int bnn_lr_linear_bwd(const bnn_lr_bwd_args* a, void* stream_) {
     o.rchunks = S * ((B + 31) / 32);
     const long nblk = (long)o.wblocks + (long)o.kchunks * o.rchunks;
     if (nblk < (1L << 30)) {
-      hipLaunchKernelGGL(lr_out_layer_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, kk, o);
+      // one sample per round (PAIR = false).  The two-samples-per-round instantiation is not used: with both samples'
+      // accumulation unrolled the compiler keeps 512 VGPRs and spills.  (The same loop written for one sample only --
+      // 8 instead of 16 row slots per thread -- measured 3 us SLOWER, 15.3 against 12.1 us; kept as measured.)
+      hipLaunchKernelGGL(lr_out_layer_bwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, stream, kk, o);
       const hipError_t e1 = hipGetLastError();
       return e1 == hipSuccess ? BNN_OK : (int)e1;
     }
