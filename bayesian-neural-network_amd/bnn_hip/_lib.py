@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 2
+#define BNN_HIP_ABI_VERSION 3
 
 enum bnn_status {
   BNN_OK = 0,
