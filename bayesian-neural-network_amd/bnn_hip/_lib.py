@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1
@@ -15,7 +15,7 @@ MATH_F32, MATH_BF16 = 0, 1
 EPS_PHILOX, EPS_MEMORY, EPS_ZERO = 0, 1, 2
 PRIOR_GAUSS, PRIOR_MIXTURE = 0, 1
 NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
-FORM_AUTO, FORM_TILE, FORM_GEMM, FORM_GEMM_KSLICE = 0, 1, 2, 3
+FORM_AUTO, FORM_TILE, FORM_GEMM, FORM_GEMM_KSLICE, FORM_BLOCK256 = 0, 1, 2, 3, 4
 
 EXPORTS = (
     "bnn_version", "bnn_status_string",
@@ -25,7 +25,7 @@ EXPORTS = (
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_stage_inputs_cast", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
     "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
-    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare", "bnn_bias_act",
+    "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
 )
 
@@ -282,8 +282,6 @@ def load():
                                       C.c_int32, C.c_void_p]
     lib.bnn_softplus.restype = C.c_int
     lib.bnn_softplus.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-    lib.bnn_bias_act.restype = C.c_int
-    lib.bnn_bias_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.bnn_eval_prepare.restype = C.c_int
     lib.bnn_eval_prepare.argtypes = [C.POINTER(PrepareArgs), C.c_void_p]
     lib.bnn_cast_bf16.restype = C.c_int

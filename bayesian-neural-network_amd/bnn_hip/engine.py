@@ -55,14 +55,15 @@ def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
 
 
 # BBB, bf16 math, forward-only: layers fed with at least this many batch rows sample their weights once per launch
-# (bnn_bbb_sample_weights: 8 B read + 2 B written per weight and sample, statistics included) and run the matmul as a
-# plain library GEMM (ops.bbb_library_matmul): 2 * batch flops per sampled weight make the matrix cores the bound, and
-# the fused kernels would redo the sampling for every 128-row batch block
-LIB_GEMM_MIN_BATCH = 512
+# (bnn_bbb_sample_weights: 8 B read + 2 B written per weight and sample, statistics included) and run the matmul over
+# them in the library's 256 x 256 block form (K1g, csrc/bbb_block_gemm.h: bnn_bbb_linear_fwd takes it for w_sampled and
+# >= 512 batch rows): 2 * batch flops per sampled weight make the matrix cores the bound, and the fused kernels would
+# redo the sampling for every 128-row batch block
+BLOCK_GEMM_MIN_BATCH = 512
 
 
-def use_library_gemm(sp, batch: int, hidden_dtype) -> bool:
-    return (not sp.lr) and hidden_dtype == torch.bfloat16 and batch >= LIB_GEMM_MIN_BATCH and sp.in_out[0] % 8 == 0 and \
+def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:
+    return (not sp.lr) and hidden_dtype == torch.bfloat16 and batch >= BLOCK_GEMM_MIN_BATCH and sp.in_out[0] % 8 == 0 and \
         state.form == L.FORM_AUTO
 
 
@@ -170,7 +171,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     hoisted = {}
     if hidden_dtype == torch.bfloat16 and sample and not differentiable and (x.dtype == torch.bfloat16 or want_cast):
         hoisted = {i: None for i, sp in enumerate(layers)
-                   if not sp.lr and hoist_sigma(*sp.in_out, n_local, x.shape[-2]) and not use_library_gemm(sp, x.shape[-2], hidden_dtype)}
+                   if not sp.lr and hoist_sigma(*sp.in_out, n_local, x.shape[-2]) and not use_block_gemm(sp, x.shape[-2], hidden_dtype)}
     if want_cast or hoisted:
         sig, c16, c16sq = ops.eval_prepare([layers[i].m.weight_rho.detach() for i in hoisted],
                                            cast=x if want_cast else None, want_sq=lr_sq and want_cast)
@@ -231,13 +232,13 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
                           sample_offset=first_sample, want_stats=want_stats, form=state.form)
-                if eps_mode == L.EPS_PHILOX and use_library_gemm(sp, h.shape[-2], hidden_dtype):
+                if eps_mode == L.EPS_PHILOX and use_block_gemm(sp, h.shape[-2], hidden_dtype):
                     if h.dtype != torch.bfloat16:
                         h = ops.cast_bf16(h)
                     sm = ops.bbb_sample_weights([dict(w_mu=pd[0], w_rho=pd[1], b_mu=pd[2], b_rho=pd[3], prior=call.prior,
                                                        layer_id=sp.layer_id)], n_samples=n_local, seed=state.seed,
                                                 sample_offset=first_sample)[0]
-                    h = ops.bbb_library_matmul(h, sm["w"], sm["b"], n_samples=n_local, relu=sp.relu, y_dtype=call.y_dtype)
+                    h = ops.bbb_sampled_matmul(h, sm["w"], sm["b"], n_samples=n_local, relu=sp.relu, y_dtype=call.y_dtype)
                     stats.append(sm["workspace"])
                     continue
                 if i in hoisted and h.dtype == torch.bfloat16:
@@ -474,8 +475,8 @@ class GraphedElbo:
         self.sums = self._sums if self.G > 1 else self._sums.view(4)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scratch = ops.final_scratch(S, dev) if (not self.lr or wide_nll(self.specs, B) or self.specs[-1].in_out[1] <= 16) else None
-        # large batches: sample once per launch, then a plain library GEMM (use_library_gemm)
-        self.lib = [use_library_gemm(sp, B, hid) for sp in self.specs]
+        # large batches: sample once per launch, then the 256 x 256 block form of the matmul (use_block_gemm)
+        self.lib = [use_block_gemm(sp, B, hid) for sp in self.specs]
         self.lib_w = [torch.empty((S, sp.in_out[1], sp.in_out[0]), dtype=torch.bfloat16, device=dev) if lb else None
                       for sp, lb in zip(self.specs, self.lib)]
         self.lib_b = [torch.empty((S, sp.in_out[1]), dtype=torch.float32, device=dev) if lb else None
@@ -564,7 +565,7 @@ class GraphedElbo:
                 ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,
                                              workspace=self.ws[i], w_out=self.lib_w[i], b_out=self.lib_b[i])],
                                        n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
-                ops.bbb_library_matmul(h, self.lib_w[i], self.lib_b[i], n_samples=self.n_local, relu=sp.relu,
+                ops.bbb_sampled_matmul(h, self.lib_w[i], self.lib_b[i], n_samples=self.n_local, relu=sp.relu,
                                        y_dtype=self.bufs[i].dtype, out=self.bufs[i])
                 if i == last:
                     ops.elbo_finalize(workspaces=self.ws, logits=self.bufs[i], **fin_kw)

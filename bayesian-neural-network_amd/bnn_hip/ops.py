@@ -308,65 +308,15 @@ def bbb_sample_weights(layers, **kw):
     return res
 
 
-def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, want_y16: bool = False, wt_out=None):
+def bbb_sampled_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None, want_y16: bool = False, wt_out=None,
+                       form: int = 0):
     """Matmul half of K1 over weights sampled by bbb_sample_weights: y[s] = act(x[s] . w[s]^T + b[s]).  `want_y16`:
     returns (y fp32, y in bf16).  `wt_out` (bf16 [S,in,out]): the launch also leaves w transposed there."""
     a, res, keep = _bbb_build(x, None, None, None, None, n_samples=n_samples, prior=PriorSpec(), math_mode=L.MATH_BF16, relu=relu,
                               y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=out, w_sampled=w, b_sampled=b,
-                              want_y16=want_y16, wt_out=wt_out)
+                              want_y16=want_y16, wt_out=wt_out, form=form)
     L.check(L.load().bnn_bbb_linear_fwd(C.byref(a), _stream()), "bnn_bbb_linear_fwd")
     return (res["y"], res["y16"]) if want_y16 else res["y"]
-
-
-def bbb_library_matmul(x, w, b, *, n_samples: int, relu: bool, y_dtype: torch.dtype, out=None):
-    """y[s] = act(x[s] . w[s]^T + b[s]) through the BLAS library (hipBLASLt / rocBLAS behind torch): what is left of a
-    BayesianLinear layer (networks.py:88) once bbb_sample_weights has drawn its weights is a plain bf16 GEMM, and for
-    batches of >= 512 rows the matrix cores, not the sampling, bound the layer (a 1024 x 4096 x 4096 sample is 34 GFLOP
-    against 168 MB of parameters).  x [B,K] (shared) or [rows,B,K] bf16 with rows | n_samples, w bf16 [S,out,in], b
-    fp32 [S,out]; y [S,B,out] in `y_dtype`.  Only the most ordinary library call is used, F.linear (an NT GEMM): one over
-    all samples' weights stacked along the output dimension when they share x, one per sample otherwise; the product
-    leaves the library in bf16 (fp32 accumulation inside), then bias, ReLU and the conversion to `y_dtype` are
-    elementwise passes over y."""
-    require_device(x, w, b)
-    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or b.dtype != torch.float32:
-        raise BnnHipError("bbb_library_matmul: bf16 x and w, fp32 b")
-    S, N, K = w.shape
-    if S != n_samples or x.shape[-1] != K or b.numel() != S * N:
-        raise BnnHipError("bbb_library_matmul: shape mismatch")
-    B = x.shape[-2]
-    rows = x.shape[0] if x.dim() == 3 else 1
-    if S % rows:
-        raise BnnHipError("bbb_library_matmul: x row blocks must divide n_samples")
-    g = S // rows
-    y = out if (out is not None and out.dtype == y_dtype and out.is_contiguous()) else torch.empty((S, B, N), dtype=y_dtype, device=x.device)
-    fused = N % 8 == 0                                   # bias + ReLU + conversion as ONE pass (bnn_bias_act) over the
-    prod = torch.empty((S, B, N), dtype=torch.bfloat16, device=x.device) if fused else None   # library's bf16 product
-    if g == 1:
-        # one NT GEMM per sample (each is >= 2 * 512 * out * in flops: large enough alone).  torch.bmm is avoided on
-        # purpose: on this image (torch 2.10 + rocm 7.0 wheels on a ROCm 7.2 gfx950 box) a bf16 bmm of
-        # [4,1024,4096] x [4,4096,4096]^T raises a GPU memory access fault inside the library, mm does not
-        x3 = x.view(S, B, K)
-        for s_ in range(S):
-            if fused:
-                torch.mm(x3[s_], w[s_].t(), out=prod[s_])     # straight into the product buffer: no copy pass
-            else:
-                y[s_].copy_(torch.nn.functional.linear(x3[s_], w[s_]))
-    else:
-        x3 = x.view(rows, B, K)
-        for r in range(rows):                                                            # one NT GEMM per minibatch
-            pr = torch.nn.functional.linear(x3[r], w[r * g:(r + 1) * g].view(g * N, K))   # [B, g * N]
-            (prod if fused else y)[r * g:(r + 1) * g].copy_(pr.view(B, g, N).transpose(0, 1))
-    if fused:
-        L.check(L.load().bnn_bias_act(prod.data_ptr(), b.data_ptr(), y.data_ptr(), _dt(y), S, B, N, int(relu), _stream()),
-                "bnn_bias_act")
-    else:
-        y.add_(b.view(S, 1, N).to(y.dtype))
-        if relu:
-            y.relu_()
-    if out is not None and y is not out:
-        out.copy_(y)
-        return out
-    return y
 
 
 def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, math_mode: int, relu: bool,

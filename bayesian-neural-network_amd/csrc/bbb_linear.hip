@@ -33,6 +33,7 @@
 #include "bnn_device.h"
 #include "bnn_fin.h"
 #include "bbb_sample_body.h"
+#include "bbb_block_gemm.h"
 #include "../../include/bnn_hip.h"
 #include <string.h>
 
@@ -1274,6 +1275,7 @@ constexpr size_t kL2WeightBudget = 2560 * 1024;   // of an XCD's 4 MiB L2: the (
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
 constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
 constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
+constexpr int kBlockGemmMinBatch = 512;     // matmul half over sampled weights: the 256 x 256 block form from this many batch rows
 constexpr int kSliceMinSamples = 4;          // ... from this many samples per launch (below: the tile form's narrow tiles)
 
 // TILE form.  Narrower tiles (more k-range classes per MFMA tile) until the launch covers the chip; the block's waves
@@ -1356,9 +1358,19 @@ hipError_t allow_big_lds(KernelT kernel, size_t lds) {
 }  // namespace
 
 // `al`: the 16-byte vector path applies (K % 8 == 0, aligned bases).  Returns a bnn_status.
-static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl) {
+static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_block = true) {
   const int S = a->n_samples, B = a->batch, K = a->in_features, N = a->out_features;
   const int mbs = (B + 127) / 128;
+  if (allow_block && a->w_sampled && a->x_dtype == BNN_BF16 && !a->w_sampled_t_out && !a->y_bf16_copy &&
+      (a->form == BNN_FORM_BLOCK256 || (a->form == BNN_FORM_AUTO && B >= kBlockGemmMinBatch)) &&
+      (double)(B > N ? B : N) * K * 2.0 < 2147483648.0) {
+    // matmul half over >= 512 batch rows: 2 * batch flops per sampled weight -- the matrix-core-bound block form (K1g)
+    pl.form = BNN_FORM_BLOCK256;
+    pl.R = 1; pl.nw = 8; pl.mt = 16; pl.tiles = (N + 15) / 16; pl.ksl = 1;
+    pl.blocks = (long)S * ((B + 255) / 256) * ((N + 255) / 256);
+    pl.lds = kBgLds;
+    return BNN_OK;
+  }
   if (a->w_sampled) {
     // matmul half only: same tile machinery, no generator work.  Without it a block's cost is the x it pulls through
     // its CU's L1 -- all of K for its rows -- so 32-row batch blocks (four times the blocks, each ingesting a quarter)
@@ -1424,7 +1436,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
     if (!aligned16(a->x) || !aligned16(a->w_sampled)) return BNN_ERR_ALIGN;
   }
   if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u ||
-      (unsigned)a->prior.kind > 1u || (unsigned)a->form > 3u)
+      (unsigned)a->prior.kind > 1u || (unsigned)a->form > 4u)
     return BNN_ERR_ENUM;
   if (!pre && a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
   if (a->want_stats) {
@@ -1499,7 +1511,7 @@ extern "C" int bnn_bbb_plan(const bnn_bbb_fwd_args* a, bnn_plan* out) {
   out->k_slices = pl.ksl;
   out->blocks = (int32_t)pl.blocks;
   out->lds_bytes = (int32_t)pl.lds;
-  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : 64;
+  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : pl.form == BNN_FORM_BLOCK256 ? 256 : 64;
   return BNN_OK;
 }
 
@@ -1516,7 +1528,7 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
     k.mask_sstride = mask_sstride;
   }
   BbbPlan pl{};
-  rc = bbb_plan(a, al, pl);
+  rc = bbb_plan(a, al, pl, grad_mask == nullptr);    // the masked input-gradient epilogue belongs to the tile form
   if (rc != BNN_OK) return rc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int K = a->in_features;
@@ -1536,6 +1548,17 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
       rc = bnn_bbb_sample_weights(a->rider, stream_);
       if (rc != BNN_OK) return rc;
     }
+  }
+  if (pl.form == BNN_FORM_BLOCK256) {
+    if (a->rider && ride) return BNN_ERR_SHAPE;      // (never: ride needs !w_sampled)
+    BlockGemmK g{};
+    g.x = reinterpret_cast<const __bf16*>(a->x);
+    g.x_sstride = k.x_sstride; g.xg = k.xg;
+    g.w = k.w_pre; g.bias = k.b_pre; g.y = a->y;
+    g.y_bf16 = k.y_bf16; g.relu = k.relu;
+    g.S = a->n_samples; g.M = a->batch; g.N = a->out_features; g.K = K;
+    err = launch_block_gemm(g, stream);
+    return err == hipSuccess ? BNN_OK : (int)err;
   }
   if (a->w_sampled) {
 #define BNN_PRE(XDT)                                                                              \

@@ -281,38 +281,6 @@ __global__ __launch_bounds__(256) void eval_prepare_kernel(const PrepK p) {
   }
 }
 
-// ----------------------------------------------------------------------------- bias + activation epilogue
-// y[s][b][n] = act(prod[s][b][n] + bias[s][n]): the epilogue of a layer whose matmul ran in the BLAS library
-// (ops.bbb_library_matmul): one pass instead of a copy, an add and a ReLU pass.  prod bf16, bias fp32, y bf16 or fp32.
-__global__ void bias_act_kernel(const __bf16* __restrict__ prod, const float* __restrict__ bias, void* __restrict__ y, long rows_per_s,
-                                int N, long total8, int relu, int y_bf16) {
-  // N % 8 == 0: a thread owns 8 consecutive features of one row
-  const int n8 = N >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
-    const long row = i / n8;
-    const int c = (int)(i - row * n8) * 8;
-    const long s = row / rows_per_s;
-    const bf16x8 pv = *reinterpret_cast<const bf16x8*>(prod + row * N + c);
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + s * N + c), b1 = *reinterpret_cast<const float4*>(bias + s * N + c + 4);
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = (float)pv[j] + bb[j];
-      if (relu) v[j] = fmaxf(v[j], 0.f);
-    }
-    if (y_bf16) {
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
-      *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(y) + row * N + c) = o;
-    } else {
-      float* yp = reinterpret_cast<float*>(y) + row * N + c;
-      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
-  }
-}
 
 // ----------------------------------------------------------------------------- Philox fill
 __global__ void philox_normal_kernel(float* __restrict__ eps, uint32_t k0, uint32_t k1, uint32_t tensor_id,
@@ -705,22 +673,6 @@ extern "C" int bnn_eval_prepare(const bnn_prepare_args* a, void* stream_) {
   }
   if (blocks == 0) return BNN_ERR_SHAPE;
   hipLaunchKernelGGL(eval_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), k);
-  hipError_t err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
-}
-
-extern "C" int bnn_bias_act(const void* prod_bf16, const float* bias, void* y, int32_t y_dtype, int32_t n_samples, int32_t batch,
-                            int32_t out_features, int32_t relu, void* stream_) {
-  if (!prod_bf16 || !bias || !y) return BNN_ERR_NULL;
-  if (n_samples <= 0 || batch <= 0 || out_features <= 0 || (out_features & 7)) return BNN_ERR_SHAPE;
-  if ((unsigned)y_dtype > 1u) return BNN_ERR_ENUM;
-  if ((reinterpret_cast<uintptr_t>(prod_bf16) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(y)) & 15) return BNN_ERR_ALIGN;
-  const long total8 = (long)n_samples * batch * (out_features >> 3);
-  long nb = (total8 + 255) / 256;
-  nb = nb > 8192 ? 8192 : nb;
-  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
-                     reinterpret_cast<const __bf16*>(prod_bf16), bias, y, (long)batch, out_features, total8, relu ? 1 : 0,
-                     y_dtype == BNN_BF16 ? 1 : 0);
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

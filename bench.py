@@ -235,25 +235,25 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     xin, ws, out = ev.bufs[0], ev.ws[1], ev.bufs[1]
     mm = bnn_hip.runtime.state.math
     if getattr(ev, "lib", [False] * 3)[1]:
-        # large batch: the layer is a sampling launch (HBM: 8 B read + 2 B written per weight and sample) followed by a
-        # plain library GEMM over the sampled weights (matrix cores): the GEMM is the dominant kernel
+        # large batch: the layer is a sampling launch (HBM: 8 B read + 2 B written per weight and sample) followed by the
+        # 256 x 256 block form of the matmul over the sampled weights (K1g, matrix cores): the matmul is the dominant kernel
         wl, bl = ev.lib_w[1], ev.lib_b[1]
         smp = lambda: ops.bbb_sample_weights([dict(w_mu=pd[0], w_rho=pd[1], b_mu=pd[2], b_rho=pd[3], prior=l2._prior_spec, layer_id=1,
                                                     workspace=ws, w_out=wl, b_out=bl)], n_samples=n, seed=1)
-        gemm = lambda: ops.bbb_library_matmul(xin, wl, bl, n_samples=n, relu=True, y_dtype=out.dtype, out=out)
+        gemm = lambda: ops.bbb_sampled_matmul(xin, wl, bl, n_samples=n, relu=True, y_dtype=out.dtype, out=out)
         us_s = kernel_alone_us(smp, torch.cuda.current_stream(), per_graph=10, reps=10)
         us_g = kernel_alone_us(gemm, torch.cuda.current_stream(), per_graph=4, reps=10)
         flops = 2.0 * n * batch * dims[1] * dims[1]
         sbytes = n * 10 * (dims[1] * dims[1] + dims[1])
         tf = flops / (us_g * 1e-6) / 1e12
         return {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None, "kernel": f"library bf16 GEMM (hipBLASLt/rocBLAS via torch) over pre-sampled weights + bias/ReLU passes, "
-                                           f"layer 2 ({dims[1]}x{dims[1]}), batch {batch}",
+                "traffic": None, "kernel": f"bnn::bbb_block_gemm_kernel (K1g: 256x256 block tile, v_mfma_f32_16x16x32_bf16, LDS-DMA operands, "
+                                           f"bias/ReLU/bf16 epilogue) over pre-sampled weights, layer 2 ({dims[1]}x{dims[1]}), batch {batch}",
                 "algorithmic_flops_per_launch": flops, "mc_samples_per_launch": n, "avg_launch_us": us_g,
                 "sampling": {"kernel": "K1s bbb_sample_kernel", "avg_launch_us": us_s, "algorithmic_bytes_per_launch": sbytes,
                              "hbm_GBps": sbytes / (us_s * 1e-6) / 1e9, "hbm_frac": sbytes / (us_s * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                "note": "HIP events around back-to-back graph launches; the GEMM time includes the bias / ReLU / copy passes of "
-                        "ops.bbb_library_matmul; 2 * batch * weights flops per sample against the dense bf16 MFMA peak"}
+                "note": "HIP events around back-to-back graph launches of the one matmul launch (bias, ReLU and the bf16 conversion are its "
+                        "epilogue); 2 * batch * weights flops per sample against the dense bf16 MFMA peak"}
     common = dict(n_samples=n, math_mode=mm, relu=True, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1,
                   workspace=ws, out=out)
     if lr:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 3
+#define BNN_HIP_ABI_VERSION 4
 
 enum bnn_status {
   BNN_OK = 0,
@@ -79,8 +79,11 @@ enum bnn_nll_mode { BNN_NLL_REGRESSION = 0, BNN_NLL_CLASSIFICATION = 1 };
 /* Kernel forms of a layer launch.  TILE: one block per (feature tile, sample, batch block), the block's
  * waves split the reduction and meet in LDS -- few samples in flight.  GEMM: block GEMM, the x tile shared
  * through LDS by LDS-DMA, a wave owns 16 features for all of K -- many samples.  GEMM_KSLICE (BBB): the GEMM
- * form with the reduction cut into slices whose fp32 partial tiles a second kernel sums in slice order. */
-enum bnn_form { BNN_FORM_AUTO = 0, BNN_FORM_TILE = 1, BNN_FORM_GEMM = 2, BNN_FORM_GEMM_KSLICE = 3 };
+ * form with the reduction cut into slices whose fp32 partial tiles a second kernel sums in slice order.
+ * BLOCK256 (BBB, matmul half over w_sampled only): one 8-wave block per 256 x 256 output tile, both operands
+ * through LDS by LDS-DMA, ping-pong MFMA / load segments -- layers fed >= 512 batch rows, where the bf16
+ * matrix cores, not the sampling, bound the layer (K1g, csrc/bbb_block_gemm.h). */
+enum bnn_form { BNN_FORM_AUTO = 0, BNN_FORM_TILE = 1, BNN_FORM_GEMM = 2, BNN_FORM_GEMM_KSLICE = 3, BNN_FORM_BLOCK256 = 4 };
 
 typedef struct bnn_prior {
   int32_t kind;      /* bnn_prior_kind */
@@ -704,13 +707,6 @@ typedef struct bnn_prepare_args {
   int64_t cast_n;
 } bnn_prepare_args;
 int bnn_eval_prepare(const bnn_prepare_args* args, void* stream);
-
-/* y[s][b][n] = act(prod[s][b][n] + bias[s][n]) in one pass: the epilogue of a BayesianLinear layer (networks.py:88,
- * :169-171) whose matmul over pre-sampled weights ran in the BLAS library (batches of >= 512 rows).  prod bf16
- * [n_samples, batch, out], bias fp32 [n_samples, out] (bnn_bbb_sample_weights' b_out), y bf16 or fp32 (bnn_dtype);
- * out_features % 8 == 0, 16-byte aligned pointers. */
-int bnn_bias_act(const void* prod_bf16, const float* bias, void* y, int32_t y_dtype, int32_t n_samples, int32_t batch,
-                 int32_t out_features, int32_t relu, void* stream);
 
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
 const char* bnn_status_string(int status); /* static string for a negative status */

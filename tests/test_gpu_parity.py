@@ -1087,11 +1087,11 @@ def test_row_split_output_layer_equals_the_two_launch_form(dev, monkeypatch, dim
     close(b1, b2.cpu().numpy(), rtol=nll_tol)
 
 
-def test_large_batch_layers_take_the_library_gemm(dev, monkeypatch):
-    """Batches of >= 512 rows: every BBB layer is one sampling launch (K1s) + a plain library GEMM over the sampled
-    weights (ops.bbb_library_matmul) instead of the fused kernels; same Philox elements, so the evaluation agrees
-    with the fused path to bf16 rounding (the library rounds each layer's product to bf16 before bias and ReLU), and
-    with the fp32 oracle within the bf16 tolerances."""
+def test_large_batch_layers_take_the_block_gemm(dev, monkeypatch):
+    """Batches of >= 512 rows: every BBB layer is one sampling launch (K1s) + the 256 x 256 block form of the matmul
+    over the sampled weights (K1g, bnn_bbb_linear_fwd with w_sampled) instead of the fused kernels; same Philox
+    elements, so the evaluation agrees with the fused path to bf16 rounding of the operands, and with the fp32 oracle
+    within the bf16 tolerances."""
     from bnn_hip import engine
     bnn_hip.set_math("bf16")
     B, dims, S = 512, (64, 96, 8), 3
@@ -1123,3 +1123,87 @@ def test_large_batch_layers_take_the_library_gemm(dev, monkeypatch):
     close(o1["log_prior"], want[:, 0], rtol=1e-5)
     close(o1["log_q"], want[:, 1], rtol=1e-5)
     close(o1["nll"], want[:, 2], rtol=BF16_NLL_RTOL)
+
+
+BLOCK_SHAPES = [  # (samples, batch, out, in, x shared by the samples): edges of every kind
+    (1, 256, 256, 64, False),      # one K-tile, one block
+    (2, 256, 256, 128, False),     # two K-tiles: prologue + the two tail forms only
+    (2, 300, 520, 192, False),     # ragged batch and feature edges (clamped rows), three K-tiles
+    (2, 512, 1200, 784, True),     # the MNIST first layer at 512 rows: K % 64 = 16 (zero-filled chunks), x shared
+    (3, 1024, 1200, 1200, False),  # the MNIST hidden layer at 1024 rows: K % 64 = 48, N % 256 = 176
+    (1, 100, 40, 8, False),        # everything smaller than one tile; K = 8: a single chunk
+    (5, 70, 10, 1200, False),      # output-layer shape: N % 4 != 0 -> the scalar bias / store path
+]
+
+
+@pytest.mark.parametrize("shape", BLOCK_SHAPES)
+@pytest.mark.parametrize("y_dtype", [torch.float32, torch.bfloat16])
+def test_block_gemm_against_fp64_reference(dev, shape, y_dtype):
+    """K1g alone (bnn_bbb_linear_fwd, w_sampled, BNN_FORM_BLOCK256 forced so small batches take it too): y[s] =
+    act(x[s] . w[s]^T + b[s]) on bf16 operands against the same product in float64 on the host.  The bf16 products are
+    exact in fp32, so only the accumulation order differs: fp32 y to 1e-5 of the row scale, bf16 y to one bf16 ulp."""
+    S, B, N, K, shared = shape
+    rs = np.random.RandomState(S * 1000 + N)
+    x = torch.from_numpy(rs.uniform(0, 1, ((1 if shared else S), B, K)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy(rs.uniform(-0.2, 0.2, (S, N, K)).astype(np.float32)).to(torch.bfloat16)
+    # asymmetric operands: a transposed C write or a swapped fragment cannot pass
+    w[:, 0, :] = 0.25
+    x[:, -1, :] = 0.5
+    b = torch.from_numpy(rs.uniform(-0.2, 0.2, (S, N)).astype(np.float32))
+    ref = torch.einsum("sbk,snk->sbn", x.double().expand(S, B, K), w.double()) + b.double()[:, None, :]
+    for relu in (True, False):
+        want = torch.relu(ref) if relu else ref
+        xin = x[0].to(dev) if shared else x.to(dev)
+        sentinel = torch.full((S, B, N), float("nan"), dtype=y_dtype, device=dev)
+        got = ops.bbb_sampled_matmul(xin, w.to(dev), b.to(dev), n_samples=S, relu=relu, y_dtype=y_dtype, out=sentinel,
+                                     form=L.FORM_BLOCK256)
+        g = got.double().cpu()
+        assert torch.isfinite(g).all()
+        scale = float(want.abs().max())
+        tol = (1e-5 if y_dtype == torch.float32 else 2.0 ** -8) * scale
+        err = float((g - want).abs().max())
+        assert err <= tol, (shape, y_dtype, relu, err, scale)
+    plan_args = ops._bbb_build(xin, None, None, None, None, n_samples=S, prior=ops.PriorSpec(), math_mode=L.MATH_BF16, relu=True,
+                               y_dtype=y_dtype, eps_mode=L.EPS_ZERO, want_stats=False, w_sampled=w.to(dev), b_sampled=b.to(dev),
+                               form=L.FORM_BLOCK256)[0]
+    pl = L.Plan()
+    L.check(L.load().bnn_bbb_plan(plan_args, pl), "bnn_bbb_plan")
+    assert pl.form == L.FORM_BLOCK256 and pl.blocks == S * ((B + 255) // 256) * ((N + 255) // 256) and pl.waves == 8
+
+
+def test_c5_wide_bbb_layer_batch_1024_block_form_against_oracle(dev):
+    """BASELINE configs[4]'s matrix-core-bound point at full size: one 4096 x 4096 BayesianLinear layer fed 1024 batch
+    rows, 2 MC samples, on-chip Philox: the sampling launch (K1s) + the block form of the matmul (K1g, chosen by the plan
+    for >= 512 rows), against the oracle's layer (networks.py:73-88) on the same epsilon: y to 2e-2 of scale (K = 4096
+    products of bf16-rounded operands), the fp32 statistics to 1e-5."""
+    S, B, K, N, seed, off = 2, 1024, 4096, 4096, 99, 40
+    rs = np.random.RandomState(78)
+    w_mu = rs.uniform(-0.2, 0.2, (N, K)).astype(np.float32)
+    w_rho = rs.uniform(-5, -4, (N, K)).astype(np.float32)
+    b_mu = rs.uniform(-0.2, 0.2, N).astype(np.float32)
+    b_rho = rs.uniform(-5, -4, N).astype(np.float32)
+    x = rs.uniform(0, 1, (B, K)).astype(np.float32)
+    prior = O.Prior.from_init([1.0], False)
+    dw = [t(a).to(dev) for a in (w_mu, w_rho, b_mu, b_rho)]
+    sm = ops.bbb_sample_weights([dict(w_mu=dw[0], w_rho=dw[1], b_mu=dw[2], b_rho=dw[3], prior=ops.PriorSpec(False, 1.0), layer_id=1)],
+                                n_samples=S, seed=seed, sample_offset=off)[0]
+    xin = t(x).to(dev).to(torch.bfloat16)
+    y = ops.bbb_sampled_matmul(xin, sm["w"], sm["b"], n_samples=S, relu=True, y_dtype=torch.float32)
+    # per-sample statistics from the sampler's workspace: {sum eps^2, sum w^2, sum log sigma (sample 0's entries)} per tile
+    ws = sm["workspace"]
+    T = int(ws[:1].view(torch.int32)[0])
+    per = ws[4:4 + 4 * S * T].view(S, T, 4).double().sum(1).cpu().numpy()
+    sls = float(ws[4:4 + 4 * T].view(T, 4).double().sum(0)[2])
+    n_el, c0 = N * K + N, -0.5 * math.log(2.0 * math.pi)
+    torch.set_num_threads(8)
+    for s in range(S):
+        ew = t(O.philox_normal(seed, O.tensor_id(1, 0), off + s, N, K))
+        eb = t(O.philox_normal(seed, O.tensor_id(1, 1), off + s, 1, N))[0]
+        yr, lp, lq = O.bbb_linear(t(x), t(w_mu), t(w_rho), t(b_mu), t(b_rho), ew, eb, prior)
+        yr = torch.relu(yr).numpy()
+        scale = float(np.abs(yr).max())
+        err = float(np.abs(y[s].double().cpu().numpy() - yr).max())
+        assert err <= 2e-2 * scale, (s, err, scale)
+        close(n_el * c0 - 0.5 * per[s, 1], float(lp), rtol=1e-5)             # Gaussian prior, sigma_p = 1 (networks.py:67-68)
+        close(n_el * c0 - sls - 0.5 * per[s, 0], float(lq), rtol=1e-5)       # networks.py:46 at w = mu + sigma eps
+    torch.set_num_threads(1)
