@@ -17,25 +17,34 @@
 // 4 x 2 accumulator tiles of v_mfma_f32_16x16x32_bf16 (A operand = 16 features x 32 k of w, B operand = 32 k x 16 rows
 // of x, so a lane ends up with 4 consecutive FEATURES of one batch row: 8 / 16-byte y stores).
 //
-// Schedule.  A K-tile is four PHASES, one quadrant (16 MFMAs x K = 64 -> 16 x 2 k-halves... 16 MFMAs) each:
-//     phase:  LOAD segment  { ds_read_b128 fragments ; issue one half-tile of LDS-DMA ; s_waitcnt vmcnt(8) }
+// Schedule.  A K-tile is a sequence of PHASES, each
+//             LOAD segment  { ds_read_b128 fragments ; issue LDS-DMA half-tiles ; counted s_waitcnt vmcnt }
 //             s_barrier
-//             MFMA segment  { s_waitcnt lgkmcnt(0) ; 16 MFMAs }
+//             MFMA segment  { s_waitcnt lgkmcnt(0) ; one or two quadrants of 16 MFMAs }
 //             s_barrier
-//   ph0 reads W0 (4) + X0 (8) -> quadrant (0,0);  ph1 reads W1 (4) -> (0,1);  ph2 reads X1 (8) -> (1,1);  ph3 reads
-//   nothing (W0 is still in registers) -> (1,0).
 // Waves 4-7 run one barrier behind waves 0-3 (they pass one extra s_barrier before the loop), so on every SIMD one
 // wave is in its MFMA segment while its partner is in its LOAD segment: the matrix pipe is never shared and the LDS /
-// DMA issue of one wave hides behind the other's MFMAs.
-// LDS-DMA pipeline (phase numbers p = 4 * tile + ph; group g in {0,1} runs LOAD(p) in barrier interval 2p + g):
-//   ph0 of tile u issues W1 of tile u+1,  ph1: X1 of u+1,  ph2: X0 of u+2,  ph3: W0 of u+2  (each into the buffer of its
-//   tile's parity).  WAR: a half-tile is re-filled at least two phases after its last read (X0/W0 read in ph0, re-filled
-//   in ph2/ph3; W1 read in ph1, re-filled in ph0 of the next tile; X1 read in ph2, re-filled in ph1 of the next tile):
-//   the later group's reads retire (lgkmcnt(0) at the top of its MFMA segment) before the barrier that precedes the
-//   earlier group's issue.  RAW: every phase waits vmcnt(8) after its issue = "my two pieces issued four phases ago have
-//   landed", then meets the block; each half-tile is read five or more phases after its issue.  Four half-tiles
-//   (64 KiB per CU) stay in flight across the barriers; vmcnt never drains to zero inside the loop.
-//   The last two K-tiles issue less, so their waits count down (8, 8, 6, 4 | 2, 0).
+// DMA issue of one wave hides behind the other's MFMAs.  Group g in {0,1} runs LOAD(p) in barrier interval 2p + g and
+// MFMA(p) in interval 2p + g + 1, so a half-tile may be re-filled from two phases after its last read on (the later
+// group's reads retire -- lgkmcnt(0) at the top of its MFMA segment -- before the barrier that precedes the earlier
+// group's issue), and LDS-DMA data may be read one phase after the phase whose LOAD segment waited for it (the wait sits
+// before that segment's barrier; nothing else orders a ds_read behind another wave's DMA).  vmcnt never drains to zero
+// inside the loop.
+//   Two-phase form (BG_PHASES 2, the product build: 104.5 against 109.2 us at 4 x 1024 x 4096 x 4096 -- half the barriers,
+//   32-MFMA segments), tile u in buffer u & 1:
+//     A: reads W0 W1 X0 (16), issues X0 W0 W1 of tile u+1, vmcnt(6) = "X1 of tile u has landed";  quadrants (0,0) (0,1)
+//     B: reads X1 (8),        issues X1 of tile u+1,       vmcnt(2) = "the three of phase A have"; quadrants (1,1) (1,0)
+//   Four-phase form (BG_PHASES 4: 16-MFMA segments, finer-grained buffer release, four half-tiles = 64 KiB per CU in flight):
+//     ph0 reads W0 X0 (12) -> (0,0); ph1 reads W1 (4) -> (0,1); ph2 reads X1 (8) -> (1,1); ph3 reads nothing -> (1,0);
+//     ph0 of tile u issues W1 of tile u+1, ph1: X1 of u+1, ph2: X0 of u+2, ph3: W0 of u+2; every phase waits vmcnt(8)
+//     after its issue = "my two pieces issued four phases ago have landed"; the last two K-tiles issue less, so their
+//     waits count down (8, 8, 6, 4 | 2, 0).
+// What bounds it (tools/block_gemm_bench.hip, BG_ABL builds, 4 x 1024 x 4096 x 4096, one block per CU): the full kernel
+// 103-113 us at 2.00 GHz, matrix pipe 63 % busy; without the LDS reads 102; without the DMA 97; with neither 91; with
+// neither and NO barriers 91-93 us at 2.16 GHz, pipe 67 % busy -- two waves per SIMD issuing nothing but MFMAs on random
+// operands reach 0.59-0.60 of the 2.5 PF figure: the chip holds its clock and its MFMA issue down under that load, and the
+// vendor BLAS runs the same shape at 0.59-0.63 on the same device (tools/block_gemm_vs_library.py).  The schedule's own
+// losses are the 13-18 % between "no reads, no DMA" and the full kernel.
 // Edges: rows past the batch / feature count are clamped in the source address (computed, never stored); K % 64 != 0:
 // the lanes whose chunk lies past K get an out-of-range buffer offset and the hardware writes zeros (K % 8 == 0 is
 // required, so a chunk is in or out as a whole).
@@ -58,10 +67,10 @@ struct BlockGemmK {
 };
 
 #ifndef BG_PHASES
-#define BG_PHASES 4
+#define BG_PHASES 2   // 2: two 32-MFMA segments per K-tile (measured faster: 104.5 vs 109.2 us at 4 x 1024 x 4096 x 4096); 4: four 16-MFMA segments
 #endif
 #ifndef BG_ABL
-#define BG_ABL 0   // development ablations (tools/block_gemm_bench.hip only): 1 = no LDS reads, 2 = no LDS-DMA after the prologue
+#define BG_ABL 0   // development ablations (tools/block_gemm_bench.hip only): 1 = no LDS reads, 2 = no LDS-DMA after the prologue, 4 = no barriers
 #endif
 constexpr int kBgThreads = 512;
 constexpr int kBgLds = 128 * 1024;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
 #define BG_BAR()                                \
   do {                                          \
     __builtin_amdgcn_sched_barrier(0);          \
-    __builtin_amdgcn_s_barrier();               \
+    if (!(BG_ABL & 4)) __builtin_amdgcn_s_barrier(); \
     __builtin_amdgcn_sched_barrier(0);          \
   } while (0)
 #define BG_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
