@@ -6,14 +6,16 @@ Workload (BASELINE.json configs[1], SURVEY ยง8(d) "C2"): the 784-1200-1200-10 BB
 rho~U(-5,-4), x~U(0,1), labels~U{0..9}; numpy RandomState seeds 1234/5678+m), Gaussian prior sigma_p=1, on-chip
 Philox epsilon.
 
-One STEP = one forward-only ELBO evaluation of ONE minibatch: the full 3-layer forward with freshly sampled weights,
-the sampled log p(w) / log q(w) reductions over all 2 395 210 stochastic parameters and the NLL (reference
-networks.py:199-203), `--samples` MC samples per GPU.  The steps are a stream of INDEPENDENT minibatches (what
-class_task.py:89-103 walks one at a time): `--group` of them are resident in HBM and go through one launch per layer
-together (`BayesianNetwork.elbo_many`, the product API), every (minibatch, MC sample) pair with its own Philox
-subsequence; K steps are K // group replays of that hipGraph plus one smaller launch for the remainder, so any K is
-timed exactly.  `single_evaluation_in_flight` in the output is the other regime: one minibatch at a time, each
-evaluation waiting for the previous one (the training loop's dependency, class_task.py:73-79).
+One STEP = one LAUNCH GROUP: `--group` (256) independent minibatches resident in HBM, each evaluated forward-only --
+the full 3-layer forward with freshly sampled weights, the sampled log p(w) / log q(w) reductions over all 2 395 210
+stochastic parameters and the NLL (reference networks.py:199-203), `--samples` MC samples per GPU -- through ONE launch
+per layer together (`BayesianNetwork.elbo_many`, the product API; one hipGraph replay), every (minibatch, MC sample)
+pair with its own Philox subsequence.  The minibatches are a stream of INDEPENDENT evaluations sharing the parameters
+(what class_task.py:89-103 walks one at a time).  `--steps K --warmup W` = K timed + W untimed replays, so the driver's
+`--steps 20` times 20 launch groups (5120 minibatch evaluations, milliseconds), not one.  `value` counts MC forward
+samples: group x samples x GPUs per step.  `single_evaluation_in_flight` in the output is the other regime: one
+minibatch at a time, each evaluation waiting for the previous one (the training loop's dependency,
+class_task.py:73-79).
 
 Multi-GPU (`--gpus N`, one process per GPU; started by the driver through torch.distributed.run, or by this script
 itself when WORLD_SIZE is unset): weak scaling.  Every minibatch is evaluated with N x `--samples` MC samples, rank r
@@ -23,8 +25,10 @@ scalars per launch group.  `c4` in the output is BASELINE configs[3] as SURVEY ย
 512) MC samples split over the ranks, one all-reduce of the 4-vector PER EVALUATION.
 
 Prints ONE JSON line (rank 0).  value = total MC samples / s over all ranks; `roofline` is the dominant kernel (layer
-2, 1200x1200 weights) against the HBM roof with SURVEY ยง8(d)'s algorithmic bytes; `cpu_baseline` is the parity-pinned
-CPU oracle timed on this host; `extras` are the other BASELINE configs on one GPU.
+2, 1200x1200 weights) against the roof that binds it -- vector issue for K1b, whose on-chip generator costs ~80 VALU
+instructions per 8 weights (counters: VALU 79 % busy, MFMA 9 %), with SURVEY ยง8(d)'s HBM figure in algorithmic bytes
+beside it (`hbm_algorithmic`) and the fabric traffic counters measured (`traffic`); `cpu_baseline` is the parity-pinned
+CPU oracle timed on this host (fastest thread count, all cores, one thread); `extras` are the other BASELINE configs.
 """
 import argparse
 import hashlib
@@ -47,8 +51,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; ONE STEP = one launch group = `--group` independent minibatches")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (launch groups)")
     ap.add_argument("--samples", type=int, default=1, help="MC samples per GPU per minibatch evaluation")
     ap.add_argument("--group", type=int, default=256,
                     help="independent minibatches resident in HBM that share one launch per layer (1 = one minibatch "
@@ -105,15 +109,22 @@ def n_stochastic(dims):
     return sum(i * o + o for i, o in ((dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])))
 
 
-def source_hash() -> str:
-    """Hash of the kernel sources: profiles/traffic.json entries carry the hash they were measured at, and a stale
-    entry is reported as null instead of being attached to a kernel that has changed since."""
+# the source files a kernel family is built from: entries of profiles/traffic.json, pmc.json and isa_mix.json carry the
+# hash of their family's files and are ignored (reported as null) once those have changed
+KERNEL_SOURCES = {
+    "bbb": ("bbb_linear.hip", "bnn_device.h", "bbb_sample_body.h", "bnn_fin.h"),
+    "lr": ("lr_linear.hip", "bnn_device.h", "bnn_fin.h"),
+    "block_gemm": ("bbb_block_gemm.h", "bnn_device.h"),
+}
+
+
+def source_hash(files=None) -> str:
+    """Hash of kernel sources (all of csrc/ by default, or the named files of one kernel family)."""
     h = hashlib.sha256()
     d = os.path.join(REPO, "bayesian-neural-network_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(files if files is not None else [f for f in os.listdir(d) if f.endswith((".hip", ".h"))]):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -278,13 +289,60 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     kname = {("bbb", "tile"): "K1a bbb_fwd_kernel", ("bbb", "gemm"): "K1b bbb_fwd_gemm_kernel",
              ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
              ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel"}[("lr" if lr else "bbb", form)]
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_key": f"{'lr' if lr else 'bbb'}_{dims[1]}_n{n}_b{batch}_{math_name}",
             "kernel": f"{kname}, layer 2 ({dims[1]}x{dims[1]})", "plan": plan,
             "algorithmic_bytes_per_launch": abytes, "mc_samples_per_launch": n, "avg_launch_us": us,
             "mfma_tflops": flops / (us * 1e-6) / 1e12, "mfma_frac_of_bf16_peak": flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "note": "HIP events around back-to-back graph launches of this kernel alone on its stream (incl. the "
                     "dependent-launch boundary); " + note}
+    if not lr and form in ("gemm", "gemm_kslice") and math_name == "bf16":
+        roof = valu_bound(roof, dims[1], dims[1], n, batch, us, ev.wsigma[1] is not None)
+    return roof
+
+
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+
+
+def valu_bound(roof, fin, fout, n, batch, us, sig):
+    """K1b is bound by vector issue, not by memory (profiles/pmc.json: VALU busy 0.79, MFMA 0.09): the on-chip generator
+    costs ~80 VALU wave-instructions per 8 sampled weights.  Price the launch against the VECTOR-ISSUE roof from the
+    kernel's own instruction mix (profiles/isa_mix.json, tools/make_isa_mix.py): issue cycles of one k-step of one wave
+    x the wave-steps of the launch, against 1024 SIMDs x 2.4 GHz; the SURVEY 8(d) HBM figure stays beside it."""
+    key = f"bbb_fwd_gemm_kernel<4,{'true' if sig else 'false'}>"
+    hbm = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
+    hbm["note"] = "SURVEY 8(d) algorithmic bytes (un-amortised: 8 B/param per (minibatch, sample) pair) over the launch time: an accounting " \
+                  "convention, not the binding resource -- the pairs of a launch share (mu, sigma) through L2 (see traffic)"
+    try:
+        e = json.load(open(os.path.join(REPO, "profiles", "isa_mix.json")))[key]
+        fresh = e["source_hash"] == source_hash(KERNEL_SOURCES["bbb"])
+    except Exception:
+        e, fresh = None, False
+    roof["hbm_algorithmic"] = hbm
+    if e is None or not fresh:
+        roof["bound"] = "valu"
+        roof.update({"achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": None,
+                     "valu_note": "profiles/isa_mix.json has no entry for the current kernel sources (run tools/make_isa_mix.py)"})
+        return roof
+    wave_steps = ((fout + 15) // 16) * n * ((batch + 127) // 128) * ((fin + 31) // 32)
+    cycles = wave_steps * e["valu_issue_cycles_per_iteration"]          # SIMD issue cycles of the launch's vector instructions
+    lane_ops = cycles * 32.0
+    achieved = lane_ops / (us * 1e-6) / 1e12
+    roof.update({"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": achieved / VALU_PEAK_TLANEOPS,
+                 "valu": {"issue_cycles_per_kstep_per_wave": e["valu_issue_cycles_per_iteration"], "classes": e["classes"],
+                          "cycle_costs": e["cycle_costs"], "wave_ksteps_per_launch": wave_steps,
+                          "floor_us_at_2p4GHz": cycles / (1024 * 2.4e9) * 1e6,
+                          "source": "profiles/isa_mix.json (static instruction mix of the k-step loop, tools/make_isa_mix.py; issue costs from "
+                                    "tools/ubench.hip); frac = that issue time at 1024 SIMDs x 2.4 GHz over the measured launch time"}})
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))
+        for k, v in pm.items():
+            if "bbb_fwd_gemm_kernel" in k and k.startswith("bbb_g256") and "valu_busy" in v:
+                roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
+                                       "key": k, "source": "profiles/pmc.json (rocprofv3 --pmc, tools/collect_pmc.py)"}
+    except Exception:
+        pass
+    return roof
 
 
 def attach_traffic(roof):
@@ -298,7 +356,8 @@ def attach_traffic(roof):
         t = json.load(open(tj))
         e = t.get(key)
         if e is not None:
-            if e.get("source_hash") == source_hash():
+            fam = "lr" if key.startswith("lr") else "bbb"
+            if e.get("source_hash") == source_hash(KERNEL_SOURCES[fam]):
                 roof["traffic"] = e["hbm_bytes_per_launch"]
                 roof["traffic_source"] = e.get("source", "profiles/traffic.json")
             else:
@@ -317,41 +376,53 @@ def cpu_baseline(dims, lr, batch, budget_s=15.0):
     from oracle import bnn_oracle as O
     from bnn_hip import synth
     ncpu = os.cpu_count() or 1
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))       # the cores this process may run on
+    except Exception:
+        pass
     sd = synth.synth_state_dict(dims[0], dims[1], dims[2], lr)
     p = O.NetParams.from_state_dict(sd, "classification", dims[0], lr, O.Prior.from_init([1.0], False))
     x, y = synth.synth_batch("classification", batch, dims[0], dims[2])
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     fn = O.sample_elbo_lr if lr else O.sample_elbo
+    def rate(nthr, seconds, max_calls):
+        """median seconds per sample_elbo(S=1) call at `nthr` intra-op threads (after one warm-up call; a thread count
+        whose warm-up call alone takes > 1.5 s -- hundreds of threads on ~25 small elementwise ops per tensor -- is
+        reported from that single call instead of being given more of the budget)"""
+        torch.set_num_threads(nthr)
+        t0 = time.perf_counter()
+        fn(p, xt, yt, 0.5, 1)
+        first = time.perf_counter() - t0
+        if first > 1.5:
+            return first, 1, first
+        ts, t_end = [], time.perf_counter() + seconds
+        while (time.perf_counter() < t_end or len(ts) < 3) and len(ts) < max_calls:
+            t0 = time.perf_counter()
+            fn(p, xt, yt, 0.5, 1)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), len(ts), float(sum(ts))
+
     with torch.no_grad():
-        # pick the intra-op thread count that is fastest for these op sizes on this host (all cores
-        # is far from it on a many-core box: ~25 tiny elementwise ops per tensor), then time that.
-        best_t, best = 1, float("inf")
-        for nthr in [t for t in (1, 4, 8, 16, 32) if t <= ncpu]:
-            torch.set_num_threads(nthr)
-            fn(p, xt, yt, 0.5, 1)
-            t0 = time.perf_counter()
-            fn(p, xt, yt, 0.5, 1)
-            fn(p, xt, yt, 0.5, 1)
-            d = (time.perf_counter() - t0) / 2
-            if d < best:
-                best_t, best = nthr, d
-        torch.set_num_threads(best_t)
-        times = []
-        t_end = time.perf_counter() + budget_s
-        while time.perf_counter() < t_end and len(times) < 400:
-            t0 = time.perf_counter()
-            fn(p, xt, yt, 0.5, 1)
-            times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+        # SURVEY 8(d): the all-cores figure AND the one-thread figure; plus the thread count that is fastest for these op
+        # sizes on this host (all cores is far from it on a many-core box: ~25 small elementwise ops per tensor) -- every
+        # candidate gets the same 1.2 s probe (median of >= 3 calls), the fastest then gets the rest of the budget
+        cands = sorted({t for t in (1, 4, 8, 16, 32, ncpu) if 1 <= t <= ncpu})
+        probe = {t: rate(t, 1.2, 60) for t in cands}
+        best_t = min(probe, key=lambda t: probe[t][0])
+        spent = sum(v[2] for v in probe.values())
+        med, calls, secs = rate(best_t, max(3.0, budget_s - spent), 400)
     model = ""
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": 1.0 / med, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} sample_elbo(S=1) calls of the CPU oracle (fp32, no_grad, incl. eps draw) in "
-                      f"{sum(times):.1f} s, median {med*1e3:.2f} ms, with the fastest of 1/4/8/16/32 intra-op threads "
-                      f"(= `cores`); os.cpu_count()={ncpu}; {model}",
+    return {"value": 1.0 / med, "unit": "MC-samples/s", "cores": best_t, "kind": "port",
+            "sample": f"{calls} sample_elbo(S=1) calls of the CPU oracle (fp32, no_grad, incl. eps draw) in {secs:.1f} s, median "
+                      f"{med*1e3:.2f} ms, at the fastest intra-op thread count of {cands} (= `cores`, 1.2 s probe each); "
+                      f"usable cores (affinity) = {ncpu}, os.cpu_count() = {os.cpu_count()}; {model}",
+            "all_cores": {"threads": ncpu, "value": 1.0 / probe[ncpu][0], "median_ms": probe[ncpu][0] * 1e3, "calls": probe[ncpu][1]},
+            "one_thread": {"threads": 1, "value": 1.0 / probe[1][0], "median_ms": probe[1][0] * 1e3, "calls": probe[1][1]},
+            "by_threads": {str(t): 1.0 / v[0] for t, v in probe.items()},
             "kl_elements_per_s": p.n_stochastic() / med}
 
 
@@ -426,7 +497,8 @@ def main():
         bnn_hip.shard_samples(True)
 
     dims, lr = DIMS[args.net], args.variant == "lr"
-    G, full, rem, warm = plan_groups(args.steps, args.warmup, args.group)
+    # ONE STEP = one launch group: `--group` independent minibatches through one launch per layer (one hipGraph replay)
+    G, full, rem, warm = max(1, args.group), args.steps, 0, args.warmup
     # the wide stack has no task attached in BASELINE: Gaussian NLL over its 4096 outputs
     mode = "regression" if args.net == "wide" else "classification"
     net, x, y = build_net(dims, lr, args.batch, dev, mode, n_minibatches=G)
@@ -443,7 +515,7 @@ def main():
     if dist is not None and run_groups.last_reduced is not None and full > 0:
         got = run_groups.last_reduced[(full + warm - 1) & 1][..., 3]         # every all-reduced row: the GLOBAL sample count
         assert bool((got == float(S_global)).all()), f"all-reduced sample counts {got.flatten().tolist()} != {S_global}"
-    value = S_global * args.steps / dt
+    value = S_global * G * args.steps / dt
     nst = n_stochastic(dims)
     layers = "-".join(map(str, (dims[0], dims[1], dims[1], dims[2])))
 
@@ -451,14 +523,16 @@ def main():
         "metric": "MC-forward-samples/sec + KL-elements/sec, 784-1200-1200-10 BNN" if args.net == "mnist"
         else f"MC-forward-samples/sec + KL-elements/sec, {layers} BNN",
         "value": value, "unit": "MC-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "warmup_executed": warm * G,
-        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt * 1e3 / args.steps, "us_per_minibatch": dt * 1e6 / (args.steps * G), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
         **({"rehearsal": "all ranks on cuda:0 over gloo; NOT a measurement"} if rehearsal else {}),
         "config": {"workload": f"{layers} {'LR' if lr else 'BBB'} forward-only ELBO evaluation of a stream of independent "
                                f"minibatches (3-layer forward with freshly sampled weights + log p/log q reductions over "
                                f"{nst} stochastic params + NLL per MC sample), batch {args.batch}, {S_local} MC sample(s) "
-                               f"per GPU per minibatch, {G} minibatches per launch group, Gaussian prior, on-chip Philox eps",
+                               f"per GPU per minibatch, Gaussian prior, on-chip Philox eps; ONE STEP = one launch group = {G} "
+                               f"minibatches resident in HBM through one launch per layer (one hipGraph replay): "
+                               f"{G * S_global} MC forward samples per step",
+                   "minibatches_per_step": G, "mc_samples_per_step_all_gpus": G * S_global,
                    "batch": args.batch, "mc_samples_per_gpu_per_step": S_local, "mc_samples_per_step": S_global,
                    "stochastic_params": nst, "hipgraph": not args.no_graph, "minibatches_per_launch_group": G,
                    "launches_timed": full + (1 if rem else 0),
