@@ -258,6 +258,50 @@ def network_forward(p: NetParams, x: torch.Tensor, eps: Optional[Sequence[torch.
     return (x, a, None) if p.local_reparam else (x, a, b)
 
 
+# --------------------------------------------------------------------------------------
+# The SAME network with the rounding points of the device's bf16 math mode (include/bnn_hip.h, BNN_MATH_BF16).
+# NOT a reference function: the reference computes in fp32 throughout (network_forward above is its restatement).  This
+# variant exists so that the bf16 kernels can be pinned TIGHTLY (accumulation order is then the only difference, ~1e-6),
+# independently of how large the bf16-vs-fp32 deviation itself is; that deviation is a property of the precision choice
+# and is measured on this CPU pair (network_forward vs network_forward_bf16), see tests/test_oracle_golden.py.
+# Rounding points (all round-to-nearest-even to bf16, everything else fp32):
+#   BBB: the matmul operands -- bf16(x) (the input batch and every hidden activation AFTER ReLU) and bf16(w) with
+#        w = mu + softplus(rho) * eps in fp32; products exact, fp32 accumulation, the fp32 bias sample added in fp32;
+#        log p / log q from the UN-rounded fp32 w.
+#   LR:  bf16(x) . bf16(M) and x2 . bf16(sigma^2) with x2 = bf16(x * x) formed from the fp32 x (`sq_carried`: the input
+#        cast and the producing layer's epilogue write it, evaluations of >= 8 pairs) or bf16(bf16(x)^2) (the consuming
+#        kernel squares the fragment it loaded, fewer pairs); sqrt, activation noise, bias and the KL in fp32.
+# --------------------------------------------------------------------------------------
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def network_forward_bf16(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tensor], sq_carried: bool = True):
+    """(logits, log_prior | kl, log_q | None) like network_forward, with the device's bf16 rounding points."""
+    if p.mode == "classification":
+        x = x.view(-1, p.input_shape)
+    a, b = 0, 0
+    for i, (wm, wr, bm, br) in enumerate(p.layers):
+        ew, eb = eps[2 * i], eps[2 * i + 1]
+        if p.local_reparam:
+            w_sigma, b_sigma = softplus_naive(wr), softplus_naive(br)
+            xr = _bf16(x)
+            x2 = _bf16(x * x) if sq_carried else _bf16(xr * xr)
+            act_mu = torch.mm(xr, _bf16(wm))
+            act_sigma = torch.sqrt(torch.mm(x2, _bf16(w_sigma * w_sigma)))
+            x = act_mu + act_sigma * ew + (bm + b_sigma * eb).unsqueeze(0)
+            a = a + (kl_closed_form(wm, w_sigma, 0.0, p.prior.sigma_p) + kl_closed_form(bm, b_sigma, 0.0, p.prior.sigma_p))
+        else:
+            w = sample_gaussian(wm, wr, ew)
+            bb = sample_gaussian(bm, br, eb)
+            a = a + (p.prior.log_prob(w).sum() + p.prior.log_prob(bb).sum())
+            b = b + (log_q(w, wm, wr).sum() + log_q(bb, bm, br).sum())
+            x = torch.nn.functional.linear(_bf16(x), _bf16(w), bb)
+        if i < 2:
+            x = torch.relu(x)
+    return (x, a, None) if p.local_reparam else (x, a, b)
+
+
 def sample_elbo(p: NetParams, x: torch.Tensor, target: torch.Tensor, beta: float, samples: int,
                 sigma: float = 1.0, eps: Optional[Sequence[Sequence[torch.Tensor]]] = None,
                 gen: Optional[torch.Generator] = None):

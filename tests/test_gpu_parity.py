@@ -17,13 +17,16 @@ from bnn_hip import ops, synth
 from oracle import bnn_oracle as O
 
 F32_RTOL = 2e-5
-# bf16-operand error of the C2 network, MEASURED on MI355X by test_timed_path_against_oracle_on_philox_eps (printed with
-# -s; round 2, 16 configurations): the NLL of one (minibatch, MC sample) pair moves by 1.4e-4 .. 1.9e-3 relative to the
-# fp32 oracle, the logits by 4.3e-3 .. 6.0e-3 of their scale.  That is ~30x what SURVEY 7.3 priced for bf16 MFMA
-# OPERANDS alone (5.5e-5): this path also ROUNDS the two hidden activations to bf16 between layers (2-byte activation
-# traffic), and the summed cross-entropy of 128 rows amplifies logit noise.  Tolerances = 3x the largest error seen.
+# bf16 math mode against the FP32 oracle (= the reference's arithmetic): the deviation is a property of rounding the
+# matmul OPERANDS (inputs, hidden activations, sampled weights) to bf16, not of the kernels -- the oracle's own CPU
+# restatement with the same rounding points (O.network_forward_bf16) moves the NLL of one (minibatch, MC sample) pair of
+# the C2 network by 3e-5 .. 2.2e-3 relative to O.network_forward (tests/test_oracle_golden.py::
+# test_bf16_rounding_points_deviation_on_cpu; SURVEY 7.3's 5.5e-5 was a single draw at the low end) and the logits by
+# ~5e-3 of their scale.  These two bounds hold that precision choice; the KERNELS are pinned separately and tightly
+# against the rounding-point oracle (BF16_POINTS_* below, 1e-4).
 BF16_NLL_RTOL = 5.5e-3
 BF16_LOGIT_TOL = 1.8e-2
+BF16_NLL_RTOL_GOLDEN = 2e-3      # the bound the golden C2 vectors (one fixed epsilon draw) have been held to since round 1
 
 
 @pytest.fixture(scope="module")
@@ -321,7 +324,7 @@ def test_c2_mnist_shape_elbo(g_c2, dev, variant, math_mode):
         nll0 = net.get_nll(logits, yd)
     scale = float(c1["logits_s0_absmax"])
     close(logits[:2], c1["logits_s0_rows01"], rtol=0, atol=(2e-5 if f32 else 3e-2) * scale)
-    close(nll0, c1["nll_s0"], rtol=2e-5 if f32 else BF16_NLL_RTOL)
+    close(nll0, c1["nll_s0"], rtol=2e-5 if f32 else BF16_NLL_RTOL_GOLDEN)
     for li, l in enumerate((net.l1, net.l2, net.l3)):
         if lr:
             close(l.kl_cost, c1[f"l{li+1}/kl"])
@@ -333,7 +336,7 @@ def test_c2_mnist_shape_elbo(g_c2, dev, variant, math_mode):
         install_eps(net, 128, S, lr)
         with torch.no_grad():
             tup = (net.sample_elbo_lr if lr else net.sample_elbo)(xd, yd, 0.5, S)
-        nll_tol = 2e-5 if f32 else BF16_NLL_RTOL
+        nll_tol = 2e-5 if f32 else BF16_NLL_RTOL_GOLDEN
         tols = [1e-4, F32_RTOL, nll_tol] if lr else [1e-4, F32_RTOL, F32_RTOL, nll_tol]   # ELBO: rtol 1e-4 (north star)
         for i, v in enumerate(tup):
             close(v, c[f"t{i}"], rtol=tols[i])
@@ -839,31 +842,72 @@ def test_split_sampling_then_matmul_equals_the_fused_layer(dev, prior, shape):
     close(sls, float(fls), rtol=2e-5)
 
 
-def _oracle_pairs(p, xs, ys, seed, base, S):
-    """Oracle scalars of every (minibatch m, MC sample j) pair on the eps the device generator draws for global
-    sample index base + m * S + j: rows of (log p | KL, log q | 0, nll), plus the logits."""
-    rows, logits = [], []
+def _oracle_pairs(p, xs, ys, seed, base, S, pairs=None, bf16=False, sq_carried=True):
+    """Oracle scalars of (minibatch m, MC sample j) pairs on the eps the device generator draws for global sample index
+    base + m * S + j: rows of (log p | KL, log q | 0, nll), plus the logits.  `pairs`: flat indices m * S + j (default
+    all).  `bf16`: additionally the same rows with the device's bf16 rounding points (O.network_forward_bf16), on the
+    same epsilon: returns (rows, logits, rows16, logits16)."""
+    rows, logits, rows16, logits16 = [], [], [], []
     torch.set_num_threads(8)
-    for m in range(len(xs)):
-        for j in range(S):
-            eps = O.philox_eps_for_network(p, xs[m].shape[0], seed, base + m * S + j)
-            out, a, b = O.network_forward(p, t(xs[m]), eps)
-            rows.append([float(a), float(b) if b is not None else 0.0, float(O.nll(out, t(ys[m]), p.mode))])
-            logits.append(out.numpy())
+    for f in (range(len(xs) * S) if pairs is None else pairs):
+        m, j = divmod(int(f), S)
+        eps = O.philox_eps_for_network(p, xs[m].shape[0], seed, base + m * S + j)
+        out, a, b = O.network_forward(p, t(xs[m]), eps)
+        rows.append([float(a), float(b) if b is not None else 0.0, float(O.nll(out, t(ys[m]), p.mode))])
+        logits.append(out.numpy())
+        if bf16:
+            out, a, b = O.network_forward_bf16(p, t(xs[m]), eps, sq_carried=sq_carried)
+            rows16.append([float(a), float(b) if b is not None else 0.0, float(O.nll(out, t(ys[m]), p.mode))])
+            logits16.append(out.numpy())
     torch.set_num_threads(1)
+    if bf16:
+        return np.asarray(rows, np.float64), np.stack(logits), np.asarray(rows16, np.float64), np.stack(logits16)
     return np.asarray(rows, np.float64), np.stack(logits)
 
 
+# beta of the reference's schedule (class_task.py:70: beta halves every minibatch, 0.5 at idx 0, exactly 0 in fp32 from idx 149
+# of 468): the first minibatch, one where the complexity term (~7.4e6 * beta) is of the NLL's size, and the tail
+BETAS = (0.5, 2.0 ** -10, 0.0)
+# Pinned tolerance of the bf16 path against the oracle WITH the device's rounding points (O.network_forward_bf16): only
+# fp32 accumulation order (and the rare operand that rounds the other way after an fma / softplus ulp) differs.  This is
+# the regression guard of the bf16 kernels: set from the arithmetic, not from a measurement of the kernels.
+BF16_POINTS_NLL_RTOL = 1e-4
+# logits: a hidden activation whose fp32 sum lands within ~1e-6 of a bf16 rounding boundary rounds the other way on the
+# device (different summation order): ~1e-3 of the 128 x 1200 activations of a layer, each a 2^-8 relative step that fans
+# out through the next layer's 1200 weights -- a few 1e-4 of the logit scale on the rows it hits, invisible in the NLL
+BF16_POINTS_LOGIT_TOL = 2e-3          # of the logit scale
 
 
-@pytest.mark.parametrize("G,S", [(1, 1), (1, 8), (4, 2), (16, 1)])
+def _elbo(rows, S, beta, lr):
+    """networks.py:205-208 / :222-224 from per-evaluation sums [.., (sum log p | KL, sum log q, sum nll)]"""
+    b32 = float(np.float32(beta))                      # the reference multiplies fp32 tensors by beta
+    if lr:
+        return b32 * rows[..., 0] / S + rows[..., 2] / S
+    return b32 * rows[..., 1] / S - b32 * rows[..., 0] / S + rows[..., 2] / S
+
+
+# (G, S, pairs checked against the oracle): the driver's old 20-minibatch group (K-sliced form), the default 256-minibatch
+# launch group (block-GEMM form: a strided subset of its pairs, ~2 s of oracle each), 64 MC samples of one minibatch
+TIMED_SHAPES = [(1, 1, None), (1, 8, None), (4, 2, None), (20, 1, None),
+                (256, 1, (0, 1, 17, 63, 64, 127, 128, 200, 254, 255)), (1, 64, (0, 1, 7, 8, 31, 32, 62, 63))]
+
+
+@pytest.mark.parametrize("G,S,pairs", TIMED_SHAPES)
 @pytest.mark.parametrize("variant", ["bbb", "lr"])
-def test_timed_path_against_oracle_on_philox_eps(dev, variant, G, S):
+def test_timed_path_against_oracle_on_philox_eps(dev, variant, G, S, pairs):
     """The path bench.py times -- engine.GraphedElbo, captured hipGraph, bf16 math, on-chip Philox, several
-    evaluations per replay, G stacked minibatches x S MC samples per launch group -- directly against the oracle
-    on the same epsilon (oracle.philox_eps_for_network for the matching global sample indices): every
-    (minibatch, sample) pair's log p / log q / KL (fp32 statistics: rtol 1e-5), its NLL and logits (bf16), and
-    every minibatch's ELBO at beta = 0.5 to the north star's rtol 1e-4."""
+    evaluations per replay, G stacked minibatches x S MC samples per launch group, at the shapes that are timed --
+    directly against the oracle on the same epsilon (oracle.philox_eps_for_network for the matching global sample
+    indices), per (minibatch, sample) pair:
+      * log p / log q / KL (fp32 statistics of un-rounded weights): rtol 1e-5 against the fp32 oracle;
+      * NLL and logits against the oracle with the device's bf16 rounding points: rtol 1e-4 / 2e-3 of scale (pinned from
+        the arithmetic: accumulation order and the boundary flips it causes), and with it the ELBO at EVERY beta of the schedule, beta = 0 (pure
+        NLL) included, to the north star's rtol 1e-4;
+      * against the fp32 oracle (= the reference's arithmetic): the bf16 operand rounding moves the NLL by up to
+        BF16_NLL_RTOL, so the ELBO agrees to rtol 1e-4 while beta * complexity >> NLL (beta = 0.5: the first minibatches
+        of an epoch) and to BF16_NLL_RTOL * NLL / (beta * complexity + NLL) in general -- the stated tolerance of the
+        bf16 mode as a function of beta; the exact-fp32 math mode meets 1e-4 at every beta
+        (test_c2_mnist_shape_elbo, test_elbo_over_the_beta_schedule_fp32_math)."""
     from bnn_hip import engine
     lr = variant == "lr"
     B, dims, seed, first, E = 128, (784, 1200, 10), 424242, 7000, 2
@@ -880,25 +924,73 @@ def test_timed_path_against_oracle_on_philox_eps(dev, variant, G, S):
     total = G * S
     assert int(ev.counter.item()) == first + total * (1 + E)       # warm-up + E evaluations
     base = first + total * E                                        # the LAST evaluation of the replay
-    want, want_logits = _oracle_pairs(p, xs, ys, seed, base, S)
+    idx = np.arange(total) if pairs is None else np.asarray(pairs)
+    want, want_logits, w16, w16_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx, bf16=True,
+                                                       sq_carried=(total >= engine.LR_SQUARES_MIN_SAMPLES))
+    if lr and engine.LR_SQUARES_MIN_SAMPLES <= total < engine.LR_PREPARE_MIN_SAMPLES:
+        # 8 .. 23 pairs: the evaluator carries bf16(x^2) between layers, but the tile form of a layer (K3a) squares the
+        # bf16 fragment it loaded and ignores the carried squares, the row-split output layer reads them: a mixture of the
+        # two documented roundings of x^2, decided by the launch plans.  Both pure variants are computed (they differ by
+        # < 1e-4 in the NLL) and the launch is held to the nearer one.
+        _, _, w16b, w16b_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx, bf16=True, sq_carried=False)
+        got_ = ev.out["nll"].double().cpu().numpy()[idx]
+        nearer = np.abs(got_ - w16b[:, 2]) < np.abs(got_ - w16[:, 2])
+        w16 = np.where(nearer[:, None], w16b, w16)
+        w16_logits = np.where(nearer[:, None, None], w16b_logits, w16_logits)
     keys = ("kl",) if lr else ("log_prior", "log_q")
     for c, k in enumerate(keys):
-        close(ev.out[k], want[:, c], rtol=1e-5)
-    got_nll = ev.out["nll"].double().cpu().numpy()
+        close(ev.out[k].double().cpu().numpy()[idx], want[:, c], rtol=1e-5)
+        close(w16[:, c], want[:, c], rtol=1e-6)                    # the statistics never see a rounded operand
+    got_nll = ev.out["nll"].double().cpu().numpy()[idx]
+    lg = ev.logits.double().cpu().numpy().reshape(total, B, dims[2])[idx]
+    # (i) pinned: against the oracle with the device's rounding points
+    nll16_err = np.abs(got_nll - w16[:, 2]) / np.abs(w16[:, 2])
+    lg16_err = np.abs(lg - w16_logits).max() / np.abs(w16_logits).max()
+    # (ii) the precision choice itself: against the fp32 oracle
     nll_err = np.abs(got_nll - want[:, 2]) / np.abs(want[:, 2])
-    lg = ev.logits.double().cpu().numpy()
     lg_err = np.abs(lg - want_logits).max() / np.abs(want_logits).max()
-    print(f"\n[bf16 error at C2] {variant} G={G} S={S}: nll rel err max {nll_err.max():.2e}, logits {lg_err:.2e} of scale")
+    print(f"\n[bf16 at C2] {variant} G={G} S={S}: vs rounding-point oracle nll {nll16_err.max():.2e} logits {lg16_err:.2e}; "
+          f"vs fp32 oracle nll {nll_err.max():.2e} logits {lg_err:.2e} of scale")
+    assert nll16_err.max() <= BF16_POINTS_NLL_RTOL and lg16_err <= BF16_POINTS_LOGIT_TOL
     assert nll_err.max() <= BF16_NLL_RTOL and lg_err <= BF16_LOGIT_TOL
-    w = want.reshape(G, S, 3).sum(1)
-    close(sums[:, 0], w[:, 0], rtol=1e-5)
-    if not lr:
-        close(sums[:, 1], w[:, 1], rtol=1e-5)
-    close(sums[:, 2], w[:, 2], rtol=BF16_NLL_RTOL)
     assert (sums[:, 3] == S).all()
-    beta = 0.5
-    elbo = lambda v: (beta * v[:, 0] / S + v[:, 2] / S) if lr else (beta * v[:, 1] / S - beta * v[:, 0] / S + v[:, 2] / S)
-    close(elbo(sums), elbo(w), rtol=1e-4)                           # networks.py:205-208 / :222-224
+    # per-evaluation sums and the ELBO over the beta schedule (evaluations all of whose pairs were checked)
+    full_eval = [m for m in range(G) if all((m * S + j) in set(idx.tolist()) for j in range(S))]
+    pos = {int(f): i for i, f in enumerate(idx.tolist())}
+    for m in full_eval:
+        sel = [pos[m * S + j] for j in range(S)]
+        e32, e16 = want[sel].sum(0), w16[sel].sum(0)
+        close(sums[m, 0], e32[0], rtol=1e-5)
+        if not lr:
+            close(sums[m, 1], e32[1], rtol=1e-5)
+        close(sums[m, 2], e16[2], rtol=BF16_POINTS_NLL_RTOL)
+        for beta in BETAS:
+            got = _elbo(sums[m, :3], S, beta, lr)
+            close(got, _elbo(e16, S, beta, lr), rtol=1e-4)          # every beta, beta = 0 included
+            ref = _elbo(e32, S, beta, lr)
+            cplx = abs(ref - e32[2] / S)                            # beta * complexity
+            close(got, ref, rtol=max(1e-4 if beta == 0.5 else 0.0, BF16_NLL_RTOL * (e32[2] / S) / (cplx + e32[2] / S)))
+
+
+@pytest.mark.parametrize("variant", ["bbb", "lr"])
+def test_elbo_over_the_beta_schedule_fp32_math(dev, variant):
+    """The exact-fp32 math mode (v_mfma_f32_16x16x4_f32) meets the north star's ELBO rtol 1e-4 at EVERY beta of the
+    reference's schedule (class_task.py:70), the pure-NLL tail (beta = 0) included: C2 network, 2 minibatches x 2 MC
+    samples, on-chip Philox, against the fp32 oracle on the same epsilon."""
+    from bnn_hip import engine
+    lr = variant == "lr"
+    G, S, B, dims, seed, first = 2, 2, 128, (784, 1200, 10), 515151, 300
+    bnn_hip.set_math("f32")
+    net, sd = build_net(dev, lr, dims, "classification")
+    p = O.NetParams.from_state_dict(sd, "classification", dims[0], lr, O.Prior.from_init([1.0], False))
+    xs, ys = zip(*[synth.synth_batch("classification", B, dims[0], dims[2], seed=300 + m) for m in range(G)])
+    bnn_hip.manual_seed(seed, counter=first)
+    got = net.elbo_many(torch.from_numpy(np.stack(xs)).to(dev), torch.from_numpy(np.stack(ys)).to(dev), S).double().cpu().numpy()
+    want, _ = _oracle_pairs(p, xs, ys, seed, first, S)
+    w = want.reshape(G, S, 3).sum(1)
+    close(got[:, 2], w[:, 2], rtol=2e-5)                            # NLL in fp32 math
+    for beta in BETAS:
+        close(_elbo(got[:, :3], S, beta, lr), _elbo(w, S, beta, lr), rtol=1e-4)
 
 
 @pytest.mark.parametrize("lr", [False, True])
