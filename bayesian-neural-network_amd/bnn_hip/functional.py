@@ -1,14 +1,14 @@
 """autograd bridges for the hot path.
 
-Forward = the HIP kernels (K1/K3/K4).  Backward = the closed-form gradients of
-SURVEY A.5, evaluated with device tensor ops on eps REGENERATED from the Philox counter
-map (nothing weight-sized is kept alive between forward and backward except in the
-identical-eps parity mode).  Hand-written backward kernels are the next scope row (F1);
-the formulas here are the ones they will implement and are pinned by golden G5 grads.
+Forward = the HIP kernels (K1/K3/K4).  Backward = the HIP backward kernels (F1: bnn_bbb_linear_bwd,
+bnn_lr_linear_bwd, bnn_nll_bwd) implementing the closed-form gradients of SURVEY A.5 on eps REGENERATED from the
+Philox counter map (nothing weight-sized is kept alive between forward and backward except in the identical-eps
+parity mode).  There is no other backward: activations that the kernels cannot take (anything but fp32 on the
+differentiable path) raise.  The same formulas evaluated with tensor ops live in tests/tensor_op_grads.py as the
+cross-check the GPU tests compare the kernels with (golden G5 / G6 pin both against the real reference's autograd).
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -35,13 +35,11 @@ class LayerCall:
     sample_counter: Optional[torch.Tensor] = None   # device int32[1] added to sample_offset at run time
 
 
-# F1 switch: True = HIP backward kernels (bnn_bbb_linear_bwd); False = the closed-form gradients
-# evaluated with device tensor ops (kept as the cross-check the GPU tests compare against).
-HIP_BACKWARD = os.environ.get("BNN_HIP_BACKWARD", "1") != "0"
-
-
-def _naive_softplus(rho):
-    return torch.log1p(torch.exp(rho))
+def _need_f32(name, *ts):
+    for t_ in ts:
+        if t_ is not None and t_.dtype != torch.float32:
+            raise ops.BnnHipError(f"{name}: the HIP backward kernels take fp32 activations (got {t_.dtype}); the differentiable "
+                                  f"path keeps hidden activations in fp32 -- cast the input batch to float32")
 
 
 class BBBLinearFn(torch.autograd.Function):
@@ -72,64 +70,16 @@ class BBBLinearFn(torch.autograd.Function):
         S = call.n_samples
         N, K = w_mu.shape
         dev = w_mu.device
-        if HIP_BACKWARD and x.dtype == torch.float32 and (y is None or y.dtype == torch.float32):
-            # F1: hand-written backward kernels, eps regenerated on chip
-            g_wmu, g_wrho, g_bmu, g_brho, gx = ops.bbb_linear_bwd(
-                x, gy.float(), y, w_mu, w_rho, b_mu, b_rho, n_samples=S, prior=call.prior, math_mode=call.math_mode,
-                relu=call.relu, eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
-                layer_id=call.layer_id, sample_offset=call.sample_offset, sample_counter=call.sample_counter,
-                g_log_prior=glp if call.want_stats else None, g_log_q=glq if call.want_stats else None,
-                want_gx=ctx.needs_input_grad[0])
-            if gx is not None and x.dim() == 2:
-                gx = gx.sum(0)
-            return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
-        if call.sample_counter is not None:
-            raise ops.BnnHipError("a device sample counter needs the HIP backward kernels (fp32 activations)")
-        if call.eps_mode == L.EPS_PHILOX:
-            eps_w = ops.philox_normal(call.seed, call.layer_id * 4 + 0, call.sample_offset, S, N, K, dev)
-            eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)
-        elif call.eps_mode == L.EPS_ZERO:
-            eps_w = torch.zeros((S, N, K), device=dev)
-            eps_b = torch.zeros((S, N), device=dev)
-        else:
-            eps_w, eps_b = eps_w.view(S, N, K), eps_b.view(S, N)
-        g = gy.float()
-        if call.relu:
-            g = g * (y > 0).to(g.dtype)
-        sig_w, sig_b = _naive_softplus(w_rho), _naive_softplus(b_rho)
-        W = w_mu + sig_w * eps_w                                   # [S,N,K]
-        bvec = b_mu + sig_b * eps_b                                # [S,N]
-        x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
-        gW = torch.matmul(g.transpose(1, 2), x3)                   # [S,N,K]
-        gb = g.sum(1)                                              # [S,N]
-        if call.want_stats and glp is not None:
-            pr = call.prior
-            if pr.mixture:
-                def dlogp(w):
-                    n1 = pr.pi * torch.exp(-w * w / (2 * pr.sigma1 ** 2)) / pr.sigma1
-                    n2 = (1 - pr.pi) * torch.exp(-w * w / (2 * pr.sigma2 ** 2)) / pr.sigma2
-                    return -w * (n1 / pr.sigma1 ** 2 + n2 / pr.sigma2 ** 2) / (n1 + n2)
-            else:
-                def dlogp(w):
-                    return -w / (pr.sigma_p ** 2)
-            gW = gW + glp.view(S, 1, 1) * dlogp(W)
-            gb = gb + glp.view(S, 1) * dlogp(bvec)
-        g_wmu = gW.sum(0)
-        g_wsig = (gW * eps_w).sum(0)
-        g_bmu = gb.sum(0)
-        g_bsig = (gb * eps_b).sum(0)
-        if call.want_stats and glq is not None:
-            c = glq.sum()
-            g_wsig = g_wsig - c / sig_w                            # d(log q)/d(sigma) = -1/sigma
-            g_bsig = g_bsig - c / sig_b
-        g_wrho = g_wsig * torch.sigmoid(w_rho)
-        g_brho = g_bsig * torch.sigmoid(b_rho)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.matmul(g, W)                                # [S,B,K]
-            if x.dim() == 2:
-                gx = gx.sum(0)
-            gx = gx.to(x.dtype)
+        _need_f32("BBBLinearFn.backward", x, y)
+        # F1: hand-written backward kernels, eps regenerated on chip
+        g_wmu, g_wrho, g_bmu, g_brho, gx = ops.bbb_linear_bwd(
+            x, gy.float(), y, w_mu, w_rho, b_mu, b_rho, n_samples=S, prior=call.prior, math_mode=call.math_mode,
+            relu=call.relu, eps_mode=call.eps_mode, eps_w=eps_w, eps_b=eps_b, seed=call.seed,
+            layer_id=call.layer_id, sample_offset=call.sample_offset, sample_counter=call.sample_counter,
+            g_log_prior=glp if call.want_stats else None, g_log_q=glq if call.want_stats else None,
+            want_gx=ctx.needs_input_grad[0])
+        if gx is not None and x.dim() == 2:
+            gx = gx.sum(0)
         return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
 
 
@@ -143,7 +93,7 @@ class LRLinearFn(torch.autograd.Function):
                                 y_dtype=call.y_dtype, eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b,
                                 seed=call.seed, layer_id=call.layer_id, sample_offset=call.sample_offset,
                                 sample_counter=call.sample_counter,
-                                want_kl=call.want_stats, want_scalars=call.want_stats, want_v=HIP_BACKWARD)
+                                want_kl=call.want_stats, want_scalars=call.want_stats, want_v=True)
         y = out["y"]
         ctx.call = call
         ctx.save_for_backward(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, y if call.relu else None, out["v"])
@@ -160,60 +110,16 @@ class LRLinearFn(torch.autograd.Function):
         S = call.n_samples
         K, N = w_mu.shape
         dev = w_mu.device
-        if v is not None and x.dtype == torch.float32 and (y is None or y.dtype == torch.float32):
-            # F1: hand-written backward kernels, eps regenerated on chip, v saved by the forward
-            g_wmu, g_wrho, g_bmu, g_brho, gx = ops.lr_linear_bwd(
-                x, gy.float(), y, v, w_mu, w_rho, b_mu, b_rho, n_samples=S, sigma_p=call.prior.sigma_p, relu=call.relu,
-                eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b, seed=call.seed, layer_id=call.layer_id,
-                sample_offset=call.sample_offset, sample_counter=call.sample_counter,
-                g_kl=gkl3 if call.want_stats else None, want_gx=ctx.needs_input_grad[0], math_mode=call.math_mode)
-            if gx is not None and x.dim() == 2:
-                gx = gx.sum(0)
-            return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
-        if call.sample_counter is not None:
-            raise ops.BnnHipError("a device sample counter needs the HIP backward kernels (fp32 activations)")
-        x3 = (x if x.dim() == 3 else x.unsqueeze(0).expand(S, -1, -1)).float()
-        B = x3.shape[1]
-        if call.eps_mode == L.EPS_PHILOX:
-            eps_act = ops.philox_normal(call.seed, call.layer_id * 4 + 2, call.sample_offset, S, B, N, dev)
-            eps_b = ops.philox_normal(call.seed, call.layer_id * 4 + 1, call.sample_offset, S, 1, N, dev).view(S, N)
-        elif call.eps_mode == L.EPS_ZERO:
-            eps_act = torch.zeros((S, B, N), device=dev)
-            eps_b = torch.zeros((S, N), device=dev)
-        else:
-            eps_act, eps_b = eps_act.view(S, B, N), eps_b.view(S, N)
-        g = gy.float()
-        if call.relu:
-            g = g * (y > 0).to(g.dtype)
-        sig_w, sig_b = _naive_softplus(w_rho), _naive_softplus(b_rho)
-        s2 = sig_w * sig_w
-        xsq = x3 * x3
-        sd = torch.sqrt(torch.matmul(xsq, s2))                    # [S,B,N]
-        h = torch.where(sd > 0, g * eps_act / (2 * sd), torch.zeros_like(g))
-        g_M = torch.matmul(x3.transpose(1, 2), g).sum(0)          # [K,N]
-        g_s2 = torch.matmul(xsq.transpose(1, 2), h).sum(0)
-        g_sig = 2 * sig_w * g_s2
-        gsum = g.sum(1)                                           # [S,N]
-        g_bmu = gsum.sum(0)
-        g_bsig = (gsum * eps_b).sum(0)
-        if call.want_stats and gkl3 is not None:
-            sp2 = call.prior.sigma_p ** 2
-            # kl3 = (kl, weight_kl, bias_kl): weights see kl + weight_kl, biases kl + bias_kl
-            cw = gkl3[0] + gkl3[1]
-            cb = gkl3[0] + gkl3[2]
-            g_M = g_M + cw * w_mu / sp2
-            g_sig = g_sig + cw * (sig_w / sp2 - 1 / sig_w)
-            g_bmu = g_bmu + cb * b_mu / sp2
-            g_bsig = g_bsig + cb * (sig_b / sp2 - 1 / sig_b)
-        g_rho = g_sig * torch.sigmoid(w_rho)
-        g_brho = g_bsig * torch.sigmoid(b_rho)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.matmul(g, w_mu.t()) + 2 * x3 * torch.matmul(h, s2.t())
-            if x.dim() == 2:
-                gx = gx.sum(0)
-            gx = gx.to(x.dtype)
-        return gx, g_M, g_rho, g_bmu, g_brho, None, None, None
+        _need_f32("LRLinearFn.backward", x, y)
+        # F1: hand-written backward kernels, eps regenerated on chip, v saved by the forward
+        g_wmu, g_wrho, g_bmu, g_brho, gx = ops.lr_linear_bwd(
+            x, gy.float(), y, v, w_mu, w_rho, b_mu, b_rho, n_samples=S, sigma_p=call.prior.sigma_p, relu=call.relu,
+            eps_mode=call.eps_mode, eps_act=eps_act, eps_b=eps_b, seed=call.seed, layer_id=call.layer_id,
+            sample_offset=call.sample_offset, sample_counter=call.sample_counter,
+            g_kl=gkl3 if call.want_stats else None, want_gx=ctx.needs_input_grad[0], math_mode=call.math_mode)
+        if gx is not None and x.dim() == 2:
+            gx = gx.sum(0)
+        return gx, g_wmu, g_wrho, g_bmu, g_brho, None, None, None
 
 
 @dataclass(frozen=True)
@@ -319,15 +225,8 @@ class NLLFn(torch.autograd.Function):
     def backward(ctx, gnll):
         logits, target = ctx.saved_tensors
         S = logits.shape[0]
-        if HIP_BACKWARD and logits.dtype == torch.float32:
-            return ops.nll_bwd(logits, target, gnll, ctx.mode, ctx.sigma), None, None, None
-        if ctx.mode == "classification":
-            p = torch.softmax(logits.float(), dim=-1)
-            onehot = torch.zeros_like(p[0]).scatter_(1, target.view(-1, 1).to(torch.int64), 1.0)
-            g = (p - onehot.unsqueeze(0)) * gnll.view(S, 1, 1)
-        else:
-            g = (logits.float() - target.float().view(1, *logits.shape[1:])) / (ctx.sigma ** 2) * gnll.view(S, 1, 1)
-        return g.to(logits.dtype), None, None, None
+        _need_f32("NLLFn.backward", logits)
+        return ops.nll_bwd(logits, target, gnll, ctx.mode, ctx.sigma), None, None, None
 
 
 class AllReduceSumFn(torch.autograd.Function):

@@ -66,8 +66,18 @@ class FusedAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """torch's format.  The device words of a capturable group are updated IN PLACE: a captured training step
+        (train.GraphedTrainStep) holds their addresses, so dropping them would leave its replays reading freed memory and
+        its bias correction at the old step; groups that have no words yet get them at their next step."""
         super().load_state_dict(state_dict)
-        self._dev = {}                   # rebuilt from state[p]['step'] at the next step
+        for gi, group in enumerate(self.param_groups):
+            if gi not in self._dev:
+                continue
+            steps = [int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]]
+            self._dev[gi][0].fill_(max(steps) if steps else 0)
+            self._dev[gi][1].fill_(group["lr"])
+            self._dev[gi][2] = group["lr"]
+            self._dev[gi][3].zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -73,7 +73,14 @@ class GraphedTrainStep:
         self.x16 = (self.x.to(torch.bfloat16) if (TRAIN_BF16_FORWARD_INPUTS and not autograd and state.math == L.MATH_BF16 and
                                                   x.dtype == torch.float32) else None)
         self.beta = torch.zeros((), dtype=torch.float32, device=dev)
-        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        # ONE device MC-sample counter per optimiser, shared by every step object built on it (full batches and the 96-row
+        # last MNIST batch are two objects on one net): a step draws global sample index base + counter (+ rank * S), the
+        # counter advances inside Adam's launch, so alternating objects never replay an index.  `mirror` is the host's copy.
+        sh = getattr(optimizer, "_sample_words", None)
+        if sh is None or sh["counter"].device != dev:
+            sh = optimizer._sample_words = dict(counter=torch.zeros(1, dtype=torch.int32, device=dev), base=take_samples(0), mirror=0)
+        self._shared = sh
+        self.counter, self.base = sh["counter"], sh["base"]
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
         self.fin_scratch = ops.final_scratch(self.samples, dev)   # hand-off words of the row-split / K-sliced output layer
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
@@ -99,9 +106,7 @@ class GraphedTrainStep:
             self.wsamp_t = [torch.empty((S, sp.in_out[0], sp.in_out[1]), dtype=torch.bfloat16, device=dev)
                             if (TRAIN_TRANSPOSED_INPUT_GRAD and 0 < i < len(specs) - 1 and sp.in_out[1] % 8 == 0) else None
                             for i, sp in enumerate(specs)]
-        self.first = take_samples(0)
-        # the step's MC-sample counter advances inside Adam's launch (after the backward re-read it)
-        optimizer.bump_after_step(self.counter, self.samples * self.world)
+        self._sync_counter()              # indices other code drew since the last step (evaluations) are skipped, not reused
 
         # ---- warm-up on a side stream (allocator pools, lazy inits), then undo its effects
         params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -138,7 +143,7 @@ class GraphedTrainStep:
             else:                                        # the warm-up created the device words: start from the host-side step
                 steps = [int(saved_state[p]["step"]) for p in optimizer.param_groups[gi]["params"] if p in saved_state]
                 optimizer._dev[gi][0].fill_(max(steps) if steps else 0)
-        self.counter.zero_()
+        self._set_counter(sh["mirror"])    # the warm-up's steps advanced it
         torch.cuda.synchronize()
 
         # ---- capture
@@ -148,6 +153,7 @@ class GraphedTrainStep:
         state.device_counter = self.counter
         try:
             take_before = state.counter
+            state.counter = self.base                # what the autograd path's take_samples bakes into the graph
             if self.dp:
                 with torch.cuda.graph(self.graph):
                     with torch.no_grad():
@@ -174,7 +180,7 @@ class GraphedTrainStep:
         lr = bool(net.local_reparam)
         h = net._flat(self.x)
         h16 = net._flat(self.x16) if self.x16 is not None else None     # what the forward launches read, when present
-        first = take_samples(S * self.world) + self.rank * S
+        first = (self.base + self.rank * S) & 0xFFFFFFFF          # + the shared device counter, added by every launch
         saved, wss = [], []
         self._wt_ready = {}                        # layers whose forward launch of this step left transposed weights
         if self.presample:
@@ -296,9 +302,24 @@ class GraphedTrainStep:
         sp.m.weight_mu.grad, sp.m.weight_rho.grad, sp.m.bias_mu.grad, sp.m.bias_rho.grad = grads[:4]
         self._bwd_g = grads[4]
 
+    def _set_counter(self, value: int):
+        value &= 0xFFFFFFFF
+        self.counter.fill_(value - (1 << 32) if value >= (1 << 31) else value)     # the kernels add it as a uint32
+        self._shared["mirror"] = value
+
+    def _sync_counter(self):
+        """Before a step: the device counter must equal the host's count of indices drawn since `base` (eager evaluations
+        between steps draw from the host counter); one small fill when they differ, nothing otherwise."""
+        want = (state.counter - self.base) & 0xFFFFFFFF
+        if want != self._shared["mirror"]:
+            self._set_counter(want)
+
     def _update(self):
         with torch.no_grad():
-            self.opt.step()                          # also advances self.counter (bump_after_step)
+            # the step's MC-sample counter advances inside Adam's launch (after the backward re-read it); set per call:
+            # another step object of this optimiser may use another increment
+            self.opt.bump_after_step(self.counter, self.samples * self.world)
+            self.opt.step()
 
     def _allreduce_upper(self):
         """Layers 1..: issued right behind the graph that produced them, asynchronously (the collective runs on its own
@@ -324,6 +345,7 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)
             out = self._elbo(self.x, self.y, self.beta, self.samples, self.sigma)
             out[0].backward()
+            self.opt.bump_after_step(self.counter, self.samples * self.world)
             self.opt.step()                          # also advances self.counter: the next step draws fresh eps
         finally:
             state.device_counter = None
@@ -346,6 +368,7 @@ class GraphedTrainStep:
             self.y.copy_(y, non_blocking=True)
             self.beta.fill_(float(beta))
         self.opt.sync_lr()
+        self._sync_counter()
         self.graph.replay()
         if self.dp:
             w_hi = self._allreduce_upper()              # beside ...
@@ -355,6 +378,7 @@ class GraphedTrainStep:
             w_lo.wait()
             self.graph_update.replay()
         take_samples(self.samples * self.world)
+        self._shared["mirror"] = (self._shared["mirror"] + self.samples * self.world) & 0xFFFFFFFF
         return self.out
 
 

@@ -6,7 +6,7 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, "bayesian-neural-network_amd")
-for p in (PKG, REPO):
+for p in (PKG, REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

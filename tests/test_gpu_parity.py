@@ -502,15 +502,14 @@ def test_bbb_backward_kernels_match_tensor_op_gradients(dev, prior, shape, eps_m
     call = Fn.LayerCall(n_samples=S, prior=prior, math_mode=L.MATH_F32, relu=relu,
                         eps_mode=L.EPS_MEMORY if mem else L.EPS_PHILOX, seed=11, layer_id=2, sample_offset=40, want_stats=True)
     gy, glp, glq = mk(S, B, N, lo=-1, hi=1), mk(S, lo=-0.5, hi=0.5), mk(S, lo=-0.5, hi=0.5)
-    grads = {}
-    for hip in (True, False):
-        Fn.HIP_BACKWARD = hip
-        leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
-        y, lp, lq = Fn.BBBLinearFn.apply(*leaves, eps_w, eps_b, call)
-        ((y * gy).sum() + (lp * glp).sum() + (lq * glq).sum()).backward()
-        grads[hip] = [l.grad.clone() for l in leaves]
-    Fn.HIP_BACKWARD = True
-    for name, a, b in zip(("x", "w_mu", "w_rho", "b_mu", "b_rho"), grads[True], grads[False]):
+    import tensor_op_grads as T
+    leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
+    y, lp, lq = Fn.BBBLinearFn.apply(*leaves, eps_w, eps_b, call)
+    ((y * gy).sum() + (lp * glp).sum() + (lq * glq).sum()).backward()
+    got = [l.grad.clone() for l in leaves]
+    with torch.no_grad():
+        want = T.bbb_grads(x, gy, glp, glq, y.detach(), w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, call)
+    for name, a, b in zip(("x", "w_mu", "w_rho", "b_mu", "b_rho"), got, want):
         scale = float(b.abs().max()) + 1e-12
         err = float((a - b).abs().max())
         assert err <= 3e-5 * scale + 1e-6, (name, err, scale)
@@ -538,15 +537,14 @@ def test_lr_backward_kernels_match_tensor_op_gradients(dev, shape, eps_mode):
                         eps_mode=L.EPS_MEMORY if mem else L.EPS_PHILOX, seed=13, layer_id=1, sample_offset=70,
                         want_stats=True)
     gy, gkl = mk(S, B, N, lo=-1, hi=1), mk(3, lo=0.1, hi=0.5)
-    grads = {}
-    for hip in (True, False):
-        Fn.HIP_BACKWARD = hip
-        leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
-        y, kl3 = Fn.LRLinearFn.apply(*leaves, eps_act, eps_b, call)
-        ((y * gy).sum() + (kl3 * gkl).sum()).backward()
-        grads[hip] = [l.grad.clone() for l in leaves]
-    Fn.HIP_BACKWARD = True
-    for name, a, b in zip(("x", "w_mu", "w_rho", "b_mu", "b_rho"), grads[True], grads[False]):
+    import tensor_op_grads as T
+    leaves = [t_.clone().requires_grad_(True) for t_ in (x, w_mu, w_rho, b_mu, b_rho)]
+    y, kl3 = Fn.LRLinearFn.apply(*leaves, eps_act, eps_b, call)
+    ((y * gy).sum() + (kl3 * gkl).sum()).backward()
+    got = [l.grad.clone() for l in leaves]
+    with torch.no_grad():
+        want = T.lr_grads(x, gy, gkl, y.detach(), w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, call)
+    for name, a, b in zip(("x", "w_mu", "w_rho", "b_mu", "b_rho"), got, want):
         scale = float(b.abs().max()) + 1e-12
         err = float((a - b).abs().max())
         assert err <= 5e-5 * scale + 1e-6, (name, err, scale)

@@ -506,8 +506,49 @@ def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
             assert torch.equal(ob.state[p]["exp_avg"], m)
         sd = ob.state_dict()
         assert all(int(st["step"]) == M for st in sd["state"].values())
-        graphed2.step(xs[1][:32], ys[1][:32], 0.1)
-        assert ob.device_step() == M + 1
+        # the two objects ALTERNATE (full batches and a short last batch, epoch after epoch): they share the optimiser's
+        # one device sample counter, so every step draws the next unused global sample indices -- the eager loop on the
+        # other replica, walking the host counter, sees the same epsilon, step by step
+        plan = [(graphed2, xs[1][:32], ys[1][:32], 0.1), (graphed, xs[2], ys[2], 0.05), (graphed2, xs[3][:32], ys[3][:32], 0.02),
+                (graphed, xs[0], ys[0], 0.01)]
+        for j, (g, xb, yb, beta) in enumerate(plan):
+            c = bnn_hip.runtime.state.counter
+            assert c == 500 + (M + j) * S
+            got = [o.clone() for o in g.step(xb, yb, beta)]
+            assert ob.device_step() == M + 1 + j and int(graphed.counter.item()) == (M + 1 + j) * S
+            assert graphed.counter is graphed2.counter and bnn_hip.runtime.state.counter == c + S
+            oa.zero_grad()
+            bnn_hip.manual_seed(99, counter=c)                # the replica draws the indices that replay drew
+            out = elbo(xb, yb, beta, S)
+            out[0].backward()
+            oa.step()
+            for a, b in zip(got, out):
+                assert float((a - b.detach()).abs().max()) <= 1e-5 * (float(b.detach().abs().max()) + 1e-6), j
+        for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), k
+        # a checkpoint loaded AFTER the step objects exist: the device words the captured graphs read are updated in place
+        # (step count -> bias correction, learning rate), and the next replay is torch.optim.Adam's update from that state
+        sd = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()} for k, st in ob.state_dict()["state"].items()},
+              "param_groups": [dict(g) for g in ob.state_dict()["param_groups"]]}
+        for st in sd["state"].values():
+            st["step"] = 3
+        sd["param_groups"][0]["lr"] = 7e-4
+        words = [id(w) for w in ob._dev[0][:2]]
+        ob.load_state_dict(sd)
+        assert [id(w) for w in ob._dev[0][:2]] == words and ob.device_step() == 3
+        ref = torch.optim.Adam(net_a.parameters(), lr=7e-4)
+        net_a.load_state_dict(net_b.state_dict())
+        ref.load_state_dict({"state": {k: {"step": torch.tensor(3.0), "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+                                       for k, st in sd["state"].items()}, "param_groups": ref.state_dict()["param_groups"]})
+        got = graphed.step(xs[1], ys[1], 0.03)
+        assert ob.device_step() == 4
+        ref.zero_grad()
+        bnn_hip.manual_seed(99, counter=500 + (M + len(plan)) * S)     # the indices that replay drew
+        out = elbo(xs[1], ys[1], 0.03, S)
+        out[0].backward()
+        ref.step()
+        for (k, a), (_, b) in zip(net_a.state_dict().items(), net_b.state_dict().items()):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), k
 
 
 def test_out_of_range_label_poisons_loss_and_gradient():
