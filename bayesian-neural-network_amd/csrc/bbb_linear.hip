@@ -1013,10 +1013,19 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
       sg[j] = rho_n[j];
     }
     const bool more = t + 1 < t_hi;
+#ifdef BNN_TUNE
+    // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 2 = no parameter loads in the loop, bit 3 = no x
+    // DMA, bit 4 = no LDS reads, bit 5 = no MFMAs
+    if (more) {
+      if (!(p.tune & 8)) stage_dma(t + 1, (t + 1) & 1);
+      if (!(p.tune & 4)) load_params(t + 1);
+    }
+#else
     if (more) {
       stage_dma(t + 1, (t + 1) & 1);     // buffer (t+1)&1 was last read in step t-1 (barrier since)
       load_params(t + 1);
     }
+#endif
     float e[8], w[8];
     if (p.eps_mode == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
@@ -1056,9 +1065,20 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
 #pragma unroll
     for (int j = 0; j < 8; ++j) wa[j] = lane_ok ? (__bf16)w[j] : (__bf16)0.f;
     const float4* xb = xt[t & 1];
+#ifdef BNN_TUNE
+    if (p.tune & 16) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, make_float4(mu[0], mu[1], mu[2], mu[3]));
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (!(p.tune & 32)) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
+    } else
+#endif
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
+#ifdef BNN_TUNE
+      if (p.tune & 32) { asm volatile("" :: "v"(xf)); continue; }
+#endif
       acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
     }
 #ifdef BNN_TUNE

@@ -1,9 +1,10 @@
-// Device-side building blocks shared by the gfx950 kernels: Philox4x32-10 + Box-Muller
+// Device-side building blocks shared by the gfx950 kernels: Philox4x32 + Box-Muller
 // (the frozen epsilon map of include/bnn_hip.h), fp32 softplus/log on the hardware
 // transcendental units, wave64 and block reductions, MFMA fragment types.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/bnn_hip.h"
 
 namespace bnn {
 
@@ -19,9 +20,10 @@ constexpr float kLog2e = 1.442695040888963407f;
 // ---------------------------------------------------------------------------- Philox
 // One round = two 32x32->64 multiplies (v_mad_u64_u32 / v_mul_hi_u32 + v_mul_lo_u32) and
 // four xors; the key schedule is wave-uniform and lives on the scalar unit.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+template <int ROUNDS = BNN_PHILOX_ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < ROUNDS; ++i) {
     const uint64_t p0 = (uint64_t)c.x * 0xD2511F53u;
     const uint64_t p1 = (uint64_t)c.z * 0xCD9E8D57u;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -50,7 +52,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 // The four N(0,1) values of epsilon group `group` (see include/bnn_hip.h).
 __device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample, uint32_t tensor_id,
                                                uint32_t k0, uint32_t k1, float out[4]) {
-  const uint4 r = philox4x32_10(make_uint4(group, gsample, tensor_id, 0u), k0, k1);
+  const uint4 r = philox4x32<>(make_uint4(group, gsample, tensor_id, 0u), k0, k1);
   box_muller(r.x, r.y, out[0], out[1]);
   box_muller(r.z, r.w, out[2], out[3]);
 }

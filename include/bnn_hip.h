@@ -19,15 +19,22 @@
  *   - Structs start with `struct_bytes` = sizeof(the struct) as the caller compiled it;
  *     a mismatch returns BNN_ERR_ABI.
  *
- * Epsilon generator (frozen; results must not depend on tiling, launch shape or #GPUs)
- *   Philox4x32-10 (Salmon et al. 2011; the generator behind rocRAND's PHILOX4_32_10) keyed
- *   by the 64-bit seed.  For an epsilon tensor of logical shape [rows, cols] belonging to
+ * Epsilon generator (map version BNN_EPS_MAP_VERSION; results must not depend on tiling, launch shape or #GPUs)
+ *   Philox4x32 with BNN_PHILOX_ROUNDS = 7 rounds (Salmon et al., SC'11: the round function and key schedule of
+ *   rocRAND's PHILOX4_32_10; 7 rounds is the variant the paper reports as passing BigCrush, 10 its default safety
+ *   margin) keyed by the 64-bit seed.  Map version 1 (rounds 1-2 of this repository) ran 10 rounds: the kernels that
+ *   draw eps per weight are bound by this integer arithmetic (20 -> 14 v_mad_u64_u32 per 4 normals; measured
+ *   238 -> 197 cycles per 4 normals per SIMD, the per-8-weights body of K1b 533 -> 424: DESIGN.md 4), so version 2
+ *   trades the margin for 20 % of the generator.  tests/test_oracle_golden.py checks the 10-round form of the SAME code
+ *   against the Random123 known-answer vectors and the 7-round outputs for avalanche, bit balance, moments, a
+ *   Kolmogorov-Smirnov distance and cross-stream correlation.
+ *   For an epsilon tensor of logical shape [rows, cols] belonging to
  *   GLOBAL MC sample index g (= sample_offset + local sample), tensor id
  *   t = 4*layer_id + kind  (kind 0: BBB weight eps [out,in]; 1: bias eps [1,out];
  *   2: LR activation eps [batch,out]):
  *       group  = row * ceil(cols/4) + (col >> 2)           (uint32)
  *       counter = (group, g, t, 0), key = (seed_lo, seed_hi)
- *       (r0,r1,r2,r3) = Philox4x32-10(counter, key)
+ *       (r0,r1,r2,r3) = Philox4x32-R(counter, key), R = BNN_PHILOX_ROUNDS
  *       u(r) = fma((float)r, 2^-32, 2^-33)                  in (0,1]
  *       slot 0,1 = sqrt(-2 ln u(r0)) * {cos, sin}(2 pi u(r1)); slot 2,3 likewise from r2,r3
  *       eps[row, col] = slot (col & 3)
@@ -44,6 +51,8 @@ extern "C" {
 #endif
 
 #define BNN_HIP_ABI_VERSION 4
+#define BNN_EPS_MAP_VERSION 2     /* 1: Philox4x32-10 (rounds 1-2); 2: Philox4x32-7 */
+#define BNN_PHILOX_ROUNDS 7
 
 enum bnn_status {
   BNN_OK = 0,

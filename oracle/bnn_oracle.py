@@ -351,8 +351,8 @@ def beta_schedule(num_batches: int, idx: int) -> float:
 
 # --------------------------------------------------------------------------------------
 # CPU restatement of the DEVICE epsilon generator (not a reference function: the reference
-# draws eps from torch's CPU generator).  Philox4x32-10 (Salmon et al., SC'11) + Box-Muller
-# with the counter->element map frozen in include/bnn_hip.h.  Used by tests to check that
+# draws eps from torch's CPU generator).  Philox4x32 (Salmon et al., SC'11) with PHILOX_ROUNDS rounds + Box-Muller
+# with the counter->element map of include/bnn_hip.h (BNN_EPS_MAP_VERSION 2: 7 rounds; version 1 ran 10).  Used by tests to check that
 # the kernels' on-chip eps is what the header says it is.
 # --------------------------------------------------------------------------------------
 _PHILOX_M0 = np.uint64(0xD2511F53)
@@ -362,13 +362,16 @@ _PHILOX_W1 = np.uint32(0xBB67AE85)
 _MASK32 = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All arguments broadcastable uint32 arrays."""
+PHILOX_ROUNDS = 7      # include/bnn_hip.h: BNN_PHILOX_ROUNDS
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds: int = PHILOX_ROUNDS):
+    """Vectorised Philox4x32-`rounds`.  All arguments broadcastable uint32 arrays."""
     c0, c1, c2, c3 = [np.asarray(v, dtype=np.uint32) for v in np.broadcast_arrays(c0, c1, c2, c3)]
     k0 = np.uint32(k0)
     k1 = np.uint32(k1)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = c0.astype(np.uint64) * _PHILOX_M0
             p1 = c2.astype(np.uint64) * _PHILOX_M1
             hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
@@ -379,6 +382,11 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
             k0 = np.uint32((int(k0) + int(_PHILOX_W0)) & 0xFFFFFFFF)
             k1 = np.uint32((int(k1) + int(_PHILOX_W1)) & 0xFFFFFFFF)
     return c0, c1, c2, c3
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """The 10-round form of the same code: what the Random123 known-answer vectors exist for."""
+    return philox4x32(c0, c1, c2, c3, k0, k1, rounds=10)
 
 
 def _u01(r: np.ndarray) -> np.ndarray:
@@ -403,7 +411,7 @@ def philox_normal(seed: int, tensor_id: int, sample: int, rows: int, cols: int) 
     gpr = (cols + 3) // 4
     g = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(gpr)
          + np.arange(gpr, dtype=np.uint64)[None, :]).astype(np.uint32)
-    r0, r1, r2, r3 = philox4x32_10(g, np.uint32(sample), np.uint32(tensor_id), np.uint32(0),
+    r0, r1, r2, r3 = philox4x32(g, np.uint32(sample), np.uint32(tensor_id), np.uint32(0),
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     n0, n1 = box_muller(r0, r1)
     n2, n3 = box_muller(r2, r3)

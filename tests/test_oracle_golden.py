@@ -199,13 +199,77 @@ def test_g9_beta_schedule(g_beta):
 
 
 def test_philox_known_answer():
-    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors): the round function, the
+    multipliers and the key schedule of the generator -- the device and this restatement run the SAME code for
+    BNN_PHILOX_ROUNDS = 7 rounds (eps map version 2), for which the tests below check the statistics."""
     r = O.philox4x32_10(0, 0, 0, 0, 0, 0)
     assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     r = O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
     assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     r = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
     assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert O.PHILOX_ROUNDS == 7
+    assert [int(v) for v in O.philox4x32(0, 0, 0, 0, 0, 0)] != [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(v) for v in O.philox4x32(0, 0, 0, 0, 0, 0, rounds=10)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+def _bits(words):
+    """uint32 arrays [4][n] -> bit matrix [n, 128]"""
+    return np.concatenate([((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8) for w in words], axis=1)
+
+
+def test_philox7_avalanche_and_bit_balance():
+    """The 7-round generator on the counters the map actually uses (consecutive groups, small sample and tensor ids,
+    one key): every output bit is balanced, and flipping ANY single counter or key bit flips each of the 128 output bits
+    with probability 1/2 (strict avalanche) -- sequential counters are the hard case for a weak round count (with 4
+    rounds this test fails by a wide margin, asserted below so that the test is known to have teeth)."""
+    n = 4096
+    rs = np.random.RandomState(11)
+    ctr = [np.arange(n, dtype=np.uint32) * np.uint32(3) + np.uint32(17), rs.randint(0, 64, n).astype(np.uint32),
+           rs.randint(0, 12, n).astype(np.uint32), np.zeros(n, np.uint32)]
+    key = (np.uint32(2026), np.uint32(0))
+
+    def worst(rounds):
+        base = _bits(O.philox4x32(*ctr, *key, rounds=rounds))
+        bal = np.abs(base.mean(0) - 0.5).max()
+        dev = 0.0
+        for word in range(3):                                      # the counter words the map varies
+            for bit in (0, 1, 2, 5, 9, 13, 21, 31):
+                c2 = [c.copy() for c in ctr]
+                c2[word] = c2[word] ^ np.uint32(1 << bit)
+                flips = (_bits(O.philox4x32(*c2, *key, rounds=rounds)) ^ base).mean(0)     # per output bit
+                dev = max(dev, float(np.abs(flips - 0.5).max()))
+        for bit in (0, 7, 31):                                     # key (seed) bits
+            flips = (_bits(O.philox4x32(*ctr, np.uint32(2026 ^ (1 << bit)), key[1], rounds=rounds)) ^ base).mean(0)
+            dev = max(dev, float(np.abs(flips - 0.5).max()))
+        return bal, dev
+
+    bal7, dev7 = worst(7)
+    bal10, dev10 = worst(10)
+    # 4096 Bernoulli(1/2) trials: sigma = 0.0078; the maximum over ~3500 (bit, flip) pairs sits near 4 sigma
+    assert bal7 < 0.04 and dev7 < 0.045, (bal7, dev7)
+    assert abs(dev7 - dev10) < 0.015                               # indistinguishable from the 10-round form here
+    _, dev4 = worst(4)
+    assert dev4 > 0.2                                              # a short generator does NOT pass: the test has teeth
+
+
+def test_philox7_normals_against_the_normal_distribution():
+    """eps of map version 2: moments, Kolmogorov-Smirnov distance to N(0,1), independence of neighbouring elements,
+    samples, tensors and seeds."""
+    from scipy import stats
+    e = O.philox_normal(2026, O.tensor_id(1, 0), 3, 600, 1200).astype(np.float64)     # 720 000 draws
+    n = e.size
+    assert abs(e.mean()) < 4.0 / np.sqrt(n) and abs(e.var() - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(stats.skew(e.ravel())) < 4.0 * np.sqrt(6.0 / n) and abs(stats.kurtosis(e.ravel())) < 4.0 * np.sqrt(24.0 / n)
+    d, _ = stats.kstest(e.ravel()[::4], "norm")                   # 180 000 draws: the 1 % critical value is 1.63 / sqrt(n)
+    assert d < 1.63 / np.sqrt(n / 4)
+    flat = e.ravel()
+    for lag in (1, 2, 3, 4, 1200):                                  # within a Philox group, across groups, across rows
+        assert abs(np.corrcoef(flat[:-lag], flat[lag:])[0, 1]) < 4.0 / np.sqrt(n)
+    for other in (O.philox_normal(2026, O.tensor_id(1, 0), 4, 600, 1200), O.philox_normal(2026, O.tensor_id(2, 0), 3, 600, 1200),
+                  O.philox_normal(2027, O.tensor_id(1, 0), 3, 600, 1200)):
+        assert abs(np.corrcoef(flat, other.ravel())[0, 1]) < 4.0 / np.sqrt(n)
+    assert np.abs(e).max() < 6.7                                    # u in (0,1] with 2^-33 granularity: |eps| <= 6.66
 
 
 def test_philox_normal_moments():
