@@ -933,7 +933,10 @@ __global__ __launch_bounds__(768) void bbb_input_grad_kernel(const BbbK p) {
 //   every wave's B-fragment read is one conflict-free ds_read_b128.  The DMA for tile t+1 is
 //   issued at the top of step t and drained (vmcnt(0)) just before the step's single barrier:
 //   a whole k-step of Philox/softplus work covers its latency.  ~115 VGPRs -> 4 waves/SIMD.
-template <int NW, bool SIG>
+// EPS: the epsilon source is a COMPILE-TIME choice.  As a run-time branch the three sources met in one block ahead of
+// w = mu + sigma * eps, and the compiler's wait-count pass, seeing eps come from memory on one path, put s_waitcnt vmcnt(0)
+// there on all of them: every wave drained the prefetch it had just issued BEFORE its generator work instead of behind it.
+template <int NW, bool SIG, int EPS>
 __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64], float (*bias_s)[16]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -975,11 +978,15 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
     }
   };
 
-  float mu_n[8], rho_n[8];
-  auto load_params = [&](int t) {
+  // (mu, rho | sigma) of a step: four 16-byte loads per lane, issued one step AHEAD into one of two explicit register sets
+  // (A / B) that the steps consume alternately.  A single loop-carried set made the compiler place its copies -- and with
+  // them s_waitcnt vmcnt(0) -- right behind the loads, ahead of the generator work the prefetch was meant to overlap.
+  struct PSet { float4 m_lo, m_hi, g_lo, g_hi; };
+  auto load_params = [&](int t, PSet& P) __attribute__((always_inline)) {
     const size_t woff = (size_t)nc * K + min(t * 32 + q * 8, K - 8);
-    load8<true>(p.w_mu + woff, 8, mu_n);
-    load8<true>((SIG ? p.w_sigma : p.w_rho) + woff, 8, rho_n);
+    const float4* pm = reinterpret_cast<const float4*>(p.w_mu + woff);
+    const float4* pg = reinterpret_cast<const float4*>((SIG ? p.w_sigma : p.w_rho) + woff);
+    P.m_lo = pm[0]; P.m_hi = pm[1]; P.g_lo = pg[0]; P.g_hi = pg[1];
   };
 
   // bias of this wave's tile: eps now, applied in the epilogue
@@ -990,8 +997,10 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
     beps_pre = bias_eps(p, n, s, gs, do_dump);
   }
 
+  PSet PA, PB;
+  PA.m_lo = PA.m_hi = PA.g_lo = PA.g_hi = PB.m_lo = PB.m_hi = PB.g_lo = PB.g_hi = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t_lo < t_hi) {
-    load_params(t_lo);
+    load_params(t_lo, PA);
     stage_dma(t_lo, t_lo & 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1002,36 +1011,32 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
 
-#pragma nounroll
-  for (int t = t_lo; t < t_hi; ++t) {
+  // one k-step over the parameters in P (loaded a step ago); `more`: step t + 1 exists and its loads go to Pn
+  auto step = [&](int t, const PSet& P, PSet& Pn) __attribute__((always_inline)) {
     const int k = t * 32 + q * 8;
     const bool lane_ok = n_ok && k < K;
-    float mu[8], sg[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      mu[j] = mu_n[j];
-      sg[j] = rho_n[j];
-    }
     const bool more = t + 1 < t_hi;
 #ifdef BNN_TUNE
     // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 2 = no parameter loads in the loop, bit 3 = no x
     // DMA, bit 4 = no LDS reads, bit 5 = no MFMAs
     if (more) {
       if (!(p.tune & 8)) stage_dma(t + 1, (t + 1) & 1);
-      if (!(p.tune & 4)) load_params(t + 1);
+      if (!(p.tune & 4)) load_params(t + 1, Pn);
     }
 #else
     if (more) {
       stage_dma(t + 1, (t + 1) & 1);     // buffer (t+1)&1 was last read in step t-1 (barrier since)
-      load_params(t + 1);
+      load_params(t + 1, Pn);
     }
 #endif
+    const float mu[8] = {P.m_lo.x, P.m_lo.y, P.m_lo.z, P.m_lo.w, P.m_hi.x, P.m_hi.y, P.m_hi.z, P.m_hi.w};
+    float sg[8] = {P.g_lo.x, P.g_lo.y, P.g_lo.z, P.g_lo.w, P.g_hi.x, P.g_hi.y, P.g_hi.z, P.g_hi.w};
     float e[8], w[8];
-    if (p.eps_mode == BNN_EPS_PHILOX) {
+    if (EPS == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
       philox_normal4(g, gs, wid, p.k0, p.k1, e);
       philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
-    } else if (p.eps_mode == BNN_EPS_MEMORY) {
+    } else if (EPS == BNN_EPS_MEMORY) {
       load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
     } else {
 #pragma unroll
@@ -1064,32 +1069,54 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
     bf16x8 wa;
 #pragma unroll
     for (int j = 0; j < 8; ++j) wa[j] = lane_ok ? (__bf16)w[j] : (__bf16)0.f;
-    const float4* xb = xt[t & 1];
+    // x fragments by hand-written ds_read_b128: a compiler-visible read of `xt` is ordered behind EVERY LDS-DMA in flight
+    // that may alias it (s_waitcnt vmcnt(0) ahead of the first read: the prefetch just issued), although buffer t & 1 was
+    // complete at the last barrier.  The "+v" operands of the wait tie the MFMAs to it.
+    const uint32_t xa = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&xt[t & 1][q * 16 + r];
 #ifdef BNN_TUNE
-    if (p.tune & 16) {
-      const bf16x8 xf = __builtin_bit_cast(bf16x8, make_float4(mu[0], mu[1], mu[2], mu[3]));
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-        if (!(p.tune & 32)) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
-    } else
+    const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
+#else
+    constexpr bool tune_nolds = false, tune_nomfma = false;
 #endif
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const bf16x8 xf = __builtin_bit_cast(bf16x8, xb[(m * 4 + q) * 16 + r]);
-#ifdef BNN_TUNE
-      if (p.tune & 32) { asm volatile("" :: "v"(xf)); continue; }
-#endif
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf, acc[m], 0, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+      f32x4 x0, x1, x2, x3;
+      if (tune_nolds) {
+        x0 = x1 = x2 = x3 = f32x4{mu[0], mu[1], mu[2], mu[3]};
+      } else {
+        if (h == 0)
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                       : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(xa));
+        else
+          asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
+                       : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(xa));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      }
+      if (!tune_nomfma) {
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+      } else {
+        asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+      }
     }
 #ifdef BNN_TUNE
-    // tuning build only: BNN_TUNE_K1B bit 0 = no per-step barrier, bit 1 = no vmcnt wait (wrong results: an upper bound on what
-    // the per-step synchronisation costs)
     if (!(p.tune & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(p.tune & 1)) __syncthreads();
 #else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and the next step's parameters) have landed
     __syncthreads();
 #endif
+  };
+  {
+    int t = t_lo;
+#pragma nounroll
+    for (; t + 1 < t_hi; t += 2) {
+      step(t, PA, PB);
+      step(t + 1, PB, PA);
+    }
+    if (t < t_hi) step(t, PA, PB);
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
@@ -1198,16 +1225,16 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   }
 }
 
-template <int NW, bool SIG>
+template <int NW, bool SIG, int EPS>
 __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) {
   __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];      // 2 x 8 KiB
   __shared__ float bias_s[NW][16];
-  bbb_gemm_body<NW, SIG>(p, xt, bias_s);
+  bbb_gemm_body<NW, SIG, EPS>(p, xt, bias_s);
 }
 
 // The block GEMM carrying an independent sampling job (bnn_bbb_fwd_args.rider) as extra 256-thread blocks behind its
 // own (whose count is a multiple of 8, so the XCD-aware work order of the layer's blocks is unchanged).
-template <bool SIG>
+template <bool SIG, int EPS>
 __global__ __launch_bounds__(256, 4) void bbb_fwd_gemm_rider_kernel(const BbbK p, const SampleK sk, int n_main) {
   __shared__ __attribute__((aligned(16))) float4 xt[2][8 * 64];
   __shared__ float bias_s[4][16];
@@ -1215,7 +1242,7 @@ __global__ __launch_bounds__(256, 4) void bbb_fwd_gemm_rider_kernel(const BbbK p
     sample_block(sk, (int)blockIdx.x - n_main, &bias_s[0][0]);
     return;
   }
-  bbb_gemm_body<4, SIG>(p, xt, bias_s);
+  bbb_gemm_body<4, SIG, EPS>(p, xt, bias_s);
 }
 
 // Per-layer reduction of the stats partials into the scalars BayesianLinear stores
@@ -1621,14 +1648,24 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
     if (ride) {
       const unsigned n_main = grid.x;
       const dim3 grid_r(n_main + (unsigned)rider_blocks);
-      if (a->w_sigma)
-        hipLaunchKernelGGL((bbb_fwd_gemm_rider_kernel<true>), grid_r, block, 0, stream, k, sk, (int)n_main);
-      else
-        hipLaunchKernelGGL((bbb_fwd_gemm_rider_kernel<false>), grid_r, block, 0, stream, k, sk, (int)n_main);
-    } else if (a->w_sigma)
-      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true>), grid, block, 0, stream, k);
-    else
-      hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false>), grid, block, 0, stream, k);
+#define BNN_GEMM_EPS(KERNEL, SIGV, ...)                                                                        \
+  do {                                                                                                         \
+    if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((KERNEL<SIGV, BNN_EPS_PHILOX>), __VA_ARGS__);          \
+    else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((KERNEL<SIGV, BNN_EPS_MEMORY>), __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<SIGV, BNN_EPS_ZERO>), __VA_ARGS__);                                         \
+  } while (0)
+      if (a->w_sigma) BNN_GEMM_EPS(bbb_fwd_gemm_rider_kernel, true, grid_r, block, 0, stream, k, sk, (int)n_main);
+      else BNN_GEMM_EPS(bbb_fwd_gemm_rider_kernel, false, grid_r, block, 0, stream, k, sk, (int)n_main);
+    } else if (a->w_sigma) {
+      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true, BNN_EPS_PHILOX>), grid, block, 0, stream, k);
+      else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true, BNN_EPS_MEMORY>), grid, block, 0, stream, k);
+      else hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, true, BNN_EPS_ZERO>), grid, block, 0, stream, k);
+    } else {
+      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false, BNN_EPS_PHILOX>), grid, block, 0, stream, k);
+      else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false, BNN_EPS_MEMORY>), grid, block, 0, stream, k);
+      else hipLaunchKernelGGL((bbb_fwd_gemm_kernel<4, false, BNN_EPS_ZERO>), grid, block, 0, stream, k);
+    }
+#undef BNN_GEMM_EPS
   } else if (ride) {
     const unsigned n_main = (unsigned)(((pl.blocks + 7) / 8) * 8);
     const dim3 grid_r(n_main + (unsigned)rider_blocks);
