@@ -258,7 +258,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
         sbytes = n * 10 * (dims[1] * dims[1] + dims[1])
         tf = flops / (us_g * 1e-6) / 1e12
         return {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None, "kernel": f"bnn::bbb_block_gemm_kernel (K1g: 256x256 block tile, v_mfma_f32_16x16x32_bf16, LDS-DMA operands, "
+                "traffic": None, "traffic_key": f"block_gemm_{dims[1]}_n{n}_b{batch}_{math_name}",
+                "kernel": f"bnn::bbb_block_gemm_kernel (K1g: 256x256 block tile, v_mfma_f32_16x16x32_bf16, LDS-DMA operands, "
                                            f"bias/ReLU/bf16 epilogue) over pre-sampled weights, layer 2 ({dims[1]}x{dims[1]}), batch {batch}",
                 "algorithmic_flops_per_launch": flops, "mc_samples_per_launch": n, "avg_launch_us": us_g,
                 "sampling": {"kernel": "K1s bbb_sample_kernel", "avg_launch_us": us_s, "algorithmic_bytes_per_launch": sbytes,
@@ -337,7 +338,8 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))
         for k, v in pm.items():
-            if "bbb_fwd_gemm_kernel" in k and k.startswith("bbb_g256") and "valu_busy" in v:
+            if "bbb_fwd_gemm_kernel" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
+                    v.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
                 roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
                                        "key": k, "source": "profiles/pmc.json (rocprofv3 --pmc, tools/collect_pmc.py)"}
     except Exception:
@@ -356,7 +358,7 @@ def attach_traffic(roof):
         t = json.load(open(tj))
         e = t.get(key)
         if e is not None:
-            fam = "lr" if key.startswith("lr") else "bbb"
+            fam = "lr" if key.startswith("lr") else "block_gemm" if key.startswith("block") else "bbb"
             if e.get("source_hash") == source_hash(KERNEL_SOURCES[fam]):
                 roof["traffic"] = e["hbm_bytes_per_launch"]
                 roof["traffic_source"] = e.get("source", "profiles/traffic.json")

@@ -7,6 +7,8 @@ GRBM_GUI_ACTIVE is reported summed over the 8 XCDs.
 usage: collect_pmc.py <pmc_dir> <key>"""
 import collections, csv, glob, json, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bench import source_hash, KERNEL_SOURCES      # entries carry the hash of the kernel sources they were measured on
 d, key = sys.argv[1:3]
 f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -17,7 +19,8 @@ out_path = os.path.join(os.environ.get("BNN_PROFILES_DIR") or os.path.join(REPO,
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for kern, cs in agg.items():
     m = {c: sum(v) / len(v) for c, v in cs.items()}
-    e = {"dispatches_averaged": len(next(iter(cs.values()))), "counters_mean_per_dispatch": m}
+    fam = "lr" if "lr_" in kern else "block_gemm" if "block_gemm" in kern else "bbb"
+    e = {"dispatches_averaged": len(next(iter(cs.values()))), "counters_mean_per_dispatch": m, "source_hash": source_hash(KERNEL_SOURCES[fam])}
     if "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # shader cycles the dispatch was active
         simd_cycles = cyc * 256 * 4

@@ -24,6 +24,15 @@ stats() {   # stats <name> <bench args...>: kernel-trace summary of bench.py --r
   echo "== $name"; head -4 "$PROF/${TAG}_${name}_kernel_stats.csv"
 }
 
+statsfull() {   # statsfull <name> <bench args...>: kernel-trace summary of a whole bench.py run (the driver's command)
+  local name=$1; shift
+  timeout -k 10 500 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/$name" -o "$name" -- python3 "$ROOT/bench.py" "$@" \
+      > "$OUT/$name.json" 2> "$OUT/$name.err" || return $?
+  cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$PROF/${TAG}_${name}_kernel_stats.csv"
+  tail -1 "$OUT/$name.json" > "$PROF/${TAG}_bench_${name}.json"
+  echo "== $name"; head -5 "$PROF/${TAG}_${name}_kernel_stats.csv"
+}
+
 traffic() { # traffic <name> <key> <kernel substring> <bench args...>: FETCH_SIZE / WRITE_SIZE in separate passes
   local name=$1 key=$2 kern=$3; shift 3
   for c in FETCH_SIZE WRITE_SIZE; do
