@@ -147,7 +147,7 @@ class AdamArgs(C.Structure):
         ("numel", C.c_int64 * ADAM_MAX_TENSORS),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
         ("step", C.c_uint32), ("bump_by", C.c_uint32),
-        ("lr_device", C.c_void_p), ("step_device", C.c_void_p), ("step_advance", C.c_int32), ("reserved", C.c_int32),
+        ("lr_device", C.c_void_p), ("step_device", C.c_void_p), ("step_advance", C.c_int32), ("grad_dtype", C.c_int32),
         ("ticket", C.c_void_p), ("bump_counter", C.c_void_p),
     ]
 

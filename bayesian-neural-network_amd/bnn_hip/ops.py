@@ -821,7 +821,7 @@ def nll_bwd(logits, target, g_nll, mode: str, sigma: float = 1.0):
 
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: float, weight_decay: float, step: int = 0,
               lr_device=None, step_device=None, ticket=None, bump_counter=None, bump_by: int = 0):
-    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch).  With `ticket` (zeroed device array
+    """F2: bnn_adam_step over lists of fp32 tensors (any number; 16 per launch; the gradients fp32 or bf16).  With `ticket` (zeroed device array
     of 16 uint32) the device step advances inside the first launch, which also adds bump_by to *bump_counter."""
     lib = L.load()
     n = len(params)
@@ -833,14 +833,19 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, *, lr: float, betas, eps: fl
         for j in range(lo, hi):
             p, g, m, v = params[j], grads[j], exp_avgs[j], exp_avg_sqs[j]
             require_device(p, g, m, v)
-            for t_ in (p, g, m, v):
+            for t_ in (p, m, v):
                 if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.numel() != p.numel():
                     raise BnnHipError("adam_step: tensors must be contiguous float32 of the parameter's size")
+            if g.dtype not in (torch.float32, torch.bfloat16) or g.dtype != grads[lo].dtype or not g.is_contiguous() or \
+                    g.numel() != p.numel():
+                raise BnnHipError("adam_step: gradients must be contiguous float32 or bfloat16 (one dtype per launch) of the "
+                                  "parameter's size")
             a.param[j - lo], a.grad[j - lo] = p.data_ptr(), g.data_ptr()
             a.exp_avg[j - lo], a.exp_avg_sq[j - lo] = m.data_ptr(), v.data_ptr()
             a.numel[j - lo] = p.numel()
         a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
         a.step = int(step)
+        a.grad_dtype = _dt(grads[lo])
         a.lr_device = _ptr(lr_device)
         a.step_device = _ptr(step_device)
         a.step_advance = int(lo == 0)                   # the first launch of the step advances the device counter

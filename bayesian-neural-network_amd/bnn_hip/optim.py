@@ -80,7 +80,9 @@ class FusedAdam(torch.optim.Optimizer):
             self._dev[gi][3].zero_()
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grads=None):
+        """`grads` (optional dict parameter -> tensor): gradients to use instead of p.grad -- a data-parallel step's bf16
+        views of its all-reduced 2-byte bucket (train.GraphedTrainStep(grad_dtype=torch.bfloat16))."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -88,9 +90,10 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             ps, gs, ms, vs = [], [], [], []
             for p in group["params"]:
-                if p.grad is None:
+                pg = grads.get(p) if grads is not None else p.grad
+                if pg is None:
                     continue
-                if p.grad.is_sparse:
+                if pg.is_sparse:
                     raise RuntimeError("FusedAdam does not support sparse gradients")
                 st = self.state[p]
                 if len(st) == 0:
@@ -98,7 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 ps.append(p)
-                gs.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+                gs.append(pg if pg.is_contiguous() else pg.contiguous())
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
             if not ps:

@@ -33,6 +33,8 @@ struct AdamK {
 
 __global__ void adam_tick_kernel(uint32_t* step) { *step += 1u; }
 
+// GBF16: the gradients arrive in bf16 (a data-parallel step's all-reduced 2-byte bucket)
+template <bool GBF16>
 __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
   int t = 0;
 #pragma unroll 1
@@ -41,6 +43,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
   const long n = k.numel[t];
   float* __restrict__ p = k.p[t];
   const float* __restrict__ g = k.g[t];
+  const __bf16* __restrict__ g16 = reinterpret_cast<const __bf16*>(k.g[t]);
+  auto ld_g4 = [&](long i) -> float4 {
+    if (!GBF16) return *reinterpret_cast<const float4*>(g + i);
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(g16 + i);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  };
+  auto ld_g1 = [&](long i) -> float { return GBF16 ? (float)g16[i] : g[i]; };
   float* __restrict__ m = k.m[t];
   float* __restrict__ v = k.v[t];
   // a whole chunk (all but the last block of a tensor): its 16 loads go out before anything else -- the double-precision
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
     for (int it = 0; it < kIt; ++it) {
       const long i = base + ((long)it * 256 + threadIdx.x) * 4;
       qa[it] = *reinterpret_cast<const float4*>(p + i);
-      qb[it] = *reinterpret_cast<const float4*>(g + i);
+      qb[it] = ld_g4(i);
       qc[it] = *reinterpret_cast<const float4*>(m + i);
       qd[it] = *reinterpret_cast<const float4*>(v + i);
     }
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = i + 3 < n;
     if (full) {
-      const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+      const float4 a = *reinterpret_cast<const float4*>(p + i), b = ld_g4(i);
       const float4 c = *reinterpret_cast<const float4*>(m + i), d = *reinterpret_cast<const float4*>(v + i);
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
       gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamK k) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool ok = i + j < n;
-        pv[j] = ok ? p[i + j] : 0.f; gv[j] = ok ? g[i + j] : 0.f; mv[j] = ok ? m[i + j] : 0.f; vv[j] = ok ? v[i + j] : 0.f;
+        pv[j] = ok ? p[i + j] : 0.f; gv[j] = ok ? ld_g1(i + j) : 0.f; mv[j] = ok ? m[i + j] : 0.f; vv[j] = ok ? v[i + j] : 0.f;
       }
     }
 #pragma unroll
@@ -215,7 +224,9 @@ extern "C" int bnn_adam_step(const bnn_adam_args* a, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (a->step_device && a->step_advance && !ticketed)
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, a->step_device);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks), dim3(256), 0, stream, k);
+  if ((unsigned)a->grad_dtype > 1u) return BNN_ERR_ENUM;
+  if (a->grad_dtype == BNN_BF16) hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, stream, k);
+  else hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, stream, k);
   const hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }

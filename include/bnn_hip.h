@@ -577,7 +577,7 @@ int bnn_lr_linear_bwd(const bnn_lr_bwd_args* args, void* stream);
  * t = step (host) or, when step_device != NULL, the device word *step_device, advanced first if
  * step_advance != 0 (so a captured hipGraph of the training step counts by itself).  lr_device (optional device float)
  * overrides lr, so StepLR (class_task.py:61) can change the rate of a captured graph.
- * All tensors fp32, contiguous, 16-byte aligned.
+ * All tensors fp32 (grad: fp32 or bf16, grad_dtype), contiguous, 16-byte aligned.
  * ---------------------------------------------------------------------------------- */
 #define BNN_ADAM_MAX_TENSORS 16
 typedef struct bnn_adam_args {
@@ -596,7 +596,8 @@ typedef struct bnn_adam_args {
   uint32_t* step_device;
   int32_t step_advance;          /* with step_device: 1 = ++(*step_device) before the update, 0 = use it
                                     as it is (second and later launches of one optimiser step) */
-  int32_t reserved;
+  int32_t grad_dtype;            /* bnn_dtype of grad[]: BNN_F32, or BNN_BF16 -- grad[t] then points at bf16 values (the
+                                    gradient bucket a data-parallel step all-reduces in 2-byte elements) */
   uint32_t* ticket;              /* optional zero-initialised device array of 16 words.  With step_advance: the update uses
                                     *step_device + 1 and the block that finishes last stores it (and re-zeroes the
                                     ticket) -- the step counts inside the one launch, no separate tick launch */

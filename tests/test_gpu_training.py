@@ -95,6 +95,31 @@ def test_fused_adam_matches_torch_adam():
             assert close_v <= 1e-6 * (float(oa.state[a]["exp_avg_sq"].abs().max()) + 1e-6) + 1e-12
 
 
+def test_fused_adam_reads_bf16_gradients():
+    """bnn_adam_args.grad_dtype = bf16 (the all-reduced 2-byte bucket of a data-parallel step): FusedAdam.step(grads=...)
+    over bf16 gradient tensors against torch.optim.Adam fed the same values widened to fp32; odd sizes (scalar tail
+    path), 20 tensors (two launches)."""
+    from bnn_hip.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(4)
+    shapes = [(1200, 784), (1200,), (7,), (33, 5), (1,), (4099,)] + [(3, 3)] * 14
+    base = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)).to(dev) for s in shapes]
+    pa = [torch.nn.Parameter(b.clone()) for b in base]
+    pb = [torch.nn.Parameter(b.clone()) for b in base]
+    oa = torch.optim.Adam(pa, lr=1e-3)
+    ob = FusedAdam(pb, lr=1e-3, capturable=True)
+    for it in range(4):
+        g16 = {}
+        for a, b in zip(pa, pb):
+            g = (torch.from_numpy(rs.standard_normal(tuple(a.shape)).astype(np.float32)).to(dev) * (10.0 ** (it % 3 - 1))).to(torch.bfloat16)
+            a.grad, g16[b] = g.float(), g
+        oa.step()
+        ob.step(grads=g16)
+    assert ob.device_step() == 4
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * (float(a.detach().abs().max()) + 1.0)
+
+
 @pytest.mark.parametrize("mode", ["classification", "regression"])
 def test_nll_backward_kernel_matches_autograd(mode):
     from bnn_hip import ops
@@ -617,6 +642,7 @@ import bnn_hip, networks
 from bnn_hip.optim import FusedAdam
 from bnn_hip.train import GraphedTrainStep, broadcast_parameters
 rank, world, lr_flag = int(sys.argv[1]), int(sys.argv[2]), sys.argv[4] == "lr"
+g16 = len(sys.argv) > 5 and sys.argv[5] == "bf16"
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
 dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks on cuda:0 (one-GPU box): gloo, not RCCL
 dev = torch.device("cuda:0")
@@ -634,7 +660,8 @@ ys = [[torch.from_numpy(rs.randint(0, 10, 32)).to(dev) for _ in range(T)] for _ 
 beta = lambda idx: 2 ** (M - (idx + 1)) / (2 ** M - 1)
 bnn_hip.manual_seed(5, counter=1000)
 opt = FusedAdam(net.parameters(), lr=1e-3, capturable=True)
-step = GraphedTrainStep(net, opt, xs[rank][0], ys[rank][0], S, data_parallel=True)
+step = GraphedTrainStep(net, opt, xs[rank][0], ys[rank][0], S, data_parallel=True,
+                        grad_dtype=torch.bfloat16 if g16 else torch.float32)
 for t in range(T):
     step.step(xs[rank][t], ys[rank][t], beta(t))
 torch.cuda.synchronize()
@@ -663,24 +690,36 @@ if rank == 0:
         ropt.step()
     for (k, a), (_, b) in zip(ref.state_dict().items(), net.state_dict().items()):
         err = float((a - b).abs().max())
-        assert err <= 2e-5 * float(a.abs().max()), (k, err)
+        if not g16:
+            assert err <= 2e-5 * float(a.abs().max()), (k, err)
+        else:
+            # bf16 bucket: each rank's finished gradient and the collective's sum are rounded to 8 significant bits.  Adam's
+            # update is the NORMALISED m / sqrt(v) (about +-lr per step early on), so an element whose per-rank gradients
+            # nearly cancel -- the rounding of the terms then exceeds their sum -- can step the other way: the bound per
+            # element is Adam's own (2 lr per step), what is small is the share of such elements, i.e. the L2 distance of
+            # the parameter displacement from the fp32-bucket run's (stated tolerance: 10 %)
+            d_ref, d_got = (a - init[k].to(a.device)).double(), (b - init[k].to(a.device)).double()
+            rel = float((d_got - d_ref).norm() / (d_ref.norm() + 1e-30))
+            print(f"bf16 bucket {{k}}: max |dp| {{err:.2e}}, relative L2 of the displacement {{rel:.3e}}", flush=True)
+            assert err <= 2.0 * T * 1e-3 * 1.0001 and rel <= 0.10, (k, err, rel)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
-@pytest.mark.parametrize("variant", ["bbb", "lr"])
+@pytest.mark.parametrize("variant", ["bbb", "lr", "bbb-bf16", "lr-bf16"])
 def test_data_parallel_train_step_two_ranks(tmp_path, variant):
     """F2, second half: GraphedTrainStep(data_parallel=True) on 2 ranks (both on this one GPU, so
     gloo instead of RCCL): one flat gradient bucket, one sum all-reduce per step between the two
     captured graphs; replicas stay identical and match a single-process run that averages the
-    ranks' gradients."""
+    ranks' gradients.  `-bf16`: the bucket is all-reduced in bf16 (half the bytes on the wire) and Adam reads the bf16
+    sums: replicas still identical, parameters within the stated bound of the fp32-bucket reference."""
     import os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_worker.py"
     script.write_text(DP_WORKER.format(repo=repo))
     port = str(31500 + (os.getpid() % 2000))
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, variant], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port] + variant.split("-"), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
