@@ -407,30 +407,60 @@ __global__ __launch_bounds__(256) void stage_inputs_kernel(const char* __restric
 __global__ __launch_bounds__(256) void mc_softmax_mean_kernel(const float* __restrict__ logits, int S, int B, int C,
                                                               float scale, float* __restrict__ probs,
                                                               long long* __restrict__ preds) {
+  // A wave per batch row; lane c owns classes c, c + 64, ...  The mean is kept in REGISTERS per 64-class chunk and the
+  // samples' logits are fetched eight at a time (independent loads): the first version added every sample into probs in
+  // global memory -- a dependent load / store round trip per sample, 11.8 us for 10 samples of 128 x 10 logits.
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= B) return;                                    // wave-uniform
   float* out = probs + (size_t)row * C;
-  for (int c = lane; c < C; c += 64) out[c] = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float* lg = logits + ((size_t)s * B + row) * C;
-    float mx = -3.0e38f;
-    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[c]);
+  float best = -1.f;
+  int bi = 0x7fffffff;
+  if (C <= 64) {
+    // the common case (10 classes): one class per lane, the whole softmax of a sample inside the wave
+    float acc = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 8) {
+      float v[8];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    float se = 0.f;
-    for (int c = lane; c < C; c += 64) se += expf(lg[c] - mx);
-    se = wave_sum(se);
-    const float inv = scale / se;                          // out / test_samples (class_task.py:85)
-    for (int c = lane; c < C; c += 64) out[c] += expf(lg[c] - mx) * inv;   // lane c owns out[c]: no race
-  }
-  if (preds) {                                             // argmax, lowest index on ties
-    float best = -1.f;
-    int bi = 0x7fffffff;
+      for (int j = 0; j < 8; ++j)
+        v[j] = (s0 + j < S && lane < C) ? logits[((size_t)(s0 + j) * B + row) * C + lane] : -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (s0 + j < S) {                                  // wave-uniform
+          float mx = v[j];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+          const float e = lane < C ? expf(v[j] - mx) : 0.f;
+          const float se = wave_sum(e);
+          acc += e * (scale / se);                         // out / test_samples (class_task.py:85)
+        }
+      }
+    }
+    if (lane < C) {
+      out[lane] = acc;
+      best = acc;
+      bi = lane;
+    }
+  } else {
+    for (int c = lane; c < C; c += 64) out[c] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* lg = logits + ((size_t)s * B + row) * C;
+      float mx = -3.0e38f;
+      for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float se = 0.f;
+      for (int c = lane; c < C; c += 64) se += expf(lg[c] - mx);
+      se = wave_sum(se);
+      const float inv = scale / se;
+      for (int c = lane; c < C; c += 64) out[c] += expf(lg[c] - mx) * inv;   // lane c owns out[c]: no race
+    }
     for (int c = lane; c < C; c += 64) {
       const float v = out[c];
       if (v > best) { best = v; bi = c; }
     }
+  }
+  if (preds) {                                             // argmax, lowest index on ties
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const float ov = __shfl_xor(best, off, 64);
