@@ -1086,10 +1086,10 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
       } else {
         if (h == 0)
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                       : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(xa));
+                       : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
         else
           asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
-                       : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(xa));
+                       : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
       }
       if (!tune_nomfma) {
@@ -1232,6 +1232,265 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
   bbb_gemm_body<NW, SIG, EPS>(p, xt, bias_s);
 }
 
+// ------------------------------------------------------------------------------------------
+// K1b2 -- the block GEMM form with the PARAMETERS shared through LDS as well (hoisted sigma only).
+// With its prefetch repaired K1b is bound by the bytes its CUs pull from L2 as much as by its vector work
+// (tools/k1b_ablate.py, 1200 x 1200, 256 pairs: 383 us with on-chip eps and statistics, 372 with eps = 0; without the
+// (mu, sigma) register loads 225; without the x DMA 259; with neither 174): every (64-feature group, pair) block re-reads
+// its group's 16 KiB of (mu, sigma) per k-step from L2 although all pairs of the launch use the same parameters.  Here a
+// block is NF feature waves x SB PAIRS (a pair = one (minibatch | MC sample, 128-row batch block) unit): the NF x 4 KiB
+// of (mu, sigma) of a k-step are brought ONCE per block by LDS-DMA and read by the SB waves that need them, each pair's
+// 8 KiB x tile by LDS-DMA as before.  Per pair and k-step the block pulls 16 / SB + 8 KiB through its CU instead of 24,
+// and a wave holds no parameter registers across the generator work.
+//   LDS per buffer: [NF tiles][mu lo | mu hi | sigma lo | sigma hi][64 lanes] x 16 B, then [SB pairs][8 batch tiles]
+//   [64 lanes] x 16 B; every piece is one lane-linear 1 KiB DMA wave-instruction whose lane l fetches exactly the 16
+//   bytes lane l of the consuming wave reads back with one ds_read_b128 (conflict-free by construction).
+// Everything else -- epsilon map, statistics, epilogue -- is K1b's; the per-step statistics are summed two lanes-worth at a
+// time (packed fp32 FMAs), so they agree with K1b's to fp32 summation order, the outputs bit for bit.
+template <int NF, int SB, int EPS>
+__global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
+  constexpr int NW = NF * SB;
+  constexpr int WPW = 4 / SB;                 // parameter pieces (of a tile's four) each of the SB waves of a tile brings
+  constexpr int XPW = 8 / NF;                 // x pieces (batch tiles of its pair) each of the NF waves of a pair brings
+  static_assert(SB == 1 || SB == 2 || SB == 4, "pairs per block");
+  static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
+  // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
+  __shared__ __attribute__((aligned(16))) float4 sm_all[2 * (NF * 256 + SB * 512) + NW * 4];
+  float4 (*sm)[NF * 256 + SB * 512] = reinterpret_cast<float4 (*)[NF * 256 + SB * 512]>(sm_all);
+  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + 2 * (NF * 256 + SB * 512));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fw = wave % NF, sb = wave / NF;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B;
+  const int mbs = (B + 127) >> 7;
+  const int U = p.S * mbs;
+  int tb, ub, in_;
+  if (!xcd2d_work_item(p.xc, tb, ub, in_)) return;             // block-uniform
+  const int unit_raw = ub * SB + sb;
+  const bool active = unit_raw < U;                           // the last block of a group may hold fewer than SB pairs
+  const int unit = active ? unit_raw : U - 1;
+  const int s = unit / mbs, mb = unit - s * mbs;
+  const int tile = tb * NF + fw;
+  const int n = tile * 16 + r;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 1);
+  const int m0 = mb * 128;
+  const int ksteps = (K + 31) >> 5;
+  const uint32_t gs = global_sample(p, s);
+  const bool do_stats = p.want_stats && mb == 0 && active;
+  const bool do_ls = do_stats && s == 0;
+  const bool do_dump = mb == 0 && active;
+  const int gpr = (K + 3) >> 2;
+  const uint32_t wid = p.layer_id * 4u;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+  const int T = (N + 15) >> 4;
+
+  if (do_stats && tb == 0 && unit == 0 && fw == 0 && lane == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
+
+  // ---- staging.  Parameter pieces of tile fw: piece j in {mu lo, mu hi, sigma lo, sigma hi}; wave (fw, sb) brings pieces
+  // sb * WPW .. + WPW - 1.  x pieces of pair sb: batch tiles fw, fw + NF, ...
+  const size_t wrow = (size_t)nc * K;
+  size_t xrow[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) xrow[i] = (size_t)min(m0 + (fw + i * NF) * 16 + r, B - 1) * K;
+  auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+    const int kk = min(t * 32 + q * 8, K - 8);
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+#ifdef BNN_TUNE
+      const int j = ((p.tune & 64) ? (SB - 1 - sb) : sb) * WPW + i;
+#else
+      const int j = sb * WPW + i;                               // wave-uniform
+#endif
+      const float* src = ((j & 2) ? p.w_sigma : p.w_mu) + wrow + kk + (j & 1) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)&sm[buf][(fw * 4 + j) * 64], 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
+                                       (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + (sb * 8 + fw + i * NF) * 64], 16, 0, 0);
+    }
+  };
+
+  // bias of this wave's tile: eps now, applied in the epilogue
+  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
+  if (q == 0 && n_ok) {
+    bmu_pre = p.b_mu[n];
+    brho_pre = p.b_rho[n];
+    beps_pre = bias_eps(p, n, s, gs, do_dump);
+  }
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
+
+  // One k-step.  FULL (block-uniform, compile-time in the body): every lane of the block holds real weights in this step --
+  // all four feature tiles inside N and the step's 32 k inside K -- so the edge masks (11 v_cndmask per step) are
+  // compiled out; the statistics and w run two lanes-worth per instruction (v_pk_fma_f32).  The kernel is bound by its
+  // vector instruction stream once the parameters come through LDS (tools/k1b_ablate.py), so every one of them counts.
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  auto step = [&](int t, auto full_) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_)::value;
+    const int k = t * 32 + q * 8;
+    const bool lane_ok = FULL || (n_ok && k < K);
+    if (t + 1 < ksteps) stage(t + 1, (t + 1) & 1);               // buffer (t+1)&1 was last read in step t-1 (barrier since)
+    // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
+    // flight that may alias it -- s_waitcnt vmcnt(0) right behind the prefetch this step has just issued -- although
+    // buffer t & 1 was complete at the last barrier.  The "+v" operands of the wait tie the consumers to it; the outputs
+    // are early-clobber: a result register must not be the address register of a later read of the same statement.
+    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[t & 1][0];
+    const uint32_t pa = lbase + (uint32_t)((fw * 256 + lane) * 16);
+    f32x4 m_lo, m_hi, g_lo, g_hi;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                 : "=&v"(m_lo), "=&v"(m_hi), "=&v"(g_lo), "=&v"(g_hi) : "v"(pa));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m_lo), "+v"(m_hi), "+v"(g_lo), "+v"(g_hi));
+    const f32x2 mu2[4] = {{m_lo[0], m_lo[1]}, {m_lo[2], m_lo[3]}, {m_hi[0], m_hi[1]}, {m_hi[2], m_hi[3]}};
+    const f32x2 sg2[4] = {{g_lo[0], g_lo[1]}, {g_lo[2], g_lo[3]}, {g_hi[0], g_hi[1]}, {g_hi[2], g_hi[3]}};
+    float e[8];
+    if (EPS == BNN_EPS_PHILOX) {
+      const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
+      philox_normal4(g, gs, wid, p.k0, p.k1, e);
+      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+    } else if (EPS == BNN_EPS_MEMORY) {
+      load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    }
+    if (p.eps_w_dump && do_dump) store8<true>(p.eps_w_dump + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
+    f32x2 w2[4], e2v = {0.f, 0.f}, av = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 ev = {e[2 * j], e[2 * j + 1]};
+      w2[j] = __builtin_elementwise_fma(sg2[j], ev, mu2[j]);
+      e2v = __builtin_elementwise_fma(ev, ev, e2v);
+    }
+    if (do_stats) {
+      float a, ls = 0.f;
+      if (p.prior_kind == BNN_PRIOR_GAUSS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av = __builtin_elementwise_fma(w2[j], w2[j], av);
+        a = av[0] + av[1];
+      } else {
+        a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a = add_log(a, mix_p(p, w2[j][0]));
+          a = add_log(a, mix_p(p, w2[j][1]));
+        }
+      }
+      if (do_ls) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ls = add_log(ls, sg2[j][0]);
+          ls = add_log(ls, sg2[j][1]);
+        }
+      }
+      const float e2 = e2v[0] + e2v[1];
+      s_e2 += lane_ok ? e2 : 0.f;
+      s_a += lane_ok ? a : 0.f;
+      s_ls += lane_ok ? ls : 0.f;
+    }
+    bf16x8 wa;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wa[2 * j] = lane_ok ? (__bf16)w2[j][0] : (__bf16)0.f;
+      wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
+    }
+    const uint32_t xa = lbase + (uint32_t)((NF * 256 + sb * 512 + q * 16 + r) * 16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 x0, x1, x2, x3;
+      if (h == 0)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
+      else
+        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+      acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+      acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+      acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+    }
+    // this wave's DMA pieces of step t + 1 have landed and its LDS reads of buffer t & 1 are back; then the block meets
+    // (a bare s_barrier: __syncthreads()'s fence would add the same vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  {
+    const bool tiles_full = (tb * NF + NF) * 16 <= N;           // block-uniform
+    const int full_steps = tiles_full ? (K >> 5) : 0;           // steps whose 32 k are all inside K
+    int t = 0;
+#pragma nounroll
+    for (; t < full_steps; ++t) step(t, std::true_type{});
+#pragma nounroll
+    for (; t < ksteps; ++t) step(t, std::false_type{});
+  }
+
+  // ---- epilogue: bias, stats, store (no cross-wave reduction)
+  if (q == 0) {
+    float b = 0.f;
+    if (n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    bias_s[wave][r] = b;
+  }
+  if (do_stats) {
+    const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
+    if (lane == 0 && tile < T) p.ws[1 + (size_t)s * T + tile] = make_float4(a, b, cc, 0.f);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int nb = tile * 16 + q * 4;
+  const bool vec_ok = (N & 3) == 0;
+  float bq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+  if (nb < N) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int brow = m0 + m * 16 + r;
+      if (brow < B) {
+        f32x4 v = acc[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o = v[i] + bq[i];
+          if (p.relu) o = fmaxf(o, 0.f);
+          v[i] = o;
+        }
+        const size_t yoff = ((size_t)s * B + brow) * N + nb;
+        if (p.y_bf16) {
+          __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
+          if (vec_ok) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            *reinterpret_cast<bf16x4*>(yp) = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = (__bf16)v[i];
+          }
+        } else {
+          float* yp = reinterpret_cast<float*>(p.y) + yoff;
+          if (vec_ok) {
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nb + i < N) yp[i] = v[i];
+          }
+        }
+      }
+    }
+  }
+}
+
 // The block GEMM carrying an independent sampling job (bnn_bbb_fwd_args.rider) as extra 256-thread blocks behind its
 // own (whose count is a multiple of 8, so the XCD-aware work order of the layer's blocks is unchanged).
 template <bool SIG, int EPS>
@@ -1313,12 +1572,17 @@ struct BbbPlan {
   int R, nw, mt;    // TILE: k-range classes, waves per block, 16-row batch tiles per block
   int tiles;        // TILE: feature tiles
   int ksl;          // GEMM_KSLICE: slices
+  int pairs;        // GEMM: (sample, batch block) units per block (K1b2; 1 = K1b)
   long blocks;
   size_t lds;
 };
 
 constexpr size_t kL2WeightBudget = 2560 * 1024;   // of an XCD's 4 MiB L2: the (mu, rho | sigma) of the feature groups a class of the
                                                   // 2-D work order keeps resident while the units' x tiles stream through
+#ifndef BNN_GEMM_PAIRS
+#define BNN_GEMM_PAIRS 2
+#endif
+constexpr int kGemmPairs = BNN_GEMM_PAIRS;   // K1b2: units that share a block's parameter tiles
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
 constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
 constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
@@ -1458,6 +1722,19 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
   pl.ksl = form == BNN_FORM_GEMM_KSLICE ? ksl : 1;
   pl.blocks = gemm_blocks * pl.ksl;
   pl.lds = 2 * 8 * 64 * 16 + 4 * 16 * sizeof(float);
+  pl.pairs = 1;
+  // K1b2: the plain block-GEMM form with hoisted sigma and no rider shares the parameters of a k-step between
+  // kGemmPairs (minibatch | sample, batch block) units of one block through LDS
+  bool pairs_on = true;
+#ifdef BNN_TUNE
+  if (const char* v = getenv("BNN_TUNE_PAIRS")) pairs_on = atoi(v) != 0;
+#endif
+  if (pairs_on && form == BNN_FORM_GEMM && a->w_sigma && !a->rider && (long)S * mbs >= 2 * kGemmPairs) {
+    pl.pairs = kGemmPairs;
+    pl.nw = 4 * kGemmPairs;
+    pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + kGemmPairs - 1) / kGemmPairs);
+    pl.lds = 2 * (4 * 256 + kGemmPairs * 512) * 16 + pl.nw * 16 * sizeof(float);
+  }
   return BNN_OK;
 }
 
@@ -1645,7 +1922,14 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
       k.ks_ticket = reinterpret_cast<uint32_t*>(base);
       k.ks_part = reinterpret_cast<float4*>(base + split_ticket_bytes(pl.blocks / pl.ksl));
     }
-    if (ride) {
+    if (pl.pairs > 1) {
+      const int ub = (int)(((long)a->n_samples * ((a->batch + 127) / 128) + pl.pairs - 1) / pl.pairs);
+      k.xc = xcd2d_make((a->out_features + 63) / 64, ub, 1, (size_t)64 * K * 8, kL2WeightBudget);
+      const dim3 grid2((unsigned)(((pl.blocks + 7) / 8) * 8)), block2(pl.nw * 64);
+      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_PHILOX>), grid2, block2, 0, stream, k);
+      else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_MEMORY>), grid2, block2, 0, stream, k);
+      else hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_ZERO>), grid2, block2, 0, stream, k);
+    } else if (ride) {
       const unsigned n_main = grid.x;
       const dim3 grid_r(n_main + (unsigned)rider_blocks);
 #define BNN_GEMM_EPS(KERNEL, SIGV, ...)                                                                        \

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
       f32x4 f0, f1, g0, g1;
 #define BNN_LDS2(a, b, O)                                                                         \
   asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                   \
-               : "=v"(a), "=v"(b)                                                                 \
+               : "=&v"(a), "=&v"(b)                                                                \
                : "v"(la), "n"((O)), "n"((O) + 1024))
 #define BNN_LGKM(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b))
 #ifdef BNN_TUNE

@@ -287,7 +287,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     achieved = abytes / (us * 1e-6) / 1e9
     flops = n * (4 if lr else 2) * batch * dims[1] * dims[1]
     form = {1: "tile", 2: "gemm", 3: "gemm_kslice"}[plan["form"]]
-    kname = {("bbb", "tile"): "K1a bbb_fwd_kernel", ("bbb", "gemm"): "K1b bbb_fwd_gemm_kernel",
+    kname = {("bbb", "tile"): "K1a bbb_fwd_kernel",
+             ("bbb", "gemm"): "K1b2 bbb_fwd_gemm2_kernel (parameters and x through LDS, 2 pairs per block)" if plan["waves"] == 8 else "K1b bbb_fwd_gemm_kernel",
              ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
              ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel"}[("lr" if lr else "bbb", form)]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -310,7 +311,7 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
     costs ~80 VALU wave-instructions per 8 sampled weights.  Price the launch against the VECTOR-ISSUE roof from the
     kernel's own instruction mix (profiles/isa_mix.json, tools/make_isa_mix.py): issue cycles of one k-step of one wave
     x the wave-steps of the launch, against 1024 SIMDs x 2.4 GHz; the SURVEY 8(d) HBM figure stays beside it."""
-    key = f"bbb_fwd_gemm_kernel<4,{'true' if sig else 'false'}>"
+    key = "bbb_fwd_gemm2_kernel<4,2,philox>" if roof["plan"]["waves"] == 8 else f"bbb_fwd_gemm_kernel<4,{'true' if sig else 'false'},philox>"
     hbm = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
     hbm["note"] = "SURVEY 8(d) algorithmic bytes (un-amortised: 8 B/param per (minibatch, sample) pair) over the launch time: an accounting " \
                   "convention, not the binding resource -- the pairs of a launch share (mu, sigma) through L2 (see traffic)"
@@ -338,7 +339,7 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))
         for k, v in pm.items():
-            if "bbb_fwd_gemm_kernel" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
+            if "bbb_fwd_gemm" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
                     v.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
                 roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
                                        "key": k, "source": "profiles/pmc.json (rocprofv3 --pmc, tools/collect_pmc.py)"}

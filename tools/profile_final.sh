@@ -16,7 +16,7 @@ $P stats bbb_S8 --samples 8 --group 1 &&
 $P stats wide_B4096_S4 --net wide --batch 4096 --samples 4 --group 1 &&
 $P stats wide_B1024_S4 --net wide --batch 1024 --samples 4 --group 1 &&
 $P statspy train_step tools/train_step_bench.py 2 graph &&
-$P traffic bbb256 bbb_1200_n256_b128_bf16 bbb_fwd_gemm_kernel &&
+$P traffic bbb256 bbb_1200_n256_b128_bf16 bbb_fwd_gemm &&
 $P traffic lr256 lr_1200_n256_b128_bf16 lr_fwd_gemm_kernel --variant lr &&
 $P traffic bbbS8 bbb_1200_n8_b128_bf16 bbb_fwd_gemm --samples 8 --group 1 &&
 $P traffic wide4096 block_gemm_4096_n4_b4096_bf16 bbb_block_gemm_kernel --net wide --batch 4096 --samples 4 --group 1 &&
