@@ -3,7 +3,7 @@
 
 bench.py prices the kernel that is VALU-bound (K1b: the on-chip Philox / Box-Muller generator feeding the matrix core)
 against the vector-issue roof with these counts: issue cycles per k-step and wave = 2 x plain VALU + 8 x transcendental
-+ 4 x 32-bit integer multiply (v_mad_u64_u32 ...) wave-instructions, the per-SIMD throughput costs measured by
++ 7 x 32-bit integer multiply (v_mad_u64_u32 ...) wave-instructions, the per-SIMD throughput costs measured by
 tools/ubench.hip (profiles/r02_ubench_generator.log: 16 fma + 16 add = 53 cycles per SIMD at 3 waves -> 1.7 per
 instruction; box_muller x2 = 8 transcendentals + ~16 VALU = 99; Philox4x32-10 = 20 multiplies + 40 xor + ... = 164).
 Compiles the kernel sources to gfx950 assembly here (hipcc -S, no GPU needed) and picks, per kernel, the loop with
@@ -31,7 +31,7 @@ KERNELS = {   # key -> (source file, mangled-name substring, family of bench.KER
     "bbb_fwd_gemm_kernel<4,false,philox>": ("bbb_linear.hip", "bbb_fwd_gemm_kernelILi4ELb0ELi0", "bbb"),
     "lr_fwd_gemm_kernel<16,true,2>": ("lr_linear.hip", "lr_fwd_gemm_kernelILi16ELb1ELi2", "lr"),
 }
-CYCLES = {"valu": 2, "trans": 8, "imul": 4}
+CYCLES = {"valu": 2, "trans": 8, "imul": 7}   # ubench: 16 v_mad_u64_u32 + 32 v_xor = 170 cycles per SIMD wave-slot -> 6.6 per multiply
 
 
 def loops(path, kname):
