@@ -23,3 +23,11 @@ $P traffic wide4096 block_gemm_4096_n4_b4096_bf16 bbb_block_gemm_kernel --net wi
 $P pmc bbb256 bbb_g256 "$PMC" &&
 $P pmc lr256 lr_g256 "$PMC" --variant lr &&
 $P pmc wide4096 wide_B4096 "$PMC" --net wide --batch 4096 --samples 4 --group 1
+# harness logs behind DESIGN.md 4 (development binaries are built in the container and travel with the snapshot)
+PROF=gpurun_out/profiles
+( tools/ubench.out > $PROF/${TAG}_ubench_generator.log 2>&1 ) || true
+( for pz in 1 0; do echo "== BNN_TUNE_PAIRS=$pz (1: K1b2, 0: K1b)"; BNN_TUNE_PAIRS=$pz BNN_HIP_LIB=$PWD/bayesian-neural-network_amd/bnn_hip/libbnn_hip_tune.so python3 tools/k1b_ablate.py 2>&1 | grep -v amdgpu.ids; done > $PROF/${TAG}_k1b_ablate.log 2>&1 ) || true
+( python3 tools/block_gemm_vs_library.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_block_gemm_vs_library.log ) || true
+( for b in tools/bg_ph2_abl0.out tools/bg_ph2_abl1.out tools/bg_ph2_abl2.out tools/bg_ph2_abl3.out tools/bg_ph2_abl7.out tools/block_gemm_bench_ph4.out; do echo "== $b (BG_ABL: 1 no LDS reads, 2 no LDS-DMA, 4 no barriers; ph4: four-phase form)"; $b 4 1024 4096 4096 20 1 | tail -1; done > $PROF/${TAG}_block_gemm_ablation.log 2>&1 ) || true
+( python3 tools/single_eval_bench.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_single_eval.log ) || true
+( python3 tools/predict_bench.py 10 2>&1 | grep "S=10" > $PROF/${TAG}_predict.log ) || true
