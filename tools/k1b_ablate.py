@@ -29,7 +29,7 @@ for name, kw in (("philox, stats, hoisted sigma", dict(eps_mode=L.EPS_PHILOX, wa
                   layer_id=1, workspace=ws if kw["want_stats"] else None, out=out, form=L.FORM_GEMM, **kw)
     plan = ops.bbb_plan(x, w_mu, w_rho, b_mu, b_rho, **common)
     tunes = [0]
-    if os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and name.startswith("eps = 0, no stats"):
+    if os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and name.startswith("eps = 0, no stats") and plan["waves"] == 4:   # (K1b's knobs)
         # tuning build: BNN_TUNE_K1B bits -- 1 no barrier, 2 no vmcnt wait, 4 no parameter loads, 8 no x DMA, 16 no LDS reads, 32 no MFMAs
         tunes = [0, 1, 3, 4, 8, 12, 16, 32, 48, 60, 63]
     for tn in tunes:
