@@ -381,3 +381,34 @@ def test_launch_plans_are_a_function_of_the_shape():
                         assert 1 <= pl.waves <= 16 and pl.lds_bytes <= 160 * 1024 and pl.blocks >= 1
                         assert pl.form in (L.FORM_TILE, L.FORM_GEMM, L.FORM_GEMM_KSLICE)
                         assert pl.k_classes in (1, 2, 4) and pl.batch_rows in (32, 128)
+
+
+def test_bench_roofline_bookkeeping_without_a_device(tmp_path, monkeypatch):
+    """bench.valu_bound / attach_traffic: the dominant kernel is priced against the vector-issue roof from the committed
+    instruction mix (profiles/isa_mix.json) with the SURVEY 8(d) HBM figure beside it, and profile entries measured on
+    other kernel sources (hash mismatch) are dropped instead of being attached to a kernel that has changed."""
+    import json
+    import bench
+    roof = {"bound": "hbm", "achieved": 7000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.875, "traffic": None,
+            "traffic_key": "bbb_1200_n256_b128_bf16", "plan": {"waves": 8}, "kernel": "k"}
+    out = bench.valu_bound(dict(roof), 1200, 1200, 256, 128, 350.0, True)
+    assert out["bound"] == "valu" and out["hbm_algorithmic"]["frac"] == 0.875 and out["peak"] == pytest.approx(78.6432)
+    mix = json.load(open(os.path.join(REPO, "profiles", "isa_mix.json")))["bbb_fwd_gemm2_kernel<4,2,philox>"]
+    if mix["source_hash"] == bench.source_hash(bench.KERNEL_SOURCES["bbb"]):      # the committed mix is current
+        steps = 75 * 256 * 38                                                    # 16-feature tiles x pairs x k-steps
+        assert out["valu"]["wave_ksteps_per_launch"] == steps
+        want = steps * mix["valu_issue_cycles_per_iteration"] * 32.0 / 350e-6 / 1e12
+        assert out["achieved"] == pytest.approx(want) and 0.0 < out["frac"] < 1.0
+    else:
+        assert out["achieved"] is None and "valu_note" in out
+    # a traffic entry is attached only while its family's sources hash to the recorded value
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "bayesian-neural-network_amd" / "csrc")
+    for f in bench.KERNEL_SOURCES["bbb"]:
+        (tmp_path / "bayesian-neural-network_amd" / "csrc" / f).write_text("// " + f)
+    good = bench.source_hash(bench.KERNEL_SOURCES["bbb"])
+    for h, want in ((good, 123.0), ("0" * 16, None)):
+        json.dump({"bbb_1200_n256_b128_bf16": {"hbm_bytes_per_launch": 123.0, "source_hash": h}}, open(tmp_path / "profiles" / "traffic.json", "w"))
+        got = bench.attach_traffic({"traffic": None, "traffic_key": "bbb_1200_n256_b128_bf16"})
+        assert got["traffic"] == want and ("traffic_note" in got) == (want is None)
