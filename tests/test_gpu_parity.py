@@ -686,6 +686,39 @@ def test_throughput_forms_over_odd_shapes(dev, monkeypatch, shape):
                 assert err <= 3e-3 * (float(ref.abs().max()) + 1e-6), (shape, "BBB", hoist, err)
 
 
+@pytest.mark.parametrize("shape", [(1200, 1200, 128, 5), (784, 1200, 128, 7), (200, 1000, 100, 9), (256, 200, 257, 3), (72, 40, 300, 5),
+                                   (1200, 1200, 128, 64)])
+@pytest.mark.parametrize("prior", [ops.PriorSpec(False, 0.9), ops.PriorSpec(True, 1.0, 0.4, 1.1, 0.05)])
+def test_pair_sharing_form_equals_the_register_form(dev, shape, prior):
+    """K1b2 (block GEMM with the parameters shared through LDS by two (sample, batch block) pairs per block: taken with a
+    hoisted sigma) against K1b (parameters in registers: taken without one) on the same on-chip epsilon: outputs bit for
+    bit, per-sample statistics to fp32 summation order -- an ODD number of pairs (the last block's second pair slot is
+    idle), ragged feature groups (fewer than four tiles in the last group), K % 32 != 0, several batch blocks per sample,
+    Gaussian and mixture prior."""
+    K, N, B, S = shape
+    gen = torch.Generator(device="cpu").manual_seed(K * 13 + N + S)
+    x16 = torch.rand(S, B, K, generator=gen).to(dev).to(torch.bfloat16)
+    wm = ((torch.rand((N, K), generator=gen) - 0.5) * 0.4).to(dev)
+    wr = (torch.rand((N, K), generator=gen) - 5.0).to(dev)
+    bm = ((torch.rand(N, generator=gen) - 0.5) * 0.4).to(dev)
+    br = (torch.rand(N, generator=gen) - 5.0).to(dev)
+    kw = dict(n_samples=S, prior=prior, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX, seed=78,
+              layer_id=1, sample_offset=11, want_stats=True, want_scalars=True, form=L.FORM_GEMM)
+    sig = ops.softplus(wr)
+    p_reg = ops.bbb_plan(x16, wm, wr, bm, br, **kw)
+    p_lds = ops.bbb_plan(x16, wm, wr, bm, br, w_sigma=sig, **kw)
+    assert p_reg["form"] == p_lds["form"] == L.FORM_GEMM and p_reg["waves"] == 4 and p_lds["waves"] == 8
+    pairs = S * ((B + 127) // 128)
+    assert p_lds["blocks"] == ((N + 63) // 64) * ((pairs + 1) // 2)
+    a = ops.bbb_linear_fwd(x16, wm, wr, bm, br, **kw)
+    b = ops.bbb_linear_fwd(x16, wm, wr, bm, br, w_sigma=sig, **kw)
+    assert torch.equal(a["y"], b["y"])
+    close(b["log_prior"], a["log_prior"].cpu().numpy(), rtol=2e-6)
+    close(b["log_q"], a["log_q"].cpu().numpy(), rtol=2e-6)
+    b2 = ops.bbb_linear_fwd(x16, wm, wr, bm, br, w_sigma=sig, **kw)            # and repeatable bit for bit
+    assert torch.equal(b["y"], b2["y"]) and torch.equal(b["log_prior"], b2["log_prior"]) and torch.equal(b["log_q"], b2["log_q"])
+
+
 @pytest.mark.parametrize("shape", [(1200, 1200, 128, 8), (784, 1200, 128, 5), (200, 1000, 100, 4), (256, 200, 257, 7), (1200, 72, 130, 9)])
 def test_kslice_form_equals_the_whole_k_form(dev, shape):
     """K-sliced block GEMM with the fused last-arriver reduce (the form of 4 .. ~100 samples per launch): against the
