@@ -39,12 +39,13 @@
 //     ph0 of tile u issues W1 of tile u+1, ph1: X1 of u+1, ph2: X0 of u+2, ph3: W0 of u+2; every phase waits vmcnt(8)
 //     after its issue = "my two pieces issued four phases ago have landed"; the last two K-tiles issue less, so their
 //     waits count down (8, 8, 6, 4 | 2, 0).
-// What bounds it (tools/block_gemm_bench.hip, BG_ABL builds, 4 x 1024 x 4096 x 4096, one block per CU): the full kernel
-// 103-113 us at 2.00 GHz, matrix pipe 63 % busy; without the LDS reads 102; without the DMA 97; with neither 91; with
-// neither and NO barriers 91-93 us at 2.16 GHz, pipe 67 % busy -- two waves per SIMD issuing nothing but MFMAs on random
-// operands reach 0.59-0.60 of the 2.5 PF figure: the chip holds its clock and its MFMA issue down under that load, and the
-// vendor BLAS runs the same shape at 0.59-0.63 on the same device (tools/block_gemm_vs_library.py).  The schedule's own
-// losses are the 13-18 % between "no reads, no DMA" and the full kernel.
+// What bounds it (tools/block_gemm_bench.hip with BG_ABL builds, tools/mfma_ceiling.hip; 4 x 1024 x 4096 x 4096, one block per
+// CU): the full kernel 104-109 us (0.50-0.53 of 2.5 PF), matrix pipe 63-65 % busy at 2.0-2.1 GHz; without the y stores 98
+// (every block reaches its epilogue at the same time: 33.5 MB at 3.3 TB/s with all matrix pipes idle); without LDS reads,
+// DMA and barriers 90; with nothing but the MFMAs left 81 (0.68).  A bare kernel issuing the same 64 MFMAs per K-tile in
+// the same ping-pong skeleton takes 69-73 us for 64 K-tiles (0.76-0.80; 0.82-0.85 in long launches, pipe 94-97 % busy at
+// 2.1-2.2 GHz): the remaining 12-15 % of this kernel's MFMA-only loop is not explained (DESIGN.md 4 lists what was
+// ruled out).  The vendor BLAS runs the shape at 0.59-0.65 on the same device (tools/block_gemm_vs_library.py).
 // Edges: rows past the batch / feature count are clamped in the source address (computed, never stored); K % 64 != 0:
 // the lanes whose chunk lies past K get an out-of-range buffer offset and the hardware writes zeros (K % 8 == 0 is
 // required, so a chunk is in or out as a whole).
@@ -70,7 +71,7 @@ struct BlockGemmK {
 #define BG_PHASES 2   // 2: two 32-MFMA segments per K-tile (measured faster: 104.5 vs 109.2 us at 4 x 1024 x 4096 x 4096); 4: four 16-MFMA segments
 #endif
 #ifndef BG_ABL
-#define BG_ABL 0   // development ablations (tools/block_gemm_bench.hip only): 1 = no LDS reads, 2 = no LDS-DMA after the prologue, 4 = no barriers
+#define BG_ABL 0   // development ablations (tools/block_gemm_bench.hip only): 1 = no LDS reads after the first K-tile, 2 = no LDS-DMA after the prologue, 4 = no barriers, 8 = no y stores, 16 = fragments read once before the loop (no read code in it), 32 = no s_waitcnt in the loop, 64 = no s_setprio
 #endif
 constexpr int kBgThreads = 512;
 constexpr int kBgLds = 128 * 1024;
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
     return *reinterpret_cast<const bf16x8*>(bg_lds + a);
   };
   bool abl_skip = false;
+  bool abl_pre = false;
   auto read_x = [&](int buf, int mh) __attribute__((always_inline)) {
+    if ((BG_ABL & 16) && !abl_pre) return;
     if ((BG_ABL & 1) && abl_skip) return;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
       for (int kh = 0; kh < 2; ++kh) xf[mi][kh] = rd(xa[kh] + (uint32_t)(buf * 65536 + mh * 16384 + mi * 2048));
   };
   auto read_w = [&](int buf, int nh) __attribute__((always_inline)) {
+    if ((BG_ABL & 16) && !abl_pre) return;
     if ((BG_ABL & 1) && abl_skip) return;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -199,15 +203,17 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
     if (!(BG_ABL & 4)) __builtin_amdgcn_s_barrier(); \
     __builtin_amdgcn_sched_barrier(0);          \
   } while (0)
-#define BG_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define BG_VM(N) do { if (!(BG_ABL & 32)) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); } while (0)
+#define BG_LGKM0() do { if (!(BG_ABL & 32)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define BG_PRIO(P) do { if (!(BG_ABL & 64)) __builtin_amdgcn_s_setprio(P); } while (0)
   // MFMA segment of a phase
 #define BG_MFMA(MH, NH)                                     \
   do {                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    BG_LGKM0();                                             \
     __builtin_amdgcn_sched_barrier(0);                      \
-    __builtin_amdgcn_s_setprio(1);                          \
+    BG_PRIO(1);                                             \
     quad(MH, NH);                                           \
-    __builtin_amdgcn_s_setprio(0);                          \
+    BG_PRIO(0);                                             \
   } while (0)
 
   // ---- prologue: K-tile 0 whole, X0 / W0 of K-tile 1
@@ -224,6 +230,13 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
   }
   BG_BAR();
   if (wr == 1) BG_BAR();                                   // waves 4-7: one barrier behind
+  if (BG_ABL & 16) {
+    abl_pre = true;
+    read_w(0, 0);
+    read_w(0, 1);
+    read_x(0, 0);
+    abl_pre = false;
+  }
 
   // MODE 0: steady (every phase issues); 1: second-to-last K-tile (ph0, ph1 issue); 2: last K-tile (no issue)
   auto ktile = [&](int u, auto mode_) __attribute__((always_inline)) {
@@ -276,12 +289,12 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
       BG_VM(0);
     }
     BG_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BG_LGKM0();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    BG_PRIO(1);
     quad(0, 0);
     quad(0, 1);
-    __builtin_amdgcn_s_setprio(0);
+    BG_PRIO(0);
     BG_BAR();
     read_x(buf, 1);
     if (!LAST) {
@@ -289,12 +302,12 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
       BG_VM(2);
     }
     BG_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BG_LGKM0();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    BG_PRIO(1);
     quad(1, 1);
     quad(1, 0);
-    __builtin_amdgcn_s_setprio(0);
+    BG_PRIO(0);
     BG_BAR();
   };
   int u = 0;
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
         for (int mi = 0; mi < 4; ++mi) {
           const int m = m0 + mh * 128 + wr * 64 + mi * 16 + r;
           if (m >= M || n >= N) continue;
+          if ((BG_ABL & 8) && acc[mh][mi][nh][ni][0] != 12345.678f) continue;
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -378,6 +392,8 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
 #undef BG_BAR
 #undef BG_VM
 #undef BG_MFMA
+#undef BG_LGKM0
+#undef BG_PRIO
 }
 
 // Host side.  Preconditions (checked by the caller, bnn_bbb_linear_fwd): K % 8 == 0, 16-byte aligned x / w, M * K and
