@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1
@@ -23,7 +23,7 @@ EXPORTS = (
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_stage_inputs_cast", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_split_scratch_bytes", "bnn_lr_split_scratch_zero_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
@@ -95,6 +95,7 @@ class LrFwdArgs(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
         ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
         ("hfac_out", C.c_void_p), ("y_bf16_copy", C.c_void_p),
+        ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
     ]
 
 
@@ -214,7 +215,8 @@ def load():
     lib.bnn_status_string.argtypes = [C.c_int]
     lib.bnn_bbb_linear_fwd_workspace_bytes.restype = C.c_size_t
     lib.bnn_bbb_linear_fwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
-    for fn in (lib.bnn_bbb_split_scratch_bytes, lib.bnn_bbb_split_scratch_zero_bytes):
+    for fn in (lib.bnn_bbb_split_scratch_bytes, lib.bnn_bbb_split_scratch_zero_bytes, lib.bnn_lr_split_scratch_bytes,
+               lib.bnn_lr_split_scratch_zero_bytes):
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.bnn_bbb_linear_fwd.restype = C.c_int

@@ -102,6 +102,11 @@ SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per e
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
 
+def lr_use_split(out_features: int, samples: int, batch: int) -> bool:
+    """Worth handing bnn_lr_linear_fwd a split scratch (K3s: at most 160 (32-feature group, sample, batch block) units)."""
+    return out_features >= 64 and out_features % 4 == 0 and ((out_features + 31) // 32) * samples * ((batch + 127) // 128) <= 160
+
+
 def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
     """True when the LR throughput kernel (block GEMM) will run for this layer and enough samples share the
     prepared weights to pay for the extra pass (mirrors the launcher's geometry rule)."""
@@ -226,7 +231,10 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                                         seed=state.seed, layer_id=sp.layer_id, sample_offset=first_sample,
                                         want_kl=want_stats, x_sq=h_sq if lr_sq else None,
                                         out_sq=torch.empty((n_local, h.shape[-2], sp.in_out[1]), dtype=torch.bfloat16,
-                                                           device=h.device) if want_sq else None)
+                                                           device=h.device) if want_sq else None,
+                                        split_scratch=ops.lr_split_scratch_cached(n_local, h.shape[-2], sp.in_out[1], h.device)
+                                        if (h.dtype == torch.bfloat16 and wfrag is None and not last and
+                                            lr_use_split(sp.in_out[1], n_local, h.shape[-2])) else None)
                 h_sq = out["y_sq"]
             else:
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
@@ -495,6 +503,11 @@ class GraphedElbo:
                       if (not self.lr and hid == torch.bfloat16 and not self.lib[i] and
                           use_split(sp.in_out[0], sp.in_out[1], S, B)) else None
                       for i, sp in enumerate(self.specs)]
+        # K3s (1-3 samples on a wide LR layer): the K slices of a 32-feature group meet through this scratch; the library's
+        # plan decides whether a launch uses it
+        self.lr_split = [ops.lr_split_scratch(S, B, sp.in_out[1], dev)
+                         if (self.lr and hid == torch.bfloat16 and i < len(self.specs) - 1 and lr_use_split(sp.in_out[1], S, B)) else None
+                         for i, sp in enumerate(self.specs)]
         self.wsigma = [torch.empty_like(sp.m.weight_rho.detach())
                       if (not self.lr and hid == torch.bfloat16 and not lb and hoist_sigma(*sp.in_out, S, B)) else None
                       for sp, lb in zip(self.specs, self.lib)]
@@ -559,7 +572,7 @@ class GraphedElbo:
                                                     **common), dict(workspaces=self.ws, **fin_kw))
                     return
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
-                                  out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], **common)
+                                  out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], split_scratch=self.lr_split[i], **common)
                 h_sq = self.bufs_sq[i]
             elif self.lib[i]:
                 ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,

@@ -120,6 +120,32 @@ def final_scratch(n_samples: int, device) -> torch.Tensor:
     return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
 
 
+def lr_split_scratch(n_samples: int, batch: int, out_features: int, device) -> torch.Tensor:
+    """Scratch for the K-sliced form of K3 (1-3 samples on a wide LR layer): arrival counters (zeroed here, once; launches
+    leave them zero) followed by the fp32 partial tiles.  One scratch serves one launch at a time."""
+    lib = L.load()
+    nbytes = lib.bnn_lr_split_scratch_bytes(n_samples, batch, out_features)
+    t = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+    t[:lib.bnn_lr_split_scratch_zero_bytes(n_samples, batch, out_features) // 4].zero_()
+    return t
+
+
+_lr_split_cache = {}
+
+
+def lr_split_scratch_cached(n_samples: int, batch: int, out_features: int, device) -> torch.Tensor:
+    """The eager path's K3s scratch: one per (device, current stream, shape), as split_scratch_cached."""
+    if torch.cuda.is_current_stream_capturing():
+        return lr_split_scratch(n_samples, batch, out_features, device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, n_samples, batch, out_features)
+    t = _lr_split_cache.get(key)
+    if t is None:
+        if len(_lr_split_cache) >= 16:
+            _lr_split_cache.clear()
+        t = _lr_split_cache[key] = lr_split_scratch(n_samples, batch, out_features, device)
+    return t
+
+
 def lr_workspace(out_features: int, device) -> torch.Tensor:
     nbytes = L.load().bnn_lr_linear_fwd_workspace_bytes(out_features)
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
@@ -325,7 +351,7 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
                   out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, want_hfac: bool = False, form: int = 0,
                   sample_group: int = 0,
-                  sample_group_stride: int = 0):
+                  sample_group_stride: int = 0, split_scratch=None):
     """Argument block of K3 + the result dict + the tensors it points at."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
@@ -387,8 +413,11 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
             raise BnnHipError("want_y16 goes with fp32 y")
         y16 = torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=y.device)
         a.y_bf16_copy = y16.data_ptr()
+    if split_scratch is not None:
+        a.split_scratch = split_scratch.data_ptr()
+        a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
     res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch)
     return a, res, keep
 
 

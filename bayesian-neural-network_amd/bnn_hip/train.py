@@ -91,6 +91,7 @@ class GraphedTrainStep:
         self.counter, self.base = sh["counter"], sh["base"]
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
         self.fin_scratch = ops.final_scratch(self.samples, dev)   # hand-off words of the row-split / K-sliced output layer
+        self._lr_split = {}                                       # layer index -> K3s scratch (owned here: zeroed once, outside capture)
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
         self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
         offs, tot = [], 0
@@ -183,6 +184,18 @@ class GraphedTrainStep:
         finally:
             state.device_counter = None
 
+    def _lr_scratch(self, i, sp, hin):
+        """K3s scratch of LR hidden layer i (None when the launch could not use one): allocated and zeroed at the first
+        forward outside capture (construction warms the step up before it captures); the kernel leaves its counters zero."""
+        from .engine import lr_use_split
+        if hin.dtype != torch.bfloat16 or not lr_use_split(sp.in_out[1], self.samples, hin.shape[-2]):
+            return None
+        if i not in self._lr_split:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self._lr_split[i] = ops.lr_split_scratch(self.samples, hin.shape[-2], sp.in_out[1], hin.device)
+        return self._lr_split[i]
+
     def _chain(self, stop_above_layer0: bool = False):
         """zero_grad -> sample_elbo -> backward, as a hand-made chain of the C-ABI kernels (no autograd).
         Leaves the gradients in p.grad and returns what sample_elbo* returns."""
@@ -257,7 +270,8 @@ class GraphedTrainStep:
                 # no mask pass: the forward saves eps / (2 sqrt(v)) instead of v and the backward no preparation launch
                 hf = i < len(specs) - 1
                 out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=not hf, want_hfac=hf,
-                                        want_y16=self.x16 is not None and i < len(specs) - 1, **common)
+                                        want_y16=self.x16 is not None and i < len(specs) - 1,
+                                        split_scratch=self._lr_scratch(i, sp, hin) if hf else None, **common)
             else:
                 out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True,
                                          want_y16=self.x16 is not None and i < len(specs) - 1, **common)

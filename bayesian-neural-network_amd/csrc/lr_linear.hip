@@ -24,6 +24,7 @@
 #include "bnn_fin.h"
 #include "../../include/bnn_hip.h"
 #include <string.h>
+#include <type_traits>
 
 namespace bnn {
 
@@ -56,6 +57,9 @@ struct LrK {
   const uint32_t* sample_counter;
   int xg;                        // samples sharing one x (x index = s / xg)
   uint32_t sgrp, sgrp_stride;    // sample groups (bnn_lr_fwd_args.sample_group): 0 = none
+  int ksl, nst;                  // K3s: K-range slices per unit, k-steps (of 32) per slice
+  uint32_t* ks_ticket;           // K3s: [unit] arrival counters of a unit's slice blocks, zero between launches
+  float4* ks_part;               // K3s: [unit][slice][wave 8][feature tile 2][mean | variance][64] x 16 B partial tiles
 #ifdef BNN_STAMPS
   unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
 #endif
@@ -82,6 +86,102 @@ __device__ __forceinline__ uint32_t lr_global_sample(const LrK& p, int s) {
 #define LR_STAMP(i)
 #define LR_STAMP_RT(i)
 #endif
+
+// Epilogue of one output item (batch row `brow`, 4 consecutive features from `nb`) of sample s:
+//   y = m + sqrt(v) * eps_act + b  [-> ReLU], with every optional by-product of bnn_lr_fwd_args.
+__device__ __forceinline__ void lr_epilogue_item(const LrK& p, int s, uint32_t gs, int brow, int nb, const f32x4& vm4, const f32x4& vv4,
+                                                 const float* bias4, const float* eps_pre = nullptr) {
+  const int N = p.N, B = p.B;
+  const bool vec_ok = (N & 3) == 0;
+  const int gprN = (N + 3) >> 2;
+  const size_t yoff = ((size_t)s * B + brow) * N + nb;
+  float e4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.eps_mode == BNN_EPS_PHILOX) {
+    if (eps_pre) {                                             // the caller drew them already (same call, earlier)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e4[i] = eps_pre[i];
+    } else {
+      philox_normal4((uint32_t)brow * (uint32_t)gprN + (uint32_t)(nb >> 2), gs, p.layer_id * 4u + 2u, p.k0, p.k1, e4);
+    }
+  } else if (p.eps_mode == BNN_EPS_MEMORY) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (nb + i < N) e4[i] = p.eps_act[yoff + i];
+  }
+  if (p.eps_act_dump) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (nb + i < N) p.eps_act_dump[yoff + i] = e4[i];
+  }
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv4[i]), e4[i], vm4[i]) + bias4[i];
+    if (p.relu) o = fmaxf(o, 0.f);
+    v[i] = o;
+  }
+  if (p.y_sq) {
+    __bf16* qp = reinterpret_cast<__bf16*>(p.y_sq) + yoff;
+    if (vec_ok) {
+      bf16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] * v[i]);
+      *reinterpret_cast<bf16x4*>(qp) = o;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+    }
+  }
+  if (p.v_out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (nb + i < N) p.v_out[yoff + i] = vv4[i];
+  }
+  if (p.hfac) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (nb + i < N) {
+        const float sd = __builtin_sqrtf(vv4[i]);
+        p.hfac[yoff + i] = sd > 0.f ? e4[i] / (2.f * sd) : 0.f;
+      }
+  }
+  if (p.y16) {
+    __bf16* cp = p.y16 + yoff;
+    if (vec_ok) {
+      bf16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+      *reinterpret_cast<bf16x4*>(cp) = o;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) cp[i] = (__bf16)v[i];
+    }
+  }
+  if (p.y_bf16) {
+    __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
+    if (vec_ok) {
+      bf16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+      *reinterpret_cast<bf16x4*>(yp) = o;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) yp[i] = (__bf16)v[i];
+    }
+  } else {
+    float* yp = reinterpret_cast<float*>(p.y) + yoff;
+    if (vec_ok) {
+      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < N) yp[i] = v[i];
+    }
+  }
+}
 
 // MT = batch tiles (of 16 rows) per block: 8, or 2 for a narrow layer (the 10-class output layer is
 // 3 feature tiles: with 128 rows per block three blocks would each ingest all of x; 32-row blocks
@@ -351,8 +451,6 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p) {
   LR_STAMP(6);
 
   // ---- epilogue: y = m + sqrt(v) * eps + b  [-> ReLU]
-  const bool vec_ok = (N & 3) == 0;
-  const int gprN = (N + 3) >> 2;
 #pragma unroll
   for (int ii = 0; ii < NI; ++ii) {
     const int it = threadIdx.x + ii * blockDim.x;
@@ -361,81 +459,7 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p) {
     const int brow = m0 + m * 16 + b;
     const int nb = nt * F + fg * 4;
     if (brow >= B || nb >= N) continue;
-    const size_t yoff = ((size_t)s * B + brow) * N + nb;
-    float e4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.eps_mode == BNN_EPS_PHILOX) {
-      philox_normal4((uint32_t)brow * (uint32_t)gprN + (uint32_t)(nb >> 2), gs, p.layer_id * 4u + 2u, p.k0, p.k1, e4);
-    } else if (p.eps_mode == BNN_EPS_MEMORY) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < N) e4[i] = p.eps_act[yoff + i];
-    }
-    if (p.eps_act_dump) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < N) p.eps_act_dump[yoff + i] = e4[i];
-    }
-    f32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv[ii][i]), e4[i], vm[ii][i]) + lds_bias[fg * 4 + i];
-      if (p.relu) o = fmaxf(o, 0.f);
-      v[i] = o;
-    }
-    if (p.y_sq) {
-      __bf16* qp = reinterpret_cast<__bf16*>(p.y_sq) + yoff;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
-    }
-    if (p.v_out) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < N) p.v_out[yoff + i] = vv[ii][i];
-    }
-    if (p.hfac) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < N) {
-          const float sd = __builtin_sqrtf(vv[ii][i]);
-          p.hfac[yoff + i] = sd > 0.f ? e4[i] / (2.f * sd) : 0.f;
-        }
-    }
-    if (p.y16) {
-      __bf16* cp = p.y16 + yoff;
-      if (vec_ok) {
-        bf16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-        *reinterpret_cast<bf16x4*>(cp) = o;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (nb + i < N) cp[i] = (__bf16)v[i];
-      }
-    }
-    if (p.y_bf16) {
-      __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
-      if (vec_ok) {
-        bf16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-        *reinterpret_cast<bf16x4*>(yp) = o;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (nb + i < N) yp[i] = (__bf16)v[i];
-      }
-    } else {
-      float* yp = reinterpret_cast<float*>(p.y) + yoff;
-      if (vec_ok) {
-        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (nb + i < N) yp[i] = v[i];
-      }
-    }
+    lr_epilogue_item(p, s, gs, brow, nb, vm[ii], vv[ii], lds_bias + fg * 4);
   }
   LR_STAMP(7);
   LR_STAMP_RT(9);
@@ -444,6 +468,302 @@ __device__ __forceinline__ void lr_fwd_body(const LrK& p) {
 template <int MATH, int XDT, int R, int MT>
 __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p) {
   lr_fwd_body<MATH, XDT, R, MT>(p);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3s  the one-evaluation / training form of a wide LR layer (1-3 samples, bf16 math on bf16 x, K % 8 == 0, N % 4 == 0):
+// K-sliced, whole parameter lines.
+//   Why: K3a's block owns 8 features x all of K x 128 rows.  Its gathers use 32 bytes of every 128-byte (mu | rho) line
+//   and every block ingests all of x: 614 KB through one CU's 64 B/clk L1 fill path = 9.6 k cycles before any latency,
+//   12-15 us per 1200 x 1200 layer measured.  Here a block owns 32 FEATURES (one whole line per k row and tensor) x
+//   128 rows x ONE K SLICE of nst <= 13 k-steps: 154 KB per block for the same layer in 152 blocks, no byte fetched
+//   twice by a CU and none unused.
+//   phase 1 (waves split the slice's k-steps): a step's (mu, rho) tile = 32 k rows x 128 B, four lane-linear 1 KiB
+//     loads per tensor; sigma^2, the KL sums and the two bf16 operand tiles [k][feature] (64-byte rows, the halves of
+//     rows 8..15 / 24..31 swapped so that the transposed reads below are conflict-free) into LDS;
+//   phase 2 (waves split the batch rows, 16 each): A operands by ds_read_b64_tr_b16 (the [in, out] layout is k-major:
+//     the hardware transposes a 4 x 16 block per 16-lane group), B operand = the wave's own x fragment of the step,
+//     issued with every other load of the wave at kernel start, x^2 formed in registers: 4 MFMAs per step;
+//   hand-off: each wave stores its four fp32 partial tiles write-through (sc1, lane-linear 1 KiB), one lane takes the
+//     unit's ticket behind the block barrier, and the block that arrives LAST adds the slices up in slice order (its
+//     own from registers, the others by sc1 loads) and runs the epilogue -- one launch, bitwise reproducible, nobody
+//     waits (the protocol of K1b's K-sliced form, bbb_linear.hip).
+// KL: one workspace entry per (feature group, slice) from the blocks of sample 0 / batch block 0.
+constexpr int kLrsMaxSteps = 13;   // k-steps per slice (x fragments a wave keeps in registers)
+constexpr int kLrsMaxSlices = 8;
+
+__global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
+  constexpr int NW = 8, XS = kLrsMaxSteps;
+  __shared__ __attribute__((aligned(16))) char tiles[XS * 4096];   // [step][mean | variance][32 k][64 B]
+  __shared__ float lds_bias[32];
+  __shared__ float lds_red[3 * NW];
+  __shared__ uint32_t last_s;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N, B = p.B, KSL = p.ksl;
+  const int G = (N + 31) >> 5, mbs = (B + 127) >> 7;
+  int item;
+  if (!xcd_work_item(G * p.S * mbs * KSL, item)) return;       // block-uniform
+  const int ks = item % KSL, unit = item / KSL;
+  const int g = unit / (p.S * mbs), s = (unit / mbs) % p.S, mb = unit % mbs;
+  const int n0 = g * 32, m0 = mb * 128;
+  const int mtiles = min(8, (B - m0 + 15) >> 4);
+  const int ksteps = (K + 31) >> 5;
+  const int t_begin = ks * p.nst, nst = max(0, min(p.nst, ksteps - t_begin));   // this slice's steps (may be none)
+  const uint32_t gs = lr_global_sample(p, s);
+  const bool do_kl = p.want_kl && mb == 0 && s == 0;
+  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+
+  if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(G * KSL), 0.f, 0.f, 0.f);
+
+  LR_STAMP(0);
+  LR_STAMP_RT(8);
+  // bias of the group (last wave, lanes 0..31): its loads go first, its noise is drawn while everything is in flight
+  const bool bias_lane = wave == NW - 1 && lane < 32 && n0 + lane < N;
+  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
+  if (bias_lane) {
+    bmu_pre = p.b_mu[n0 + lane];
+    brho_pre = p.b_rho[n0 + lane];
+    if (p.eps_mode == BNN_EPS_MEMORY) beps_pre = p.eps_b[(size_t)s * N + n0 + lane];
+  }
+  // ---- every load of the wave, issued before anything is waited for (branch-free: clamped steps re-read a line)
+  // phase-1 share of this wave: the slice's 8-row groups wave, wave + 8, ... (4 per k-step: a lane-linear 1 KiB load
+  // of 8 k rows x 32 features per tensor)
+  constexpr int PG = (4 * XS + NW - 1) / NW;                   // groups per wave at most
+  const int c8 = lane & 7, rr = lane >> 3;                     // 16-byte chunk (4 features) and row within the group
+  const int nf = n0 + c8 * 4;                                  // first of the lane's 4 features
+  const bool nf_ok = nf < N;                                   // N % 4 == 0: a chunk is in or out as a whole
+  const int nfc = min(nf, N - 4);
+  const int ngr = nst * 4;
+  float4 pm[PG], pr[PG];
+#pragma unroll
+  for (int u = 0; u < PG; ++u) {
+    const int rg = min(wave + u * NW, max(ngr - 1, 0));
+    const size_t off = (size_t)min(t_begin * 32 + rg * 8 + rr, K - 1) * N + nfc;
+    pm[u] = *reinterpret_cast<const float4*>(p.w_mu + off);
+    pr[u] = *reinterpret_cast<const float4*>(p.w_rho + off);
+  }
+  // phase-2 x fragments: rows 16 wave + r, k = 32 (t_begin + j) + 8 q
+  const __bf16* xrow = xs + (size_t)min(m0 + wave * 16 + r, B - 1) * K;
+  float4 xf[XS];
+#pragma unroll
+  for (int j = 0; j < XS; ++j) xf[j] = *reinterpret_cast<const float4*>(xrow + min((t_begin + min(j, max(nst - 1, 0))) * 32 + q * 8, K - 8));
+  if (bias_lane && p.eps_mode == BNN_EPS_PHILOX) {
+    const int n = n0 + lane;
+    float e4[4];
+    philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
+    beps_pre = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+  }
+#pragma unroll
+  for (int u = 0; u < PG; ++u) {                               // the arithmetic starts HERE: issued loads stay ahead of it
+    asm volatile("" : "+v"(pm[u].x), "+v"(pm[u].y), "+v"(pm[u].z), "+v"(pm[u].w));
+    asm volatile("" : "+v"(pr[u].x), "+v"(pr[u].y), "+v"(pr[u].z), "+v"(pr[u].w));
+  }
+
+  LR_STAMP(1);
+  // ---- phase 1: sigma^2, KL sums, bf16 operand tiles into LDS
+  float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
+  // FULL: every k row of the slice and every feature of the group is real (block-uniform) -- no masks in the arithmetic
+  auto park = [&](auto full_, auto kl_) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_)::value, KL = decltype(kl_)::value;
+#pragma unroll
+    for (int u = 0; u < PG; ++u) {
+      const int rg = wave + u * NW;                            // 8-row group of the slice
+      if (rg < ngr) {
+        const int kk = (rg & 3) * 8 + rr;                      // k row within its step
+        const bool ok = FULL || (nf_ok && (t_begin * 32 + rg * 8 + rr) < K);
+        const float mu4[4] = {pm[u].x, pm[u].y, pm[u].z, pm[u].w};
+        const float rh4[4] = {pr[u].x, pr[u].y, pr[u].z, pr[u].w};
+        bf16x4 mb4, sb4;
+        float ls = 0.f, a2 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sig = softplus(rh4[e]);
+          const float sg2 = sig * sig;
+          if (KL) {
+            ls += ok ? fast_log(sig) : 0.f;
+            a2 += ok ? sg2 : 0.f;
+            m2 += ok ? mu4[e] * mu4[e] : 0.f;
+          }
+          mb4[e] = (__bf16)(ok ? mu4[e] : 0.f);
+          sb4[e] = (__bf16)(ok ? sg2 : 0.f);
+        }
+        s_ls += ls;
+        s_s2 += a2;
+        s_m2 += m2;
+        const int off = (rg >> 2) * 4096 + kk * 64 + ((c8 * 8) ^ (((kk >> 3) & 1) * 32));
+        *reinterpret_cast<bf16x4*>(tiles + off) = mb4;
+        *reinterpret_cast<bf16x4*>(tiles + off + 2048) = sb4;
+      }
+    }
+  };
+  const bool full = n0 + 32 <= N && (t_begin + nst) * 32 <= K;
+  if (full) {
+    if (do_kl) park(std::true_type{}, std::true_type{}); else park(std::true_type{}, std::false_type{});
+  } else {
+    if (do_kl) park(std::false_type{}, std::true_type{}); else park(std::false_type{}, std::false_type{});
+  }
+  LR_STAMP(2);
+  if (wave == NW - 1 && lane < 32) {
+    float b = 0.f;
+    if (bias_lane) {
+      const int n = n0 + lane;
+      const float bsig = softplus(brho_pre);
+      if (p.eps_b_dump && mb == 0 && ks == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
+      b = __builtin_fmaf(bsig, beps_pre, bmu_pre);
+      if (do_kl && ks == 0) {
+        s_ls += fast_log(bsig);
+        s_s2 = __builtin_fmaf(bsig, bsig, s_s2);
+        s_m2 = __builtin_fmaf(bmu_pre, bmu_pre, s_m2);
+      }
+    }
+    lds_bias[lane] = b;
+  }
+  if (do_kl) {
+    const float a = wave_sum(s_ls), b = wave_sum(s_s2), cc = wave_sum(s_m2);
+    if (lane == 0) {
+      lds_red[wave * 3 + 0] = a;
+      lds_red[wave * 3 + 1] = b;
+      lds_red[wave * 3 + 2] = cc;
+    }
+  }
+  __syncthreads();
+  LR_STAMP(3);
+  if (do_kl && threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+    for (int wv = 0; wv < NW; ++wv) {
+      a += lds_red[wv * 3 + 0];
+      b += lds_red[wv * 3 + 1];
+      cc += lds_red[wv * 3 + 2];
+    }
+    p.ws[1 + g * KSL + ks] = make_float4(a, b, cc, 0.f);
+  }
+
+  // ---- phase 2: rows 16 wave .. + 15 against the slice's operand tiles (every wave: the transposed reads want EXEC
+  // all ones, and a wave past the batch multiplies clamped rows it never stores)
+  f32x4 acc[2][2];                                            // [feature tile][mean | variance]
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft) acc[ft][0] = acc[ft][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4;
+  // lane 4 q' + p' of a 16-lane group kg supplies row 8 kg + (4 h) + q', columns 4 p' .. 4 p' + 3 of the feature tile
+  const int tr_off = (q * 8 + ((lane & 15) >> 2)) * 64;
+  const int tr_col = (lane & 3) * 8, tr_sw = (q & 1) * 32;
+  auto operands = [&](int j, bf16x8 (&wa)[2][2]) __attribute__((always_inline)) {   // [feature tile][mean | variance] of step j
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int a0 = j * 4096 + tr_off + ((ft * 32 + tr_col) ^ tr_sw);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(tiles + a0 + st * 2048));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4)(tiles + a0 + st * 2048 + 256));
+        wa[ft][st] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  // NS steps fully unrolled and branch-free (a step past the slice multiplies a zeroed x fragment with the last step's
+  // tiles), the next step's operands read before this step's products
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (__bf16)0.f;
+  auto products = [&](auto ns_) __attribute__((always_inline)) {
+    constexpr int NS = decltype(ns_)::value;
+    bf16x8 wa[2][2][2];                                        // [parity][feature tile][mean | variance]
+    operands(0, wa[0]);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      if (j + 1 < NS) operands(min(j + 1, max(nst - 1, 0)), wa[(j + 1) & 1]);
+      const bf16x8 xb = j < nst ? __builtin_bit_cast(bf16x8, xf[j]) : zero8;
+      bf16x8 x2b;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 pr2 = {(float)xb[e], (float)xb[e + 1]};
+        pr2 = pr2 * pr2;
+        x2b[e] = (__bf16)pr2[0];
+        x2b[e + 1] = (__bf16)pr2[1];
+      }
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j & 1][ft][0], xb, acc[ft][0], 0, 0, 0);
+        acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j & 1][ft][1], x2b, acc[ft][1], 0, 0, 0);
+      }
+    }
+  };
+  if (nst > 10) products(std::integral_constant<int, XS>{});
+  else if (nst > 8) products(std::integral_constant<int, 10>{});
+  else if (nst > 4) products(std::integral_constant<int, 8>{});
+  else if (nst > 0) products(std::integral_constant<int, 4>{});
+
+  LR_STAMP(4);
+  // activation noise of the lane's two output items (drawn by whoever runs the epilogue; the last arriver draws it while
+  // the other slices' tiles are in flight)
+  const int brow = m0 + wave * 16 + r;
+  const int gprN = (N + 3) >> 2;
+  float eps_pre[2][4];
+  auto draw_eps = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+      philox_normal4((uint32_t)brow * (uint32_t)gprN + (uint32_t)((n0 + ft * 16 + q * 4) >> 2), gs, p.layer_id * 4u + 2u, p.k0, p.k1, eps_pre[ft]);
+  };
+  // ---- hand-off between the slices of the unit
+  if (KSL > 1) {
+    float4* const unit_part = p.ks_part + (size_t)unit * KSL * (NW * 4 * 64);
+    float4* const mine = unit_part + ((size_t)ks * NW + wave) * (4 * 64) + lane;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (ft * 2 + st) * 64), "v"(acc[ft][st]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tk = __hip_atomic_fetch_add(p.ks_ticket + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_s = (tk == (uint32_t)KSL - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    LR_STAMP(5);
+    LR_STAMP_RT(9);
+    if (last_s == 0u) return;                                  // block-uniform
+    if (threadIdx.x == 0) __hip_atomic_store(p.ks_ticket + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 part[kLrsMaxSlices][4];
+#pragma unroll
+    for (int sl = 0; sl < kLrsMaxSlices; ++sl) {               // every other slice's tiles, one round of loads
+      if (sl < KSL && sl != ks) {                              // block-uniform
+        const float4* src = unit_part + ((size_t)sl * NW + wave) * (4 * 64) + lane;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[sl][m]) : "v"(src + m * 64) : "memory");
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) part[sl][m] = acc[m >> 1][m & 1];
+      }
+    }
+    if (p.eps_mode == BNN_EPS_PHILOX) draw_eps();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 sum[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sum[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < kLrsMaxSlices; ++sl)                 // slice order, whoever arrived last
+      if (sl < KSL) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sum[m] += part[sl][m];
+      }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m >> 1][m & 1] = sum[m];
+  } else if (p.eps_mode == BNN_EPS_PHILOX) {
+    draw_eps();
+  }
+  LR_STAMP(6);
+  // ---- epilogue: lane (r, q) of feature tile ft holds batch row m0 + 16 wave + r, features n0 + 16 ft + 4 q ..
+  if (wave < mtiles && brow < B) {
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const int nb = n0 + ft * 16 + q * 4;
+      if (nb < N) lr_epilogue_item(p, s, gs, brow, nb, acc[ft][0], acc[ft][1], lds_bias + ft * 16 + q * 4, eps_pre[ft]);
+    }
+  }
+  LR_STAMP(7);
+  LR_STAMP_RT(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1321,12 +1641,14 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.xg = a->x_per_sample > 0 ? a->x_per_sample : 1;
   k.sgrp = a->sample_group; k.sgrp_stride = a->sample_group_stride;
+  k.ksl = 1; k.nst = 0; k.ks_ticket = nullptr; k.ks_part = nullptr;
   k.w_mu = a->w_mu; k.w_rho = a->w_rho; k.b_mu = a->b_mu; k.b_rho = a->b_rho;
   k.eps_act = a->eps_act; k.eps_b = a->eps_b; k.eps_act_dump = a->eps_act_dump; k.eps_b_dump = a->eps_b_dump;
   k.y = a->y;
   k.x_sq = a->x_sq; k.y_sq = a->y_sq; k.v_out = a->v_out;
   k.y16 = reinterpret_cast<__bf16*>(a->y_bf16_copy);
   k.hfac = a->hfac_out;
+  if ((unsigned)a->form > 3u) return BNN_ERR_ENUM;
   if (a->hfac_out && a->form == BNN_FORM_GEMM) return BNN_ERR_ENUM;
   if (a->y_bf16_copy && (a->y_dtype != BNN_F32 || a->form == BNN_FORM_GEMM)) return BNN_ERR_ENUM;
   k.w_frag = reinterpret_cast<const float4*>(a->w_frag);
@@ -1350,7 +1672,22 @@ struct LrPlan {
   int R, MT, nw;    // K3a: k-range classes, 16-row batch tiles per block, waves;  K3b: nw = 4 or 8
   long total;       // blocks
   size_t lds;
+  int ksl, nst;     // K3s: slices per unit, k-steps per slice
 };
+
+static size_t lr_ticket_bytes(long units) { return (((size_t)units * 4 + 255) / 256) * 256; }
+static long lr_split_units(int n_samples, int batch, int out_features) {
+  return (long)((out_features + 31) / 32) * n_samples * ((batch + 127) / 128);
+}
+extern "C" size_t bnn_lr_split_scratch_zero_bytes(int32_t n_samples, int32_t batch, int32_t out_features) {
+  if (n_samples <= 0 || batch <= 0 || out_features <= 0) return 0;
+  return lr_ticket_bytes(lr_split_units(n_samples, batch, out_features));
+}
+extern "C" size_t bnn_lr_split_scratch_bytes(int32_t n_samples, int32_t batch, int32_t out_features) {
+  if (n_samples <= 0 || batch <= 0 || out_features <= 0) return 0;
+  const long units = lr_split_units(n_samples, batch, out_features);
+  return lr_ticket_bytes(units) + (size_t)units * kLrsMaxSlices * (8 * 4 * 64 * 16);
+}
 
 static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
@@ -1371,6 +1708,37 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
     pl.total = (long)((N + 16 * pl.nw - 1) / (16 * pl.nw)) * a->n_samples * mbs;
     pl.lds = (size_t)(a->w_frag ? 3 : 2) * 2 * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);   // static: the ring of x / x^2 tile pairs + biases
     return BNN_OK;
+  }
+  // K3s: few samples on a wide layer -- 32-feature groups x K slices, so that ~150-300 blocks exist and each pulls
+  // whole parameter lines and a slice of x through its CU (see lr_fwd_kslice_kernel)
+  pl.ksl = 1; pl.nst = 0;
+  {
+    const long units = lr_split_units(a->n_samples, a->batch, N);
+    const int ksteps = (K + 31) / 32;
+    const bool ok = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && (K % 8 == 0) && K >= 64 && (N % 4 == 0) && N >= 64 &&
+                    a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
+                    a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(a->n_samples, a->batch, N) &&
+                    !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
+                    (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE) && units <= 160;
+    if (ok) {
+      int ksl = (int)(160 / units);
+      ksl = ksl < 1 ? 1 : ksl > kLrsMaxSlices ? kLrsMaxSlices : ksl;
+#if defined(BNN_TUNE) || defined(BNN_STAMPS)
+      if (const char* v = getenv("BNN_TUNE_LRKSL")) { const int f = atoi(v); if (f >= 1 && f <= kLrsMaxSlices) ksl = f; }
+#endif
+      while (ksl < kLrsMaxSlices && (ksteps + ksl - 1) / ksl > kLrsMaxSteps) ++ksl;
+      const int nst = (ksteps + ksl - 1) / ksl;
+      ksl = (ksteps + nst - 1) / nst;                          // no empty slices
+      if (nst <= kLrsMaxSteps && units * ksl <= 256) {          // one round of blocks: slices that queue behind each other gain nothing
+        pl.form = BNN_FORM_GEMM_KSLICE;
+        pl.R = 1; pl.MT = 8; pl.nw = 8;
+        pl.ksl = ksl; pl.nst = nst;
+        pl.total = units * ksl;
+        pl.lds = (size_t)kLrsMaxSteps * 4096 + (32 + 24 + 1) * sizeof(float);
+        return BNN_OK;
+      }
+    }
+    if (a->form == BNN_FORM_GEMM_KSLICE) return BNN_ERR_ENUM;  // asked for, not possible
   }
   int R = 1;
   while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
@@ -1415,10 +1783,10 @@ extern "C" int bnn_lr_plan(const bnn_lr_fwd_args* a, bnn_plan* out) {
   out->k_classes = pl.R;
   out->waves = pl.nw;
   out->batch_rows = 16 * pl.MT;
-  out->k_slices = 1;
+  out->k_slices = pl.form == BNN_FORM_GEMM_KSLICE ? pl.ksl : 1;
   out->blocks = (int32_t)pl.total;
   out->lds_bytes = (int32_t)pl.lds;
-  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : 16 * pl.nw;
+  out->features_per_block = pl.form == BNN_FORM_TILE ? 16 / pl.R : pl.form == BNN_FORM_GEMM_KSLICE ? 32 : 16 * pl.nw;
   return BNN_OK;
 }
 
@@ -1433,7 +1801,13 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   const int K = a->in_features, N = a->out_features;
   hipError_t err = hipSuccess;
   const dim3 grid((unsigned)(((pl.total + 7) / 8) * 8)), block(pl.nw * 64);
-  if (pl.form == BNN_FORM_GEMM) {
+  if (pl.form == BNN_FORM_GEMM_KSLICE) {
+    char* base = reinterpret_cast<char*>(a->split_scratch);
+    k.ksl = pl.ksl; k.nst = pl.nst;
+    k.ks_ticket = reinterpret_cast<uint32_t*>(base);
+    k.ks_part = reinterpret_cast<float4*>(base + lr_ticket_bytes(pl.total / pl.ksl));
+    hipLaunchKernelGGL(lr_fwd_kslice_kernel, grid, block, 0, stream, k);
+  } else if (pl.form == BNN_FORM_GEMM) {
 #ifdef BNN_TUNE
     k.tune = getenv("BNN_TUNE_LRFLAGS") ? atoi(getenv("BNN_TUNE_LRFLAGS")) : 0;
 #endif

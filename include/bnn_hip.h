@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 4
+#define BNN_HIP_ABI_VERSION 5
 #define BNN_EPS_MAP_VERSION 2     /* 1: Philox4x32-10 (rounds 1-2); 2: Philox4x32-7 */
 #define BNN_PHILOX_ROUNDS 7
 
@@ -331,9 +331,18 @@ typedef struct bnn_lr_fwd_args {
                                step keeps fp32 activations for the backward and feeds the next layer's forward
                                the bf16 ones (half the bytes through the CU, no conversion in its k loop).
                                Selects the latency form of the kernel. */
+  void* split_scratch;      /* optional, 16-byte aligned, >= bnn_lr_split_scratch_bytes(n_samples, batch, out_features), its
+                               first bnn_lr_split_scratch_zero_bytes(...) bytes zero before the first launch that uses it
+                               (the kernel leaves them zero): lets a launch of 1-3 samples on a wide layer split the K
+                               range of a 32-feature group over several blocks that meet through it (BNN_FORM_GEMM_KSLICE;
+                               bf16 math on bf16 x, in_features % 8 == 0, out_features % 4 == 0).  One launch at a time
+                               per scratch. */
+  size_t split_scratch_bytes;
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
+size_t bnn_lr_split_scratch_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
+size_t bnn_lr_split_scratch_zero_bytes(int32_t n_samples, int32_t batch, int32_t out_features);
 int bnn_lr_linear_fwd(const bnn_lr_fwd_args* args, void* stream);
 int bnn_lr_plan(const bnn_lr_fwd_args* args, bnn_plan* plan);
 

@@ -1094,6 +1094,64 @@ def test_c5_wide_bbb_layer_against_oracle(dev, form):
             close(out["log_q"][s], ref[s][2], rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 1200, 1200), (1, 128, 784, 1200), (2, 128, 1200, 1200), (3, 100, 264, 72),
+                                   (1, 20, 1000, 1200), (1, 128, 64, 4096)])
+def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
+    """K3s (lr_fwd_kslice_kernel, BNN_FORM_GEMM_KSLICE): 32-feature groups x K slices meeting through a scratch, for 1-3
+    samples on a wide [in,out] layer.  y, y^2, the saved variance and the backward factor against the oracle
+    (networks.py:116-138) and against K3a on the same inputs; the KL sums; twice the same bits (the slices are added in
+    slice order whoever arrives last); ragged batch, K tail inside a k-step, a slice count that does not divide the
+    k-steps, N % 32 != 0."""
+    S, B, K, N = shape
+    seed, off = 9, 5
+    rs = np.random.RandomState(sum(shape))
+    w_mu = rs.uniform(-0.2, 0.2, (K, N)).astype(np.float32)
+    w_rho = rs.uniform(-5, -4, (K, N)).astype(np.float32)
+    b_mu = rs.uniform(-0.2, 0.2, N).astype(np.float32)
+    b_rho = rs.uniform(-5, -4, N).astype(np.float32)
+    x = rs.uniform(0, 1, (B, K)).astype(np.float32)
+    dw = [t(a).to(dev) for a in (w_mu, w_rho, b_mu, b_rho)]
+    x16 = t(x).to(dev).to(torch.bfloat16)
+    xr = x16.float().cpu()                                     # the oracle sees the bf16-rounded input
+    ref = []
+    torch.set_num_threads(8)
+    for s in range(S):
+        ea = t(O.philox_normal(seed, O.tensor_id(2, 2), off + s, B, N))
+        eb = t(O.philox_normal(seed, O.tensor_id(2, 1), off + s, 1, N))[0]
+        y, kw_, kb_ = O.lr_linear(xr, t(w_mu), t(w_rho), t(b_mu), t(b_rho), ea, eb, 1.0)
+        ref.append((torch.relu(y).numpy(), float(kw_ + kb_)))
+    torch.set_num_threads(1)
+    kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX, seed=seed,
+              layer_id=2, sample_offset=off, want_kl=True, want_scalars=True, want_v=True, want_hfac=True, want_y16=True)
+    scratch = ops.lr_split_scratch(S, B, N, dev)
+    plan = ops.lr_plan(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw)
+    assert plan["form"] == L.FORM_GEMM_KSLICE and plan["features_per_block"] == 32, plan
+    assert plan["blocks"] == ((N + 31) // 32) * S * ((B + 127) // 128) * plan["k_slices"], plan
+    sq = lambda: torch.empty((S, B, N), dtype=torch.bfloat16, device=dev)
+    a = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
+    a2 = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
+    b = ops.lr_linear_fwd(x16, *dw, form=L.FORM_TILE, out_sq=sq(), **kw)
+    zero = L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4
+    assert int(scratch[:zero].abs().sum()) == 0                # the arrival counters are left at zero
+    for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):
+        assert torch.equal(a[key], a2[key]), key               # reproducible bit for bit
+    close(a["kl3"][0], ref[0][1], rtol=1e-5)
+    close(a["kl3"][0], float(b["kl3"][0]), rtol=1e-6)
+    for s in range(S):
+        scale = float(np.abs(ref[s][0]).max())
+        err = float(np.abs(a["y"][s].double().cpu().numpy() - ref[s][0]).max())
+        assert err <= 2e-2 * scale, (s, err, scale)
+        # against K3a: the same operands rounded to bf16 at the same points, another summation order
+        assert float((a["y"][s] - b["y"][s]).abs().max()) <= 2e-3 * scale
+        assert float((a["v"][s] - b["v"][s]).abs().max()) <= 1e-3 * float(b["v"][s].abs().max())
+        assert float((a["y16"][s].float() - a["y"][s]).abs().max()) <= 4e-3 * scale
+        assert float((a["y_sq"][s].float() - a["y"][s] ** 2).abs().max()) <= 8e-3 * scale * scale
+        sd = torch.sqrt(a["v"][s])
+        ea = t(O.philox_normal(seed, O.tensor_id(2, 2), off + s, B, N)).to(dev)
+        want = torch.where(sd > 0, ea / (2 * sd), torch.zeros_like(sd))
+        assert float((a["hfac"][s] - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("form", ["tile", "gemm"])
 def test_c5_wide_lr_layer_against_oracle(dev, form):
     """The local-reparameterisation twin of the C5 layer test: 4096 x 4096 [in,out] weights, batch 128, 4 MC

@@ -327,9 +327,11 @@ def test_launch_plans_are_a_function_of_the_shape():
         assert lib.bnn_bbb_plan(C.byref(a), C.byref(pl)) == 0
         return pl
 
-    def lr(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, sq=False, frag=False):
+    def lr(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, sq=False, frag=False, scratch=False):
         a = _plan_args(L.LrFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
-                       b_mu=P, b_rho=P, math=math, y=P, form=form, x_sq=P if sq else None, w_frag=P if frag else None)
+                       b_mu=P, b_rho=P, math=math, y=P, form=form, x_sq=P if sq else None, w_frag=P if frag else None,
+                       split_scratch=P if scratch else None,
+                       split_scratch_bytes=lib.bnn_lr_split_scratch_bytes(S, B, N) if scratch else 0)
         pl = L.Plan()
         assert lib.bnn_lr_plan(C.byref(a), C.byref(pl)) == 0
         return pl
@@ -372,6 +374,19 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 16 and lr(64, 128, 1200, 256, sq=True, frag=True).waves == 8
     pl = lr(1, 128, 1200, 10)
     assert (pl.form, pl.batch_rows, pl.k_classes) == (L.FORM_TILE, 32, 4)
+    # K3s: with a split scratch, 1-2 samples on the wide layers run as 32-feature groups x K slices in ONE round of blocks
+    # (38 groups x 4 slices of <= 10 k-steps; 76 units x 3 slices of 13); more units than that would queue: K3a
+    pl = lr(1, 128, 1200, 1200, scratch=True)
+    assert (pl.form, pl.k_slices, pl.blocks, pl.features_per_block, pl.waves) == (L.FORM_GEMM_KSLICE, 4, 152, 32, 8)
+    pl = lr(1, 128, 784, 1200, scratch=True)
+    assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 4, 152)
+    pl = lr(2, 128, 1200, 1200, scratch=True)
+    assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 228)
+    assert lr(3, 128, 1200, 1200, scratch=True).form == L.FORM_TILE
+    assert lr(1, 128, 1200, 1200, scratch=True, xdt=L.F32).form == L.FORM_TILE and lr(1, 128, 1200, 10, scratch=True).form == L.FORM_TILE
+    assert lr(1, 128, 1204, 1200, scratch=True).form == L.FORM_TILE and lr(1, 128, 1200, 1202, scratch=True).form == L.FORM_TILE
+    assert lr(1, 128, 1200, 1200, scratch=True, form=L.FORM_TILE).form == L.FORM_TILE
+    assert lib.bnn_lr_split_scratch_zero_bytes(1, 128, 1200) == 256 and lib.bnn_lr_split_scratch_bytes(1, 128, 1200) == 256 + 38 * 8 * 32768
     # invariants over a sweep of shapes
     for S in (1, 2, 3, 8, 31, 64):
         for B in (1, 16, 100, 128, 300):
