@@ -233,8 +233,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                                         out_sq=torch.empty((n_local, h.shape[-2], sp.in_out[1]), dtype=torch.bfloat16,
                                                            device=h.device) if want_sq else None,
                                         split_scratch=ops.lr_split_scratch_cached(n_local, h.shape[-2], sp.in_out[1], h.device)
-                                        if (h.dtype == torch.bfloat16 and wfrag is None and not last and
-                                            lr_use_split(sp.in_out[1], n_local, h.shape[-2])) else None)
+                                        if (wfrag is None and not last and lr_use_split(sp.in_out[1], n_local, h.shape[-2])) else None)
                 h_sq = out["y_sq"]
             else:
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
@@ -492,9 +491,13 @@ class GraphedElbo:
         for i, (sp, lb) in enumerate(zip(self.specs, self.lib)):
             if lb:
                 self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
+        # LR, 1-2 samples: the first layer's K-sliced form (K3s) reads the fp32 minibatch itself -- no cast launch ahead of it
+        k3s_first = (self.lr and hid == torch.bfloat16 and len(self.specs) > 1 and self.specs[0].in_out[0] % 8 == 0 and
+                     lr_use_split(self.specs[0].in_out[1], S, B) and not self.G > 1)
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
-                        (self.lib[0] or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES))) else None)
+                        (self.lib[0] or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) and
+                        not k3s_first) else None)
         self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)

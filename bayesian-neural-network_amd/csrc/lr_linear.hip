@@ -471,7 +471,7 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
 }
 
 // ------------------------------------------------------------------------------------------
-// K3s  the one-evaluation / training form of a wide LR layer (1-3 samples, bf16 math on bf16 x, K % 8 == 0, N % 4 == 0):
+// K3s  the one-evaluation / training form of a wide LR layer (1-2 samples, bf16 math, bf16 or fp32 x, K % 8 == 0, N % 4 == 0):
 // K-sliced, whole parameter lines.
 //   Why: K3a's block owns 8 features x all of K x 128 rows.  Its gathers use 32 bytes of every 128-byte (mu | rho) line
 //   and every block ingests all of x: 614 KB through one CU's 64 B/clk L1 fill path = 9.6 k cycles before any latency,
@@ -492,6 +492,9 @@ __global__ __launch_bounds__(MT == 2 ? 768 : 512) void lr_fwd_kernel(const LrK p
 constexpr int kLrsMaxSteps = 13;   // k-steps per slice (x fragments a wave keeps in registers)
 constexpr int kLrsMaxSlices = 8;
 
+// XF32: the layer input is fp32 (the first layer of an evaluation: the minibatch as it arrives -- no cast launch ahead of it);
+// a fragment is then two 16-byte loads, rounded to bf16 in registers where the cast kernel would have rounded it
+template <bool XF32>
 __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
   constexpr int NW = 8, XS = kLrsMaxSteps;
   __shared__ __attribute__((aligned(16))) char tiles[XS * 4096];   // [step][mean | variance][32 k][64 B]
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
   const int t_begin = ks * p.nst, nst = max(0, min(p.nst, ksteps - t_begin));   // this slice's steps (may be none)
   const uint32_t gs = lr_global_sample(p, s);
   const bool do_kl = p.want_kl && mb == 0 && s == 0;
-  const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+  const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride * (XF32 ? 4 : 2);
 
   if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(G * KSL), 0.f, 0.f, 0.f);
 
@@ -544,10 +547,19 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
     pr[u] = *reinterpret_cast<const float4*>(p.w_rho + off);
   }
   // phase-2 x fragments: rows 16 wave + r, k = 32 (t_begin + j) + 8 q
-  const __bf16* xrow = xs + (size_t)min(m0 + wave * 16 + r, B - 1) * K;
-  float4 xf[XS];
+  const char* xrow = xs + (size_t)min(m0 + wave * 16 + r, B - 1) * K * (XF32 ? 4 : 2);
+  float4 xf[XS][XF32 ? 2 : 1];
 #pragma unroll
-  for (int j = 0; j < XS; ++j) xf[j] = *reinterpret_cast<const float4*>(xrow + min((t_begin + min(j, max(nst - 1, 0))) * 32 + q * 8, K - 8));
+  for (int j = 0; j < XS; ++j) {
+    const int kx = min((t_begin + min(j, max(nst - 1, 0))) * 32 + q * 8, K - 8);
+    if (XF32) {
+      const float4* px = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xrow) + kx);
+      xf[j][0] = px[0];
+      xf[j][XF32 ? 1 : 0] = px[1];
+    } else {
+      xf[j][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xrow) + kx);
+    }
+  }
   if (bias_lane && p.eps_mode == BNN_EPS_PHILOX) {
     const int n = n0 + lane;
     float e4[4];
@@ -673,7 +685,16 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       if (j + 1 < NS) operands(min(j + 1, max(nst - 1, 0)), wa[(j + 1) & 1]);
-      const bf16x8 xb = j < nst ? __builtin_bit_cast(bf16x8, xf[j]) : zero8;
+      bf16x8 xb;
+      if (XF32) {
+        const float xv[8] = {xf[j][0].x, xf[j][0].y, xf[j][0].z, xf[j][0].w, xf[j][XF32 ? 1 : 0].x, xf[j][XF32 ? 1 : 0].y,
+                             xf[j][XF32 ? 1 : 0].z, xf[j][XF32 ? 1 : 0].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xb[e] = (__bf16)xv[e];
+      } else {
+        xb = __builtin_bit_cast(bf16x8, xf[j][0]);
+      }
+      if (j >= nst) xb = zero8;
       bf16x8 x2b;
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
@@ -1715,7 +1736,7 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   {
     const long units = lr_split_units(a->n_samples, a->batch, N);
     const int ksteps = (K + 31) / 32;
-    const bool ok = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && (K % 8 == 0) && K >= 64 && (N % 4 == 0) && N >= 64 &&
+    const bool ok = a->math == BNN_MATH_BF16 && (K % 8 == 0) && K >= 64 && (N % 4 == 0) && N >= 64 &&
                     a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
                     a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(a->n_samples, a->batch, N) &&
                     !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
@@ -1806,7 +1827,8 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     k.ksl = pl.ksl; k.nst = pl.nst;
     k.ks_ticket = reinterpret_cast<uint32_t*>(base);
     k.ks_part = reinterpret_cast<float4*>(base + lr_ticket_bytes(pl.total / pl.ksl));
-    hipLaunchKernelGGL(lr_fwd_kslice_kernel, grid, block, 0, stream, k);
+    if (a->x_dtype == BNN_F32) hipLaunchKernelGGL(lr_fwd_kslice_kernel<true>, grid, block, 0, stream, k);
+    else hipLaunchKernelGGL(lr_fwd_kslice_kernel<false>, grid, block, 0, stream, k);
   } else if (pl.form == BNN_FORM_GEMM) {
 #ifdef BNN_TUNE
     k.tune = getenv("BNN_TUNE_LRFLAGS") ? atoi(getenv("BNN_TUNE_LRFLAGS")) : 0;

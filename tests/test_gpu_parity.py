@@ -1097,8 +1097,8 @@ def test_c5_wide_bbb_layer_against_oracle(dev, form):
 @pytest.mark.parametrize("shape", [(1, 128, 1200, 1200), (1, 128, 784, 1200), (2, 128, 1200, 1200), (3, 100, 264, 72),
                                    (1, 20, 1000, 1200), (1, 128, 64, 4096)])
 def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
-    """K3s (lr_fwd_kslice_kernel, BNN_FORM_GEMM_KSLICE): 32-feature groups x K slices meeting through a scratch, for 1-3
-    samples on a wide [in,out] layer.  y, y^2, the saved variance and the backward factor against the oracle
+    """K3s (lr_fwd_kslice_kernel, BNN_FORM_GEMM_KSLICE): 32-feature groups x K slices meeting through a scratch, for 1-2
+    samples on a wide [in,out] layer (more where the layer is narrower).  y, y^2, the saved variance and the backward factor against the oracle
     (networks.py:116-138) and against K3a on the same inputs; the KL sums; twice the same bits (the slices are added in
     slice order whoever arrives last); ragged batch, K tail inside a k-step, a slice count that does not divide the
     k-steps, N % 32 != 0."""
@@ -1131,6 +1131,11 @@ def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
     a = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
     a2 = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
     b = ops.lr_linear_fwd(x16, *dw, form=L.FORM_TILE, out_sq=sq(), **kw)
+    # the fp32-input variant (first layer of an evaluation: no cast launch) rounds x where the cast would have: on an
+    # input that is already bf16-representable it gives the same bits
+    a3 = ops.lr_linear_fwd(x16.float(), *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
+    for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):
+        assert torch.equal(a[key], a3[key]), key
     zero = L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4
     assert int(scratch[:zero].abs().sum()) == 0                # the arrival counters are left at zero
     for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):

@@ -383,7 +383,8 @@ def test_launch_plans_are_a_function_of_the_shape():
     pl = lr(2, 128, 1200, 1200, scratch=True)
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 228)
     assert lr(3, 128, 1200, 1200, scratch=True).form == L.FORM_TILE
-    assert lr(1, 128, 1200, 1200, scratch=True, xdt=L.F32).form == L.FORM_TILE and lr(1, 128, 1200, 10, scratch=True).form == L.FORM_TILE
+    assert lr(1, 128, 784, 1200, scratch=True, xdt=L.F32).form == L.FORM_GEMM_KSLICE        # the first layer reads the fp32 minibatch itself
+    assert lr(1, 128, 1200, 1200, scratch=True, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE and lr(1, 128, 1200, 10, scratch=True).form == L.FORM_TILE
     assert lr(1, 128, 1204, 1200, scratch=True).form == L.FORM_TILE and lr(1, 128, 1200, 1202, scratch=True).form == L.FORM_TILE
     assert lr(1, 128, 1200, 1200, scratch=True, form=L.FORM_TILE).form == L.FORM_TILE
     assert lib.bnn_lr_split_scratch_zero_bytes(1, 128, 1200) == 256 and lib.bnn_lr_split_scratch_bytes(1, 128, 1200) == 256 + 38 * 8 * 32768
