@@ -269,7 +269,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     common = dict(n_samples=n, math_mode=mm, relu=True, y_dtype=out.dtype, eps_mode=L.EPS_PHILOX, seed=1, layer_id=1,
                   workspace=ws, out=out)
     if lr:
-        kw = dict(sigma_p=1.0, want_kl=True, x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1], **common)
+        kw = dict(sigma_p=1.0, want_kl=True, x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1],
+                  split_scratch=getattr(ev, "lr_split", [None] * 3)[1], **common)
         plan = ops.lr_plan(xin, *pd, **kw)
         launch = lambda: ops.lr_linear_fwd(xin, *pd, **kw)
     else:
@@ -290,7 +291,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     kname = {("bbb", "tile"): "K1a bbb_fwd_kernel",
              ("bbb", "gemm"): "K1b2 bbb_fwd_gemm2_kernel (parameters and x through LDS, 2 pairs per block)" if plan["waves"] == 8 else "K1b bbb_fwd_gemm_kernel",
              ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
-             ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel"}[("lr" if lr else "bbb", form)]
+             ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel",
+             ("lr", "gemm_kslice"): "K3s lr_fwd_kslice_kernel (32-feature groups x K slices, whole parameter lines, slices meet through a scratch)"}[("lr" if lr else "bbb", form)]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_key": f"{'lr' if lr else 'bbb'}_{dims[1]}_n{n}_b{batch}_{math_name}",
             "kernel": f"{kname}, layer 2 ({dims[1]}x{dims[1]})", "plan": plan,

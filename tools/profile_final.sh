@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's judged profiles in one GPU-box call: kernel-trace summaries of the driver's command (--steps 20 --warmup 5),
 # of the isolated dominant kernels (headline K1b, LR K3b, 8-sample K-sliced form, the block GEMM K1g at batch 4096) and of
-# the training step; the FETCH_SIZE / WRITE_SIZE passes behind profiles/traffic.json and the SQ / GRBM passes behind
+# the training step, the one-evaluation LR layer (K3s); the FETCH_SIZE / WRITE_SIZE passes behind profiles/traffic.json and the SQ / GRBM passes behind
 # profiles/pmc.json (both stamped with the hash of the kernel sources they were measured on; pmc.json is rebuilt from
 # scratch so that it holds current kernels only).
 # usage: tools/profile_final.sh <round tag>      (copy gpurun_out/profiles/* into profiles/ afterwards)
@@ -13,12 +13,14 @@ $P statsfull steps20 --steps 20 --warmup 5 --no-extras --no-cpu-baseline &&
 $P stats bbb_g256 &&
 $P stats lr_g256_l2 --variant lr &&
 $P stats bbb_S8 --samples 8 --group 1 &&
+$P stats lr_S1 --variant lr --samples 1 --group 1 &&
 $P stats wide_B4096_S4 --net wide --batch 4096 --samples 4 --group 1 &&
 $P stats wide_B1024_S4 --net wide --batch 1024 --samples 4 --group 1 &&
 $P statspy train_step tools/train_step_bench.py 2 graph &&
 $P traffic bbb256 bbb_1200_n256_b128_bf16 bbb_fwd_gemm &&
 $P traffic lr256 lr_1200_n256_b128_bf16 lr_fwd_gemm_kernel --variant lr &&
 $P traffic bbbS8 bbb_1200_n8_b128_bf16 bbb_fwd_gemm --samples 8 --group 1 &&
+$P traffic lrS1 lr_1200_n1_b128_bf16 lr_fwd_kslice_kernel --variant lr --samples 1 --group 1 &&
 $P traffic wide4096 block_gemm_4096_n4_b4096_bf16 bbb_block_gemm_kernel --net wide --batch 4096 --samples 4 --group 1 &&
 $P pmc bbb256 bbb_g256 "$PMC" &&
 $P pmc lr256 lr_g256 "$PMC" --variant lr &&
