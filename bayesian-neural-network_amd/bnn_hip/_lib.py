@@ -78,6 +78,14 @@ class SampleArgs(C.Structure):
     ]
 
 
+class LrRider(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("in_features", C.c_int32), ("out_features", C.c_int32),
+        ("w_mu", C.c_void_p), ("w_rho", C.c_void_p), ("b_mu", C.c_void_p), ("b_rho", C.c_void_p),
+        ("w_frag", C.c_void_p), ("w_frag_bytes", C.c_size_t), ("kl_workspace", C.c_void_p), ("kl_workspace_bytes", C.c_size_t),
+    ]
+
+
 class LrFwdArgs(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_uint32),
@@ -95,7 +103,7 @@ class LrFwdArgs(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("reserved2", C.c_int32),
         ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
         ("hfac_out", C.c_void_p), ("y_bf16_copy", C.c_void_p),
-        ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
+        ("rider", C.POINTER(LrRider)), ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
     ]
 
 

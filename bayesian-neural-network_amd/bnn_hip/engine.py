@@ -107,6 +107,21 @@ def lr_use_split(out_features: int, samples: int, batch: int) -> bool:
     return out_features >= 64 and out_features % 4 == 0 and ((out_features + 31) // 32) * samples * ((batch + 127) // 128) <= 160
 
 
+def lr_kslice_expected(in_features: int, out_features: int, samples: int, batch: int) -> bool:
+    """Mirror of the library's plan for K3s (csrc/lr_linear.hip: lr_plan): True where a launch with a split scratch and bf16
+    math takes the K-sliced form -- used to decide whether a rider is worth attaching (elsewhere it costs a launch)."""
+    if not lr_use_split(out_features, samples, batch) or in_features % 8 or in_features < 64:
+        return False
+    units = ((out_features + 31) // 32) * samples * ((batch + 127) // 128)
+    ksteps = (in_features + 31) // 32
+    ksl = min(8, max(1, 160 // units))
+    while ksl < 8 and (ksteps + ksl - 1) // ksl > 13:
+        ksl += 1
+    nst = (ksteps + ksl - 1) // ksl
+    ksl = (ksteps + nst - 1) // nst
+    return nst <= 13 and units * ksl <= 256
+
+
 def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
     """True when the LR throughput kernel (block GEMM) will run for this layer and enough samples share the
     prepared weights to pay for the extra pass (mirrors the launcher's geometry rule)."""
@@ -518,6 +533,17 @@ class GraphedElbo:
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
                           if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
+        # LR, few samples: the narrow output layer's operands are prepared by a rider of the previous layer's launch
+        # (bnn_lr_rider), so that the row-split final launch (K3r) parks nothing
+        nl = len(self.specs)
+        self.lr_rider = None
+        if (self.lr and hid == torch.bfloat16 and nl > 1 and self.wfrag[nl - 1] is None and self.scratch is not None and
+                not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= 16 and self.lr_split[nl - 2] is not None and
+                lr_kslice_expected(*self.specs[-2].in_out, S, B)):
+            sp = self.specs[-1]
+            self.lr_rider = dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
+                                 b_rho=sp.m.bias_rho.detach(), workspace=self.ws[nl - 1],
+                                 w_frag=torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev))
         self.pre_from = presample_from(self.specs, S, B, hid)      # the layer whose launch samples all layers after it
         self.rows = self.pre_from >= 0
         self.w_pre, self.b_pre = [None] * len(self.specs), [None] * len(self.specs)
@@ -571,11 +597,13 @@ class GraphedElbo:
                     ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
                 if i == last and self.scratch is not None and not wide_nll(self.specs, self.x.shape[-2]):
                     # output layer + finalize in one launch when the library's row-split form applies (else it issues both)
-                    ops.lr_final_fwd((h,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq, w_frag=self.wfrag[i],
+                    ops.lr_final_fwd((h,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
+                                                    w_frag=self.lr_rider["w_frag"] if self.lr_rider is not None else self.wfrag[i],
                                                     **common), dict(workspaces=self.ws, **fin_kw))
                     return
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
-                                  out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], split_scratch=self.lr_split[i], **common)
+                                  out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], split_scratch=self.lr_split[i],
+                                  rider=self.lr_rider if i == last - 1 else None, **common)
                 h_sq = self.bufs_sq[i]
             elif self.lib[i]:
                 ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,

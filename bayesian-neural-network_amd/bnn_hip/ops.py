@@ -351,8 +351,9 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
                   out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, want_hfac: bool = False, form: int = 0,
                   sample_group: int = 0,
-                  sample_group_stride: int = 0, split_scratch=None):
-    """Argument block of K3 + the result dict + the tensors it points at."""
+                  sample_group_stride: int = 0, split_scratch=None, rider=None):
+    """Argument block of K3 + the result dict + the tensors it points at.  `rider`: dict(w_mu, w_rho, b_mu, b_rho, w_frag,
+    workspace) of a narrow LR layer whose operands this launch prepares on the side (bnn_lr_rider)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
@@ -416,8 +417,21 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     if split_scratch is not None:
         a.split_scratch = split_scratch.data_ptr()
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
+    rd = None
+    if rider is not None:
+        rw = [_f32c(rider[k], k) for k in ("w_mu", "w_rho", "b_mu", "b_rho")]
+        require_device(*rw, rider["w_frag"], rider["workspace"])
+        rd = L.LrRider()
+        rd.struct_bytes = C.sizeof(L.LrRider)
+        rd.in_features, rd.out_features = int(rw[0].shape[0]), int(rw[0].shape[1])
+        rd.w_mu, rd.w_rho, rd.b_mu, rd.b_rho = (t.data_ptr() for t in rw)
+        rd.w_frag, rd.w_frag_bytes = rider["w_frag"].data_ptr(), rider["w_frag"].numel() * rider["w_frag"].element_size()
+        rd.kl_workspace = rider["workspace"].data_ptr()
+        rd.kl_workspace_bytes = rider["workspace"].numel() * rider["workspace"].element_size()
+        a.rider = C.pointer(rd)
+        rd = (rd, rw, rider["w_frag"], rider["workspace"])
     res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch, rd)
     return a, res, keep
 
 

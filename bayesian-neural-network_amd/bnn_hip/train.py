@@ -92,6 +92,7 @@ class GraphedTrainStep:
         self.fin_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # lets the samples be finalized in parallel
         self.fin_scratch = ops.final_scratch(self.samples, dev)   # hand-off words of the row-split / K-sliced output layer
         self._lr_split = {}                                       # layer index -> K3s scratch (owned here: zeroed once, outside capture)
+        self._lr_rider_bufs, self._lr_rider_job = None, None      # the output layer's prepared operands + KL workspace (bnn_lr_rider)
         # one flat gradient bucket (each slice 256-byte aligned); p.grad are views of it
         self.params = [p for sp in net._specs() for p in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho)]
         offs, tot = [], 0
@@ -184,6 +185,25 @@ class GraphedTrainStep:
         finally:
             state.device_counter = None
 
+    def _lr_rider(self, i, specs, hin):
+        """bnn_lr_rider of the output layer, attached to the last hidden LR layer's launch when that launch is expected to run
+        K-sliced (elsewhere the preparation would be a launch of its own): the final launch (K3r) then parks nothing."""
+        from .engine import lr_kslice_expected
+        last = specs[-1]
+        if (i != len(specs) - 2 or not last.lr or last.in_out[1] > 16 or hin.dtype != torch.bfloat16 or self.samples > 16 or
+                hin.shape[-2] > 128 or self._lr_scratch(i, specs[i], hin) is None or
+                not lr_kslice_expected(*specs[i].in_out, self.samples, hin.shape[-2])):
+            return None
+        if self._lr_rider_bufs is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self._lr_rider_bufs = (torch.empty(L.load().bnn_lr_prepare_bytes(*last.in_out) // 4, dtype=torch.float32, device=hin.device),
+                                   ops.lr_workspace(last.in_out[1], hin.device))
+        m = last.m
+        self._lr_rider_job = dict(w_mu=m.weight_mu.detach(), w_rho=m.weight_rho.detach(), b_mu=m.bias_mu.detach(), b_rho=m.bias_rho.detach(),
+                                  w_frag=self._lr_rider_bufs[0], workspace=self._lr_rider_bufs[1])
+        return self._lr_rider_job
+
     def _lr_scratch(self, i, sp, hin):
         """K3s scratch of LR hidden layer i (None when the launch could not use one): allocated and zeroed at the first
         forward outside capture (construction warms the step up before it captures); the kernel leaves its counters zero."""
@@ -200,6 +220,7 @@ class GraphedTrainStep:
         """zero_grad -> sample_elbo -> backward, as a hand-made chain of the C-ABI kernels (no autograd).
         Leaves the gradients in p.grad and returns what sample_elbo* returns."""
         net, S = self.net, self.samples
+        self._lr_rider_job = None
         specs = net._specs()
         lr = bool(net.local_reparam)
         h = net._flat(self.x)
@@ -257,9 +278,10 @@ class GraphedTrainStep:
             if sp.lr and i == len(specs) - 1:
                 # output layer + finalize + loss tail through bnn_lr_final_fwd: one launch when the layer is narrow and its
                 # input is bf16 (K3r; it also saves the variance for the backward), else layer, finalize, loss launches
-                ws_last = ops.lr_workspace(sp.in_out[1], h.device)
+                rd = self._lr_rider_job
+                ws_last = rd["workspace"] if rd is not None else ops.lr_workspace(sp.in_out[1], h.device)
                 out, fin = ops.lr_final_fwd((hin,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=True,
-                                                             workspace=ws_last, **common),
+                                                             workspace=ws_last, w_frag=rd["w_frag"] if rd is not None else None, **common),
                                             dict(workspaces=wss + [ws_last], scratch=self.fin_scratch,
                                                  loss=dict(beta=self.beta, total_samples=S, grad_scale=1.0 / self.world), **fin_kw))
                 saved.append((h, out["y"], out.get("v"), p, None))
@@ -271,7 +293,8 @@ class GraphedTrainStep:
                 hf = i < len(specs) - 1
                 out = ops.lr_linear_fwd(hin, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, want_v=not hf, want_hfac=hf,
                                         want_y16=self.x16 is not None and i < len(specs) - 1,
-                                        split_scratch=self._lr_scratch(i, sp, hin) if hf else None, **common)
+                                        split_scratch=self._lr_scratch(i, sp, hin) if hf else None,
+                                        rider=self._lr_rider(i, specs, hin), **common)
             else:
                 out = ops.bbb_linear_fwd(hin, *p, prior=sp.m._prior_spec, want_stats=True,
                                          want_y16=self.x16 is not None and i < len(specs) - 1, **common)

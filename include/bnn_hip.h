@@ -281,6 +281,25 @@ int bnn_bbb_sample_weights(const bnn_bbb_sample_args* args, void* stream);
  * {sum log sigma, sum sigma^2, sum mu^2} over the tile's weights and biases.
  * kl_out (optional, float[3]) = {weight_kl + bias_kl, weight_kl, bias_kl}.
  * ---------------------------------------------------------------------------------- */
+/* bnn_lr_rider — what bnn_lr_prepare does for one NARROW layer (out_features <= 16: the output layer of the reference's
+ * networks, networks.py:160-164), carried by another layer's launch: the K-sliced form of bnn_lr_linear_fwd (K3s) runs it as a
+ * few extra blocks on CUs its own blocks leave idle; any other form launches bnn_lr_prepare ahead of itself.  Either way,
+ * after bnn_lr_linear_fwd returns (in stream order) `w_frag` holds the bf16 (M, sigma^2) operands in fragment order and
+ * `kl_workspace` the layer's closed-form KL sums -- what bnn_lr_final_fwd takes as bnn_lr_fwd_args.w_frag / .workspace, so
+ * that its row blocks park nothing (the one-evaluation chain: 12.4 -> 8 us for the 1200 x 10 layer). */
+typedef struct bnn_lr_rider {
+  uint32_t struct_bytes;
+  int32_t in_features, out_features;
+  const float* w_mu;        /* [in, out] */
+  const float* w_rho;
+  const float* b_mu;        /* [out] */
+  const float* b_rho;
+  void* w_frag;             /* >= bnn_lr_prepare_bytes(in, out), 16-byte aligned */
+  size_t w_frag_bytes;
+  void* kl_workspace;       /* >= bnn_lr_linear_fwd_workspace_bytes(out), 16-byte aligned */
+  size_t kl_workspace_bytes;
+} bnn_lr_rider;
+
 typedef struct bnn_lr_fwd_args {
   uint32_t struct_bytes;
   int32_t n_samples, batch, in_features, out_features;
@@ -331,6 +350,7 @@ typedef struct bnn_lr_fwd_args {
                                step keeps fp32 activations for the backward and feeds the next layer's forward
                                the bf16 ones (half the bytes through the CU, no conversion in its k loop).
                                Selects the latency form of the kernel. */
+  const struct bnn_lr_rider* rider; /* optional: prepare ANOTHER (narrow) LR layer's operands beside this launch -- see bnn_lr_rider */
   void* split_scratch;      /* optional, 16-byte aligned, >= bnn_lr_split_scratch_bytes(n_samples, batch, out_features), its
                                first bnn_lr_split_scratch_zero_bytes(...) bytes zero before the first launch that uses it
                                (the kernel leaves them zero): lets a launch of 1-3 samples on a wide layer split the K

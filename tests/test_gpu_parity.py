@@ -1136,6 +1136,21 @@ def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
     a3 = ops.lr_linear_fwd(x16.float(), *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
     for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):
         assert torch.equal(a[key], a3[key]), key
+    # bnn_lr_rider: the NEXT (narrow) layer's operands prepared beside this launch -- as extra blocks of the K-sliced form, or
+    # by a bnn_lr_prepare launch ahead of any other form: bitwise the fragments of a stand-alone bnn_lr_prepare, its KL
+    # sums, and this layer's own results unchanged
+    w3 = [t(rs.uniform(-0.3, 0.3, (N, 10)).astype(np.float32)).to(dev), t(rs.uniform(-5, -4, (N, 10)).astype(np.float32)).to(dev),
+          t(rs.uniform(-0.3, 0.3, 10).astype(np.float32)).to(dev), t(rs.uniform(-5, -4, 10).astype(np.float32)).to(dev)]
+    ref_frag, ref_ws = ops.lr_prepare(*w3)
+    ws_sum = lambda w: w.view(-1, 4)[1:1 + int(w.view(torch.int32)[0])].double().sum(0)[:3]
+    for fm in (L.FORM_GEMM_KSLICE, L.FORM_TILE):
+        frag = torch.zeros_like(ref_frag)
+        wsr = ops.lr_workspace(10, dev)
+        a4 = ops.lr_linear_fwd(x16, *dw, form=fm, split_scratch=scratch if fm == L.FORM_GEMM_KSLICE else None, out_sq=sq(),
+                               rider=dict(w_mu=w3[0], w_rho=w3[1], b_mu=w3[2], b_rho=w3[3], w_frag=frag, workspace=wsr), **kw)
+        assert torch.equal(frag.view(torch.int32), ref_frag.view(torch.int32)), fm
+        assert float((ws_sum(wsr) - ws_sum(ref_ws)).abs().max()) <= 1e-5 * float(ws_sum(ref_ws).abs().max()), fm
+        assert torch.equal(a4["y"], (a if fm == L.FORM_GEMM_KSLICE else b)["y"]), fm
     zero = L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4
     assert int(scratch[:zero].abs().sum()) == 0                # the arrival counters are left at zero
     for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):

@@ -349,6 +349,20 @@ def test_lr_final_launch_with_loss_tail_and_saved_variance(mode):
         for i, (a, b) in enumerate(zip(fin["loss"], loss2)):
             assert torch.isfinite(b).all()
             assert close(a, b, 2e-4), (mode, S, B, K, N, i)
+        if N <= 16:
+            # the same launch over PREPARED operands (bnn_lr_prepare here; in an evaluation the rider of the previous layer's
+            # launch): the row blocks park nothing, the statistics block takes the KL sums that came with the fragments --
+            # the same bf16 operands in the same order, so the logits and the variance are the same bits
+            wfrag, wsp = ops.lr_prepare(*p)
+            pre, fin3 = ops.lr_final_fwd((x,) + p, dict(workspace=wsp, w_frag=wfrag, **kw),
+                                         dict(workspaces=[wsp], scratch=ops.final_scratch(S, dev),
+                                              ticket=torch.zeros(1, dtype=torch.int32, device=dev) if S > 1 else None,
+                                              loss=dict(beta=beta, total_samples=S, grad_scale=0.5), **fin_kw))
+            torch.cuda.synchronize()
+            assert torch.equal(pre["y"], one["y"]) and torch.equal(pre["v"], one["v"]), (mode, S, B, K, N)
+            assert close(fin3["kl"], fin["kl"], 1e-6) and torch.equal(fin3["nll"], fin["nll"]), (mode, S, B, K, N)
+            for i, (a, b) in enumerate(zip(fin3["loss"], fin["loss"])):
+                assert close(a, b, 1e-5), (mode, S, B, K, N, i)
 
 
 @pytest.mark.parametrize("mode", ["classification", "regression"])
