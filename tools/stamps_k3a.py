@@ -1,6 +1,6 @@
 """Diagnostic only: where a block of K3a (one LR layer, few samples) spends its time, from in-kernel shader-clock stamps of
 wave 0 (build: make -C bayesian-neural-network_amd/csrc stamps; never a timed build).
-usage: stamps_k3a.py [n_samples] [K] [N]      K3_FORM=tile|kslice (default kslice: K3s), BNN_TUNE_LRKSL=n slices"""
+usage: stamps_k3a.py [n_samples] [K] [N]      K3_FORM=tile|kslice (default kslice: K3s), BNN_TUNE_LRKSL=n slices, X_F32=1 fp32 layer input"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["BNN_HIP_LIB"] = os.path.join(REPO, "bayesian-neural-network_amd", "bnn_hip", "libbnn_hip_stamps.so")
@@ -16,7 +16,9 @@ B = 128
 torch.manual_seed(0)
 wmu = torch.empty(K, N, device=dev).uniform_(-0.2, 0.2); wrho = torch.empty(K, N, device=dev).uniform_(-5, -4)
 bmu = torch.empty(N, device=dev).uniform_(-0.2, 0.2); brho = torch.empty(N, device=dev).uniform_(-5, -4)
-x16 = torch.rand(B, K, device=dev).to(torch.bfloat16)
+x16 = torch.rand(B, K, device=dev)
+if os.environ.get("X_F32", "0") != "1":
+    x16 = x16.to(torch.bfloat16)
 ws = ops.lr_workspace(N, dev)
 dbg = torch.zeros(8192 * 16, dtype=torch.int64, device=dev)
 os.environ["BNN_HIP_DBG_PTR"] = str(dbg.data_ptr())
