@@ -1172,6 +1172,42 @@ def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
         assert float((a["hfac"][s] - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
+def test_lr_k_sliced_form_per_sample_inputs_and_injected_eps(dev):
+    """K3s on a hidden layer's inputs (one x per MC sample) and with epsilon from memory: the on-chip draw dumped by one
+    launch and injected into the next gives the same bits; K3a on the same injected epsilon agrees to summation order;
+    sample groups (stacked minibatches) index x and the Philox subsequence as K3a does."""
+    S, B, K, N = 2, 77, 392, 328
+    rs = np.random.RandomState(5)
+    mk = lambda *sh, lo=-0.3, hi=0.3: t(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+    dw = [mk(K, N), mk(K, N, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4)]
+    x3 = mk(S, B, K, lo=0, hi=1).to(torch.bfloat16)
+    kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.bfloat16, seed=3, layer_id=1, sample_offset=9,
+              want_kl=True, want_scalars=True)
+    scratch = ops.lr_split_scratch(S, B, N, dev)
+    ks = dict(form=L.FORM_GEMM_KSLICE, split_scratch=scratch)
+    assert ops.lr_plan(x3, *dw, eps_mode=L.EPS_PHILOX, **ks, **kw)["form"] == L.FORM_GEMM_KSLICE
+    a = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_PHILOX, dump_eps=True, **ks, **kw)
+    b = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_MEMORY, eps_act=a["eps_act"], eps_b=a["eps_b"], **ks, **kw)
+    c = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_MEMORY, eps_act=a["eps_act"], eps_b=a["eps_b"], form=L.FORM_TILE, **kw)
+    d = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_PHILOX, dump_eps=True, form=L.FORM_TILE, **kw)
+    assert torch.equal(a["y"], b["y"]) and torch.equal(a["kl3"], b["kl3"])
+    assert torch.equal(a["eps_act"], d["eps_act"]) and torch.equal(a["eps_b"], d["eps_b"])     # the same epsilon map
+    scale = float(c["y"].float().abs().max())
+    assert float((a["y"].float() - c["y"].float()).abs().max()) <= 1e-2 * scale               # bf16 outputs: one ulp of rounding
+    assert float((a["y"].float() - c["y"].float()).abs().mean()) <= 2e-4 * scale
+    # the samples really read their own x: swapping the inputs swaps the outputs' pre-noise part
+    e0 = torch.zeros_like(a["eps_act"])
+    z = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_MEMORY, eps_act=e0, eps_b=torch.zeros_like(a["eps_b"]), **ks, **kw)
+    zs = ops.lr_linear_fwd(x3.flip(0).contiguous(), *dw, eps_mode=L.EPS_MEMORY, eps_act=e0, eps_b=torch.zeros_like(a["eps_b"]), **ks, **kw)
+    assert torch.equal(z["y"], zs["y"].flip(0)) and not torch.equal(z["y"][0], z["y"][1])
+    # sample groups: 2 stacked minibatches x 1 sample = the two one-sample launches with the group's offsets
+    g = ops.lr_linear_fwd(x3, *dw, eps_mode=L.EPS_PHILOX, sample_group=1, sample_group_stride=7, **ks, **kw)
+    for s in range(S):
+        kw1 = dict(kw, n_samples=1, sample_offset=9 + 7 * s)
+        one = ops.lr_linear_fwd(x3[s], *dw, eps_mode=L.EPS_PHILOX, form=L.FORM_GEMM_KSLICE, split_scratch=ops.lr_split_scratch(1, B, N, dev), **kw1)
+        assert torch.equal(g["y"][s], one["y"][0]), s
+
+
 @pytest.mark.parametrize("form", ["tile", "gemm"])
 def test_c5_wide_lr_layer_against_oracle(dev, form):
     """The local-reparameterisation twin of the C5 layer test: 4096 x 4096 [in,out] weights, batch 128, 4 MC
