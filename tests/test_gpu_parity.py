@@ -1208,6 +1208,39 @@ def test_lr_k_sliced_form_per_sample_inputs_and_injected_eps(dev):
         assert torch.equal(g["y"][s], one["y"][0]), s
 
 
+def test_lr_k_sliced_form_over_random_shapes_against_k3a(dev):
+    """K3s against K3a over shapes drawn at random among those its plan accepts (batch 1..300: ragged 16-row tiles and several
+    batch blocks; K any multiple of 8 from 64: K tails inside a k-step, 1..8 slices, slices of unequal length; N any multiple
+    of 4 from 64: a last 32-feature group of 4..28 features), both layer-input types: same epsilon map, outputs and KL sums
+    within summation order, counters left at zero."""
+    rs = np.random.RandomState(2024)
+    done = 0
+    for _ in range(60):
+        S = int(rs.randint(1, 3)); B = int(rs.randint(1, 301)); K = 8 * int(rs.randint(8, 257)); N = 4 * int(rs.randint(16, 151))
+        mk = lambda *sh, lo=-0.3, hi=0.3: t(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        dw = [mk(K, N), mk(K, N, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4)]
+        x = mk(S, B, K, lo=0, hi=1) if rs.rand() < 0.5 else mk(B, K, lo=0, hi=1)
+        if rs.rand() < 0.6:
+            x = x.to(torch.bfloat16)
+        kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=bool(rs.rand() < 0.5), y_dtype=torch.float32, seed=int(rs.randint(1 << 30)),
+                  layer_id=int(rs.randint(4)), sample_offset=int(rs.randint(100)), want_kl=True, want_scalars=True, eps_mode=L.EPS_PHILOX)
+        scratch = ops.lr_split_scratch(S, B, N, dev)
+        try:
+            plan = ops.lr_plan(x, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw)
+        except ops.BnnHipError:
+            continue                                            # more than one round of blocks: the plan declines
+        assert plan["form"] == L.FORM_GEMM_KSLICE and plan["blocks"] <= 256 and 1 <= plan["k_slices"] <= 8, (S, B, K, N, plan)
+        a = ops.lr_linear_fwd(x, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw)
+        b = ops.lr_linear_fwd(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16), *dw, form=L.FORM_TILE, **kw)
+        scale = float(b["y"].abs().max()) + 1e-6
+        assert torch.isfinite(a["y"]).all(), (S, B, K, N)
+        assert float((a["y"] - b["y"]).abs().max()) <= 3e-3 * scale, (S, B, K, N, plan, float((a["y"] - b["y"]).abs().max()), scale)
+        close(a["kl3"][0], float(b["kl3"][0]), rtol=2e-6)
+        assert int(scratch[:L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4].abs().sum()) == 0
+        done += 1
+    assert done >= 25, done
+
+
 @pytest.mark.parametrize("form", ["tile", "gemm"])
 def test_c5_wide_lr_layer_against_oracle(dev, form):
     """The local-reparameterisation twin of the C5 layer test: 4096 x 4096 [in,out] weights, batch 128, 4 MC
