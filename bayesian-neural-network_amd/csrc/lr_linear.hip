@@ -575,10 +575,13 @@ constexpr int kLrsMaxSlices = 8;
 
 // XF32: the layer input is fp32 (the first layer of an evaluation: the minibatch as it arrives -- no cast launch ahead of it);
 // a fragment is then two 16-byte loads, rounded to bf16 in registers where the cast kernel would have rounded it
-template <bool XF32>
+// NX: k-steps a slice may have in this instantiation (4, 8, 10 or 13: the wave's x fragments and the product loop are
+// unrolled to it -- a 7-step slice of the 784-wide layer issues 8 fragment loads, not 13)
+template <bool XF32, int NX>
 __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
-  constexpr int NW = 8, XS = kLrsMaxSteps;
-  __shared__ __attribute__((aligned(16))) char tiles[XS * 4096];   // [step][mean | variance][32 k][64 B]
+  constexpr int NW = 8, XS = NX;
+  constexpr int kTilesBytes = XS * 4096 > kLrRiderSteps * 2048 ? XS * 4096 : kLrRiderSteps * 2048;   // (a rider block's two images)
+  __shared__ __attribute__((aligned(16))) char tiles[kTilesBytes];   // [step][mean | variance][32 k][64 B]
   __shared__ float lds_bias[32];
   __shared__ float lds_red[3 * NW];
   __shared__ uint32_t last_s;
@@ -606,14 +609,6 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
 
   LR_STAMP(0);
   LR_STAMP_RT(8);
-  // bias of the group (last wave, lanes 0..31): its loads go first, its noise is drawn while everything is in flight
-  const bool bias_lane = wave == NW - 1 && lane < 32 && n0 + lane < N;
-  float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
-  if (bias_lane) {
-    bmu_pre = p.b_mu[n0 + lane];
-    brho_pre = p.b_rho[n0 + lane];
-    if (p.eps_mode == BNN_EPS_MEMORY) beps_pre = p.eps_b[(size_t)s * N + n0 + lane];
-  }
   // ---- every load of the wave, issued before anything is waited for (branch-free: clamped steps re-read a line)
   // phase-1 share of this wave: the slice's 8-row groups wave, wave + 8, ... (4 per k-step: a lane-linear 1 KiB load
   // of 8 k rows x 32 features per tensor)
@@ -631,6 +626,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
     pm[u] = *reinterpret_cast<const float4*>(p.w_mu + off);
     pr[u] = *reinterpret_cast<const float4*>(p.w_rho + off);
   }
+  __builtin_amdgcn_sched_barrier(0);                           // the parameters are wanted first: keep their loads ahead of x's
   // phase-2 x fragments: rows 16 wave + r, k = 32 (t_begin + j) + 8 q
   const char* xrow = xs + (size_t)min(m0 + wave * 16 + r, B - 1) * K * (XF32 ? 4 : 2);
   float4 xf[XS][XF32 ? 2 : 1];
@@ -645,11 +641,21 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
       xf[j][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xrow) + kx);
     }
   }
+  // bias of the group (used by the last wave's lanes 0..31): loaded by every lane at clamped addresses, BEHIND the parameter and x
+  // loads and without a branch -- two loads issued under `if (bias_lane)` ahead of the others made the compiler wait for them
+  // before it issued the second half of the parameter loads and all of x (a whole round trip in wave 7, which the block
+  // then waited for at the barrier)
+  const bool bias_lane = wave == NW - 1 && lane < 32 && n0 + lane < N;
+  float bmu_pre = p.b_mu[min(n0 + (lane & 31), N - 1)], brho_pre = p.b_rho[min(n0 + (lane & 31), N - 1)];
+  // (the injected epsilon stays in its own register until the select below: sharing one variable with the drawn value let the
+  // generator's temporaries reuse the load's destination, and the compiler then waited for EVERY load before the draw)
+  float beps_mem = 0.f, beps_phx = 0.f;
+  if (p.eps_mode == BNN_EPS_MEMORY) beps_mem = p.eps_b[(size_t)s * N + min(n0 + (lane & 31), N - 1)];
   if (bias_lane && p.eps_mode == BNN_EPS_PHILOX) {
     const int n = n0 + lane;
     float e4[4];
     philox_normal4((uint32_t)(n >> 2), gs, p.layer_id * 4u + 1u, p.k0, p.k1, e4);
-    beps_pre = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+    beps_phx = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
   }
 #pragma unroll
   for (int u = 0; u < PG; ++u) {                               // the arithmetic starts HERE: issued loads stay ahead of it
@@ -706,6 +712,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
     if (bias_lane) {
       const int n = n0 + lane;
       const float bsig = softplus(brho_pre);
+      const float beps_pre = p.eps_mode == BNN_EPS_MEMORY ? beps_mem : beps_phx;
       if (p.eps_b_dump && mb == 0 && ks == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
       b = __builtin_fmaf(bsig, beps_pre, bmu_pre);
       if (do_kl && ks == 0) {
@@ -795,10 +802,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
       }
     }
   };
-  if (nst > 10) products(std::integral_constant<int, XS>{});
-  else if (nst > 8) products(std::integral_constant<int, 10>{});
-  else if (nst > 4) products(std::integral_constant<int, 8>{});
-  else if (nst > 0) products(std::integral_constant<int, 4>{});
+  if (nst > 0) products(std::integral_constant<int, NX>{});
 
   LR_STAMP(4);
   // activation noise of the lane's two output items (drawn by whoever runs the epilogue; the last arriver draws it while
@@ -1974,8 +1978,15 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
     k.ksl = pl.ksl; k.nst = pl.nst;
     k.ks_ticket = reinterpret_cast<uint32_t*>(base);
     k.ks_part = reinterpret_cast<float4*>(base + lr_ticket_bytes(pl.total / pl.ksl));
-    if (a->x_dtype == BNN_F32) hipLaunchKernelGGL(lr_fwd_kslice_kernel<true>, grid, block, 0, stream, k);
-    else hipLaunchKernelGGL(lr_fwd_kslice_kernel<false>, grid, block, 0, stream, k);
+#define BNN_LRS(XF)                                                                                             \
+  do {                                                                                                          \
+    if (pl.nst <= 4) hipLaunchKernelGGL((lr_fwd_kslice_kernel<XF, 4>), grid, block, 0, stream, k);              \
+    else if (pl.nst <= 8) hipLaunchKernelGGL((lr_fwd_kslice_kernel<XF, 8>), grid, block, 0, stream, k);         \
+    else if (pl.nst <= 10) hipLaunchKernelGGL((lr_fwd_kslice_kernel<XF, 10>), grid, block, 0, stream, k);       \
+    else hipLaunchKernelGGL((lr_fwd_kslice_kernel<XF, kLrsMaxSteps>), grid, block, 0, stream, k);               \
+  } while (0)
+    if (a->x_dtype == BNN_F32) BNN_LRS(true); else BNN_LRS(false);
+#undef BNN_LRS
   } else if (pl.form == BNN_FORM_GEMM) {
 #ifdef BNN_TUNE
     k.tune = getenv("BNN_TUNE_LRFLAGS") ? atoi(getenv("BNN_TUNE_LRFLAGS")) : 0;
