@@ -1482,6 +1482,14 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
 #pragma unroll
     for (int u = 0; u < kRowsX; ++u)
       xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+    // the lane's four biases (wave 0 applies them after the reduction): requested now, at clamped addresses by every lane -- read
+    // in the epilogue they were a round trip of their own behind the barrier
+    float bmu4[4], brho4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bmu4[i] = p.b_mu[min(q * 4 + i, N - 1)];
+      brho4[i] = p.b_rho[min(q * 4 + i, N - 1)];
+    }
     // prepared operands (p.w_frag, block-uniform): the wave's fragments of its first kRowsX k-steps straight from memory, in the
     // same round trip as x -- nothing is parked, no barrier
     float4 fm[kRowsX], fv[kRowsX];
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int n = q * 4 + i;
-        const float bias = n < N ? __builtin_fmaf(softplus(p.b_rho[n]), eb[i], p.b_mu[n]) : 0.f;
+        const float bias = n < N ? __builtin_fmaf(softplus(brho4[i]), eb[i], bmu4[i]) : 0.f;
         float o = __builtin_fmaf(__builtin_amdgcn_sqrtf(v[i]), ea[i], m[i]) + bias;
         if (p.relu) o = fmaxf(o, 0.f);
         o4[i] = o;
