@@ -1247,17 +1247,18 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 //   bytes lane l of the consuming wave reads back with one ds_read_b128 (conflict-free by construction).
 // Everything else -- epsilon map, statistics, epilogue -- is K1b's; the per-step statistics are summed two lanes-worth at a
 // time (packed fp32 FMAs), so they agree with K1b's to fp32 summation order, the outputs bit for bit.
-template <int NF, int SB, int EPS>
+template <int NF, int SB, int EPS, int NB = 2>
 __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
   constexpr int NW = NF * SB;
+  static_assert(NB == 2 || NB == 3, "staging buffers (NB - 1 k-steps of DMA run-ahead)");
   constexpr int WPW = 4 / SB;                 // parameter pieces (of a tile's four) each of the SB waves of a tile brings
   constexpr int XPW = 8 / NF;                 // x pieces (batch tiles of its pair) each of the NF waves of a pair brings
   static_assert(SB == 1 || SB == 2 || SB == 4, "pairs per block");
   static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
   // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
-  __shared__ __attribute__((aligned(16))) float4 sm_all[2 * (NF * 256 + SB * 512) + NW * 4];
+  __shared__ __attribute__((aligned(16))) float4 sm_all[NB * (NF * 256 + SB * 512) + NW * 4];
   float4 (*sm)[NF * 256 + SB * 512] = reinterpret_cast<float4 (*)[NF * 256 + SB * 512]>(sm_all);
-  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + 2 * (NF * 256 + SB * 512));
+  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + NB * (NF * 256 + SB * 512));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fw = wave % NF, sb = wave / NF;
   const int r = lane & 15, q = lane >> 4;
@@ -1321,7 +1322,15 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
     beps_pre = bias_eps(p, n, s, gs, do_dump);
   }
   stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NB == 3) {
+    // two k-steps of run-ahead (build knob BNN_GEMM_RING=3, tools/build_k1b2_variants.sh): step 1 is in flight while step
+    // 0's pieces are waited for (a one-step layer issues a clamped re-read of step 0 into the idle buffer 1 so that the
+    // counted wait holds on every path)
+    stage(ksteps > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + XPW) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
 
   f32x4 acc[8];
@@ -1334,16 +1343,18 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   // compiled out; the statistics and w run two lanes-worth per instruction (v_pk_fma_f32).  The kernel is bound by its
   // vector instruction stream once the parameters come through LDS (tools/k1b_ablate.py), so every one of them counts.
   typedef __attribute__((ext_vector_type(2))) float f32x2;
-  auto step = [&](int t, auto full_) __attribute__((always_inline)) {
+  auto step = [&](int t, int cur, auto full_) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_)::value;
     const int k = t * 32 + q * 8;
     const bool lane_ok = FULL || (n_ok && k < K);
-    if (t + 1 < ksteps) stage(t + 1, (t + 1) & 1);               // buffer (t+1)&1 was last read in step t-1 (barrier since)
+    // the buffer staged here was last read in step t - 1 (barrier since)
+    const bool staged = t + NB - 1 < ksteps;                     // block-uniform
+    if (staged) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
     // flight that may alias it -- s_waitcnt vmcnt(0) right behind the prefetch this step has just issued -- although
     // buffer t & 1 was complete at the last barrier.  The "+v" operands of the wait tie the consumers to it; the outputs
     // are early-clobber: a result register must not be the address register of a later read of the same statement.
-    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[t & 1][0];
+    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[cur][0];
     const uint32_t pa = lbase + (uint32_t)((fw * 256 + lane) * 16);
     f32x4 m_lo, m_hi, g_lo, g_hi;
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
@@ -1418,20 +1429,23 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
       acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
       acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
     }
-    // this wave's DMA pieces of step t + 1 have landed and its LDS reads of buffer t & 1 are back; then the block meets
-    // (a bare s_barrier: __syncthreads()'s fence would add the same vmcnt(0))
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // this wave's DMA pieces of step t + 1 have landed and its LDS reads of buffer `cur` are back; then the block meets
+    // (a bare s_barrier: __syncthreads()'s fence would add the same vmcnt(0)).  With three buffers the pieces of step
+    // t + 2, issued at the top of this step, stay in flight: vector-memory operations complete in issue order, and
+    // WPW + XPW of them are younger than step t + 1's pieces whenever this step staged anything.
+    if (NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   {
     const bool tiles_full = (tb * NF + NF) * 16 <= N;           // block-uniform
     const int full_steps = tiles_full ? (K >> 5) : 0;           // steps whose 32 k are all inside K
-    int t = 0;
+    int t = 0, cur = 0;
 #pragma nounroll
-    for (; t < full_steps; ++t) step(t, std::true_type{});
+    for (; t < full_steps; ++t, cur = (cur + 1 == NB ? 0 : cur + 1)) step(t, cur, std::true_type{});
 #pragma nounroll
-    for (; t < ksteps; ++t) step(t, std::false_type{});
+    for (; t < ksteps; ++t, cur = (cur + 1 == NB ? 0 : cur + 1)) step(t, cur, std::false_type{});
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
@@ -1582,7 +1596,12 @@ constexpr size_t kL2WeightBudget = 2560 * 1024;   // of an XCD's 4 MiB L2: the (
 #ifndef BNN_GEMM_PAIRS
 #define BNN_GEMM_PAIRS 2
 #endif
+#ifndef BNN_GEMM_RING
+#define BNN_GEMM_RING 2
+#endif
 constexpr int kGemmPairs = BNN_GEMM_PAIRS;   // K1b2: units that share a block's parameter tiles
+constexpr int kGemmRing = BNN_GEMM_RING;     // K1b2: LDS staging buffers (k-steps of DMA run-ahead + 1); 2 x 2 is the measured
+                                             // best of {2, 4} pairs x {2, 3} buffers (profiles/r03_k1b2_variants.log)
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
 constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
 constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
@@ -1733,7 +1752,7 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
     pl.pairs = kGemmPairs;
     pl.nw = 4 * kGemmPairs;
     pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + kGemmPairs - 1) / kGemmPairs);
-    pl.lds = 2 * (4 * 256 + kGemmPairs * 512) * 16 + pl.nw * 16 * sizeof(float);
+    pl.lds = kGemmRing * (4 * 256 + kGemmPairs * 512) * 16 + pl.nw * 16 * sizeof(float);
   }
   return BNN_OK;
 }
@@ -1926,9 +1945,9 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
       const int ub = (int)(((long)a->n_samples * ((a->batch + 127) / 128) + pl.pairs - 1) / pl.pairs);
       k.xc = xcd2d_make((a->out_features + 63) / 64, ub, 1, (size_t)64 * K * 8, kL2WeightBudget);
       const dim3 grid2((unsigned)(((pl.blocks + 7) / 8) * 8)), block2(pl.nw * 64);
-      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_PHILOX>), grid2, block2, 0, stream, k);
-      else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_MEMORY>), grid2, block2, 0, stream, k);
-      else hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_ZERO>), grid2, block2, 0, stream, k);
+      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_PHILOX, kGemmRing>), grid2, block2, 0, stream, k);
+      else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_MEMORY, kGemmRing>), grid2, block2, 0, stream, k);
+      else hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_ZERO, kGemmRing>), grid2, block2, 0, stream, k);
     } else if (ride) {
       const unsigned n_main = grid.x;
       const dim3 grid_r(n_main + (unsigned)rider_blocks);

@@ -32,6 +32,8 @@ for name, kw in (("philox, stats, hoisted sigma", dict(eps_mode=L.EPS_PHILOX, wa
     if os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and name.startswith("eps = 0, no stats") and plan["waves"] == 4:   # (K1b's knobs)
         # tuning build: BNN_TUNE_K1B bits -- 1 no barrier, 2 no vmcnt wait, 4 no parameter loads, 8 no x DMA, 16 no LDS reads, 32 no MFMAs
         tunes = [0, 1, 3, 4, 8, 12, 16, 32, 48, 60, 63]
+    elif os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and name.startswith("philox") and "hoisted" in name and plan["waves"] == 4:
+        tunes = [0, 12, 60, 63]      # the generator (and the statistics) with the memory path / everything else compiled out
     for tn in tunes:
         os.environ["BNN_TUNE_K1B"] = str(tn)
         us = kernel_alone_us(lambda: ops.bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **common), torch.cuda.current_stream(), per_graph=8, reps=10)
