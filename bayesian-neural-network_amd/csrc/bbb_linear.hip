@@ -1972,7 +1972,7 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
   } else if (ride) {
     const unsigned n_main = (unsigned)(((pl.blocks + 7) / 8) * 8);
     const dim3 grid_r(n_main + (unsigned)rider_blocks);
-    const size_t lds_r = pl.lds > (size_t)pl.nw * 3 * sizeof(float) ? pl.lds : (size_t)pl.nw * 3 * sizeof(float);
+    const size_t lds_r = pl.lds > kSampleRedFloats * sizeof(float) ? pl.lds : kSampleRedFloats * sizeof(float);
 #define BNN_RIDE(XDT, RR)                                                                                    \
   do {                                                                                                       \
     err = allow_big_lds(bbb_fwd_rider_kernel<XDT, RR>, lds_r);                                               \

@@ -12,7 +12,8 @@
 // extra HBM write and read; pays for few MC samples (the per-sample weights of many samples would not fit the
 // caches, K1b keeps them in registers instead).
 //
-// Layout: 1-D grid, blocks ordered [layer][sample][chunk]; a block of 256 threads owns 512 consecutive octets
+// Layout: 1-D grid, blocks ordered [layer][group of 4 samples][chunk] (the parameters are read once per group); a block of
+// 256 threads owns 512 consecutive octets
 // (8 consecutive k of one output feature: one 16-byte bf16 store, two Philox groups) of the flattened [out, in]
 // matrix, two per thread, all eight 16-byte parameter loads of a thread issued before any arithmetic.  Needs
 // in_features % 8 == 0 and 16-byte aligned bases.  Statistics: one float4 {sum eps^2, sum w^2 | sum log p_mix,
@@ -23,7 +24,7 @@
 namespace bnn {
 
 __global__ __launch_bounds__(kSampleThreads) void bbb_sample_kernel(const SampleK p) {
-  __shared__ float red[(kSampleThreads / 64) * 3];
+  __shared__ float red[kSampleRedFloats];
   sample_block(p, (int)blockIdx.x, red);
 }
 

@@ -10,6 +10,8 @@ namespace bnn {
 
 constexpr int kSampleThreads = 256;                   // threads of a block that sample (a wider block's other threads idle)
 constexpr int kSampleOctets = 2 * kSampleThreads;     // octets per block
+constexpr int kSampleGroup = 4;                       // samples per block: one read of (mu, rho), one softplus, for all of them
+constexpr int kSampleRedFloats = (kSampleThreads / 64) * 3 * kSampleGroup;   // LDS scratch a block needs (floats)
 
 struct SampleL {
   const float* w_mu;
@@ -22,7 +24,7 @@ struct SampleL {
   int K, N;
   uint32_t layer_id;
   int first_block;      // of the layer
-  int T;                // blocks (= statistics entries) per sample
+  int T;                // chunks (= statistics entries) per sample; a block = one chunk x one group of kSampleGroup samples
   int bias_per_block;   // block `chunk` also samples biases [chunk * bpb, (chunk + 1) * bpb)
   int prior_kind;
   float inv2var1, c1, inv2var2, c2, pi;
@@ -49,8 +51,13 @@ __device__ __forceinline__ float sample_mix_p(const SampleL& L, float w) {
 }
 
 // One block of the sampling job: `block` = index within the job's own block range, `red` = LDS scratch of
-// >= (blockDim.x / 64) * 3 floats.  Every thread of the block must call it (one barrier inside); threads beyond
+// >= kSampleRedFloats floats.  Every thread of the block must call it (one barrier inside); threads beyond
 // kSampleThreads take no octet.
+// A block owns one 512-octet chunk of a layer for a GROUP of up to kSampleGroup samples: (mu, rho) are read and
+// softplus is taken once for the group (the pass was bound by its 8 B read + 2 B written per weight AND sample: 98 us per
+// 4 samples of a 4096 x 4096 layer at 0.85 of the HBM figure; per group of four it moves 16 B per weight instead of 40).
+// Each sample's epsilon, sums and stores are what a one-sample block produced: same statistics entry (sample, chunk),
+// same bits.
 __device__ __forceinline__ void sample_block(const SampleK& p, int block, float* red) {
   if (block >= p.cast_first) {                             // rider: fp32 -> bf16 of the input batch, 8 per thread
     if ((int)threadIdx.x >= kSampleThreads) return;        // (block-uniform branch above: no barrier on this path)
@@ -71,21 +78,19 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
   while (l + 1 < p.n_layers && block >= p.L[l + 1].first_block) ++l;
   const SampleL& L = p.L[l];
   const int local = block - L.first_block;
-  const int s = local / L.T, chunk = local - s * L.T;
+  const int grp = local / L.T, chunk = local - grp * L.T;
+  const int s0 = grp * kSampleGroup;
+  const int ns = min(kSampleGroup, p.S - s0);              // samples of this block (block-uniform)
   const int K = L.K, N = L.N;
   const int opr = K >> 3;                                  // octets per row
   const long total = (long)N * opr;
-  uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
-  if (p.sgrp == 0u) gs += (uint32_t)s;
-  else gs += ((uint32_t)s / p.sgrp) * p.sgrp_stride + (uint32_t)s % p.sgrp;
+  const uint32_t gs_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   const uint32_t gpr = (uint32_t)(K >> 2);
   const uint32_t wid = L.layer_id * 4u;
-  const bool do_ls = s == 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool active = (int)threadIdx.x < kSampleThreads;
   if (!active) {                                          // whole waves (kSampleThreads is a multiple of 64): a wider block's
-    if (lane == 0) red[wave * 3 + 0] = red[wave * 3 + 1] = red[wave * 3 + 2] = 0.f;   // extra waves only meet the barrier
-    __syncthreads();
+    __syncthreads();                                      // extra waves only meet the barrier
     return;
   }
 
@@ -95,7 +100,7 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
   float4 m[2][2], r[2][2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    o[u] = active ? (long)chunk * kSampleOctets + u * kSampleThreads + threadIdx.x : total;   // idle threads: no octet
+    o[u] = (long)chunk * kSampleOctets + u * kSampleThreads + threadIdx.x;
     const long oc = o[u] < total ? o[u] : total - 1;
     n[u] = (int)(oc / opr);
     k[u] = (int)(oc - (long)n[u] * opr) << 3;
@@ -115,63 +120,88 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
   }
   __builtin_amdgcn_sched_barrier(0);                      // the loads stay one batch ahead of the generator work
 
-  float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
+  // ---- once per group: sigma (and, for the group that holds sample 0, the sum of log sigma)
+  float mu[2][8], sg[2][8];
+  float ls_oct[2] = {0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const bool ok = o[u] < total;
-    const uint32_t g = (uint32_t)n[u] * gpr + (uint32_t)(k[u] >> 2);
-    float e[8];
-    philox_normal4(g, gs, wid, p.k0, p.k1, e);
-    philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
-    const float mu[8] = {m[u][0].x, m[u][0].y, m[u][0].z, m[u][0].w, m[u][1].x, m[u][1].y, m[u][1].z, m[u][1].w};
+    const float mm[8] = {m[u][0].x, m[u][0].y, m[u][0].z, m[u][0].w, m[u][1].x, m[u][1].y, m[u][1].z, m[u][1].w};
     const float rh[8] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y, r[u][1].z, r[u][1].w};
-    float w[8], e2 = 0.f, a = 0.f, ls = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float sg = softplus(rh[j]);
-      w[j] = __builtin_fmaf(sg, e[j], mu[j]);
-      e2 = __builtin_fmaf(e[j], e[j], e2);
-      if (L.prior_kind == BNN_PRIOR_GAUSS) a = __builtin_fmaf(w[j], w[j], a);
-      else a = add_log(a, sample_mix_p(L, w[j]));
-      if (do_ls) ls = add_log(ls, sg);
+      mu[u][j] = mm[j];
+      sg[u][j] = softplus(rh[j]);
     }
-    s_e2 += ok ? e2 : 0.f;
-    s_a += ok ? a : 0.f;
-    s_ls += ok ? ls : 0.f;
-    if (ok) {
-      bf16x8 wb;
+    if (s0 == 0) {                                         // block-uniform
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wb[j] = (__bf16)w[j];
-      *reinterpret_cast<bf16x8*>(L.w_out + ((size_t)s * N + n[u]) * K + k[u]) = wb;
+      for (int j = 0; j < 8; ++j) ls_oct[u] = add_log(ls_oct[u], sg[u][j]);
     }
   }
-  if (has_bias) {
-    float e4[4];
-    philox_normal4((uint32_t)(bn >> 2), gs, wid + 1u, p.k0, p.k1, e4);
-    const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
-    const float sg = softplus(brho);
-    const float b = __builtin_fmaf(sg, e, bmu);
-    L.b_out[(size_t)s * N + bn] = b;
-    s_e2 = __builtin_fmaf(e, e, s_e2);
-    s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
-    if (do_ls) s_ls = add_log(s_ls, sg);
-  }
-  const float a0 = wave_sum(s_e2), a1 = wave_sum(s_a), a2 = wave_sum(s_ls);
-  if (lane == 0) {
-    red[wave * 3 + 0] = a0;
-    red[wave * 3 + 1] = a1;
-    red[wave * 3 + 2] = a2;
+  const float bsg = has_bias ? softplus(brho) : 0.f;
+
+#pragma unroll 1
+  for (int si = 0; si < ns; ++si) {
+    const int s = s0 + si;
+    uint32_t gs = gs_base;
+    if (p.sgrp == 0u) gs += (uint32_t)s;
+    else gs += ((uint32_t)s / p.sgrp) * p.sgrp_stride + (uint32_t)s % p.sgrp;
+    const bool do_ls = s == 0;
+    float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bool ok = o[u] < total;
+      const uint32_t g = (uint32_t)n[u] * gpr + (uint32_t)(k[u] >> 2);
+      float e[8];
+      philox_normal4(g, gs, wid, p.k0, p.k1, e);
+      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+      float w[8], e2 = 0.f, a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w[j] = __builtin_fmaf(sg[u][j], e[j], mu[u][j]);
+        e2 = __builtin_fmaf(e[j], e[j], e2);
+        if (L.prior_kind == BNN_PRIOR_GAUSS) a = __builtin_fmaf(w[j], w[j], a);
+        else a = add_log(a, sample_mix_p(L, w[j]));
+      }
+      s_e2 += ok ? e2 : 0.f;
+      s_a += ok ? a : 0.f;
+      s_ls += (ok && do_ls) ? ls_oct[u] : 0.f;
+      if (ok) {
+        bf16x8 wb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wb[j] = (__bf16)w[j];
+        *reinterpret_cast<bf16x8*>(L.w_out + ((size_t)s * N + n[u]) * K + k[u]) = wb;
+      }
+    }
+    if (has_bias) {
+      float e4[4];
+      philox_normal4((uint32_t)(bn >> 2), gs, wid + 1u, p.k0, p.k1, e4);
+      const float e = (bn & 3) == 0 ? e4[0] : (bn & 3) == 1 ? e4[1] : (bn & 3) == 2 ? e4[2] : e4[3];
+      const float b = __builtin_fmaf(bsg, e, bmu);
+      L.b_out[(size_t)s * N + bn] = b;
+      s_e2 = __builtin_fmaf(e, e, s_e2);
+      s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
+      if (do_ls) s_ls = add_log(s_ls, bsg);
+    }
+    const float a0 = wave_sum(s_e2), a1 = wave_sum(s_a), a2 = wave_sum(s_ls);
+    if (lane == 0) {
+      float* rd = red + (si * (kSampleThreads / 64) + wave) * 3;
+      rd[0] = a0;
+      rd[1] = a1;
+      rd[2] = a2;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if ((int)threadIdx.x < ns) {                            // thread si folds sample s0 + si: the four waves in wave order
+    const int si = threadIdx.x;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-    for (int wv = 0; wv < kSampleThreads / 64 && wv < nwv; ++wv) {   // idle waves hold zeros: the sum is that of a 256-thread block
-      t0 += red[wv * 3 + 0];
-      t1 += red[wv * 3 + 1];
-      t2 += red[wv * 3 + 2];
+    for (int wv = 0; wv < kSampleThreads / 64; ++wv) {
+      const float* rd = red + (si * (kSampleThreads / 64) + wv) * 3;
+      t0 += rd[0];
+      t1 += rd[1];
+      t2 += rd[2];
     }
-    L.ws[1 + (size_t)s * L.T + chunk] = make_float4(t0, t1, t2, 0.f);
-    if (local == 0) L.ws[0] = make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f);
+    L.ws[1 + (size_t)(s0 + si) * L.T + chunk] = make_float4(t0, t1, t2, 0.f);
+    if (local == 0 && si == 0) L.ws[0] = make_float4(__int_as_float(L.T), 0.f, 0.f, 0.f);
   }
 }
 
@@ -225,7 +255,7 @@ static inline int fill_sample(const bnn_bbb_sample_args* a, bnn::SampleK& k, lon
       if (!(l.prior.sigma_p > 0.f)) return BNN_ERR_SHAPE;
       o.inv2var1 = o.inv2var2 = o.c1 = o.c2 = 0.f;
     }
-    blocks += (long)o.T * a->n_samples;
+    blocks += (long)o.T * ((a->n_samples + kSampleGroup - 1) / kSampleGroup);
     if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
   }
   for (int i = a->n_layers; i < BNN_SAMPLE_MAX_LAYERS; ++i) {
