@@ -102,16 +102,28 @@ SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per e
 LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
 
 
-def lr_use_split(out_features: int, samples: int, batch: int) -> bool:
+LR_SHARED_MAX_SAMPLES = 23    # csrc/lr_linear.hip: kLrsMaxShared (from LR_PREPARE_MIN_SAMPLES on K3b is the faster way)
+
+
+def lr_unit_samples(samples: int, shared: bool) -> int:
+    """Samples the K3s units count: all samples of a launch on ONE input (the first layer of sample_elbo_lr / predict: the
+    reference runs forward(x) `samples` times on the same x, networks.py:211-225) share the unit's two products -- the
+    kernel makes them once and runs the epilogue (bias, activation noise, stores) per sample."""
+    return 1 if (shared and 2 <= samples <= LR_SHARED_MAX_SAMPLES) else samples
+
+
+def lr_use_split(out_features: int, samples: int, batch: int, shared: bool = False) -> bool:
     """Worth handing bnn_lr_linear_fwd a split scratch (K3s: at most 160 (32-feature group, sample, batch block) units)."""
+    samples = lr_unit_samples(samples, shared)
     return out_features >= 64 and out_features % 4 == 0 and ((out_features + 31) // 32) * samples * ((batch + 127) // 128) <= 160
 
 
-def lr_kslice_expected(in_features: int, out_features: int, samples: int, batch: int) -> bool:
+def lr_kslice_expected(in_features: int, out_features: int, samples: int, batch: int, shared: bool = False) -> bool:
     """Mirror of the library's plan for K3s (csrc/lr_linear.hip: lr_plan): True where a launch with a split scratch and bf16
     math takes the K-sliced form -- used to decide whether a rider is worth attaching (elsewhere it costs a launch)."""
-    if not lr_use_split(out_features, samples, batch) or in_features % 8 or in_features < 64:
+    if not lr_use_split(out_features, samples, batch, shared) or in_features % 8 or in_features < 64:
         return False
+    samples = lr_unit_samples(samples, shared)
     units = ((out_features + 31) // 32) * samples * ((batch + 127) // 128)
     ksteps = (in_features + 31) // 32
     ksl = min(8, max(1, 160 // units))
@@ -188,6 +200,12 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     # LR: and its elementwise square) and sigma = softplus(rho) of the layers that will run a block-GEMM form
     want_cast = hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES  # (eager
     # calls are host-bound: the one-sample LR cast of GraphedElbo would only add a launch here)
+    # LR, 2 .. 23 samples on one minibatch: the first layer's K3s makes its products once for all of them and reads the fp32
+    # minibatch itself
+    first_shared = (layers[0].lr and x.dim() == 2 and not differentiable and hidden_dtype == torch.bfloat16 and len(layers) > 1 and
+                    lr_unit_samples(n_local, True) == 1 and lr_kslice_expected(*layers[0].in_out, n_local, x.shape[-2], True))
+    if first_shared and all(sp.lr for sp in layers):
+        want_cast = False
     hoisted = {}
     if hidden_dtype == torch.bfloat16 and sample and not differentiable and (x.dtype == torch.bfloat16 or want_cast):
         hoisted = {i: None for i, sp in enumerate(layers)
@@ -228,7 +246,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
             if sp.lr:
                 want_sq = lr_sq and not last
                 wfrag, ws_pre = (None, None)
-                if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]):
+                shared_i = i == 0 and first_shared
+                if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]) and not shared_i:
                     wfrag, ws_pre = ops.lr_prepare(*pd)
                 if last and fin_kw is not None and want_stats and eps_mode == L.EPS_PHILOX and fin_kw.get("scratch") is not None \
                         and not wide_nll(layers, h.shape[-2]) and all(q.lr for q in layers):
@@ -247,8 +266,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                                         want_kl=want_stats, x_sq=h_sq if lr_sq else None,
                                         out_sq=torch.empty((n_local, h.shape[-2], sp.in_out[1]), dtype=torch.bfloat16,
                                                            device=h.device) if want_sq else None,
-                                        split_scratch=ops.lr_split_scratch_cached(n_local, h.shape[-2], sp.in_out[1], h.device)
-                                        if (wfrag is None and not last and lr_use_split(sp.in_out[1], n_local, h.shape[-2])) else None)
+                                        split_scratch=ops.lr_split_scratch_cached(lr_unit_samples(n_local, shared_i), h.shape[-2], sp.in_out[1], h.device)
+                                        if (wfrag is None and not last and lr_use_split(sp.in_out[1], n_local, h.shape[-2], shared_i)) else None)
                 h_sq = out["y_sq"]
             else:
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
@@ -507,14 +526,17 @@ class GraphedElbo:
             if lb:
                 self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
         # LR, 1-2 samples: the first layer's K-sliced form (K3s) reads the fp32 minibatch itself -- no cast launch ahead of it
+        # (2 .. 23 samples of one minibatch share that layer's products: lr_unit_samples)
+        shared0 = self.lr and not self.G > 1 and lr_unit_samples(S, True) == 1
         k3s_first = (self.lr and hid == torch.bfloat16 and len(self.specs) > 1 and self.specs[0].in_out[0] % 8 == 0 and
-                     lr_use_split(self.specs[0].in_out[1], S, B) and not self.G > 1)
+                     lr_use_split(self.specs[0].in_out[1], S, B, shared0) and not self.G > 1)
+        shared0 = shared0 and k3s_first
         self.x16 = (torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev)
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
                         (self.lib[0] or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) and
                         not k3s_first) else None)
-        self.lr_sq = self.lr and self.x16 is not None and S >= LR_SQUARES_MIN_SAMPLES
-        self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if self.lr_sq else None
+        self.lr_sq = self.lr and (self.x16 is not None or (k3s_first and hid == torch.bfloat16)) and S >= LR_SQUARES_MIN_SAMPLES
+        self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and self.x16 is not None) else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
                         else None for i, b in enumerate(self.bufs)]
         self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
@@ -523,8 +545,9 @@ class GraphedElbo:
                       for i, sp in enumerate(self.specs)]
         # K3s (1-3 samples on a wide LR layer): the K slices of a 32-feature group meet through this scratch; the library's
         # plan decides whether a launch uses it
-        self.lr_split = [ops.lr_split_scratch(S, B, sp.in_out[1], dev)
-                         if (self.lr and hid == torch.bfloat16 and i < len(self.specs) - 1 and lr_use_split(sp.in_out[1], S, B)) else None
+        self.lr_split = [ops.lr_split_scratch(lr_unit_samples(S, shared0 and i == 0), B, sp.in_out[1], dev)
+                         if (self.lr and hid == torch.bfloat16 and i < len(self.specs) - 1 and
+                             lr_use_split(sp.in_out[1], S, B, shared0 and i == 0)) else None
                          for i, sp in enumerate(self.specs)]
         self.wsigma = [torch.empty_like(sp.m.weight_rho.detach())
                       if (not self.lr and hid == torch.bfloat16 and not lb and hoist_sigma(*sp.in_out, S, B)) else None
@@ -532,7 +555,8 @@ class GraphedElbo:
         self.wfrag = [None] * len(self.specs)
         if self.lr_sq:
             self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
-                          if lr_use_prepare(sp.in_out[1], S, B) else None for sp in self.specs]
+                          if (lr_use_prepare(sp.in_out[1], S, B) and not (shared0 and i == 0)) else None
+                          for i, sp in enumerate(self.specs)]
         # LR, few samples: the narrow output layer's operands are prepared by a rider of the previous layer's launch
         # (bnn_lr_rider), so that the row-split final launch (K3r) parks nothing
         nl = len(self.specs)
@@ -577,9 +601,9 @@ class GraphedElbo:
         if self.x16 is not None or hoist:
             ops.eval_prepare([self.specs[i].m.weight_rho.detach() for i in hoist], [self.wsigma[i] for i in hoist],
                              cast=self.x if self.x16 is not None else None, cast_out=self.x16,
-                             cast_out_sq=self.x16_sq if self.lr_sq else None)
+                             cast_out_sq=self.x16_sq)
             if self.x16 is not None:
-                h, h_sq = self.x16, (self.x16_sq if self.lr_sq else None)
+                h, h_sq = self.x16, self.x16_sq
         last = len(self.specs) - 1
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],

@@ -207,13 +207,14 @@ class GraphedTrainStep:
     def _lr_scratch(self, i, sp, hin):
         """K3s scratch of LR hidden layer i (None when the launch could not use one): allocated and zeroed at the first
         forward outside capture (construction warms the step up before it captures); the kernel leaves its counters zero."""
-        from .engine import lr_use_split
-        if hin.dtype != torch.bfloat16 or not lr_use_split(sp.in_out[1], self.samples, hin.shape[-2]):
+        from .engine import lr_use_split, lr_unit_samples
+        shared = hin.dim() == 2                     # the step's samples on one minibatch: the first layer's products are made once
+        if hin.dtype != torch.bfloat16 or not lr_use_split(sp.in_out[1], self.samples, hin.shape[-2], shared):
             return None
         if i not in self._lr_split:
             if torch.cuda.is_current_stream_capturing():
                 return None
-            self._lr_split[i] = ops.lr_split_scratch(self.samples, hin.shape[-2], sp.in_out[1], hin.device)
+            self._lr_split[i] = ops.lr_split_scratch(lr_unit_samples(self.samples, shared), hin.shape[-2], sp.in_out[1], hin.device)
         return self._lr_split[i]
 
     def _chain(self, stop_above_layer0: bool = False):

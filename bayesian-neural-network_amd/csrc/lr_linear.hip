@@ -63,6 +63,8 @@ struct LrK {
   float4* rd_ws;                 // header {blocks}, then one KL entry per rider block
   int rd_K, rd_N, rd_blocks, rd_spb, main_blocks;   // rider blocks, k-steps per rider block, first rider block index
   int ksl, nst;                  // K3s: K-range slices per unit, k-steps (of 32) per slice
+  int es;                        // K3s: samples per unit (> 1: all samples share x -- the unit's products are made once and
+                                 // its epilogue runs per sample; the units then count ONE sample)
   uint32_t* ks_ticket;           // K3s: [unit] arrival counters of a unit's slice blocks, zero between launches
   float4* ks_part;               // K3s: [unit][slice][wave 8][feature tile 2][mean | variance][64] x 16 B partial tiles
 #ifdef BNN_STAMPS
@@ -572,6 +574,9 @@ __device__ __forceinline__ void lr_rider_block(const LrK& p, int rb, char* lds_i
 
 constexpr int kLrsMaxSteps = 13;   // k-steps per slice (x fragments a wave keeps in registers)
 constexpr int kLrsMaxSlices = 8;
+constexpr int kLrsMaxShared = 23;  // samples that may share one unit's products (their biases wait in LDS).  The unit's epilogues
+                                   // all run in the block that arrives last (38 blocks on a 1200-wide layer, ~1.6 us per sample):
+                                   // from 24 samples on the block-GEMM form over prepared fragments (K3b) is the faster way
 
 // XF32: the layer input is fp32 (the first layer of an evaluation: the minibatch as it arrives -- no cast launch ahead of it);
 // a fragment is then two 16-byte loads, rounded to bf16 in registers where the cast kernel would have rounded it
@@ -582,21 +587,25 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
   constexpr int NW = 8, XS = NX;
   constexpr int kTilesBytes = XS * 4096 > kLrRiderSteps * 2048 ? XS * 4096 : kLrRiderSteps * 2048;   // (a rider block's two images)
   __shared__ __attribute__((aligned(16))) char tiles[kTilesBytes];   // [step][mean | variance][32 k][64 B]
-  __shared__ float lds_bias[32];
+  __shared__ float lds_bias[kLrsMaxShared * 32];
   __shared__ float lds_red[3 * NW];
   __shared__ uint32_t last_s;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B, KSL = p.ksl;
+  // All samples on ONE input (x_sstride == 0, e.g. the first layer of sample_elbo_lr / predict: networks.py:211-225 runs
+  // forward(x) `samples` times on the same x): m = x M and v = x^2 sigma^2 do not depend on the sample, only the bias and
+  // the activation noise do.  The units then count one sample, and whoever runs a unit's epilogue runs it ES times.
+  const int ES = p.es, SU = ES > 1 ? 1 : p.S;
   const int G = (N + 31) >> 5, mbs = (B + 127) >> 7;
   if (p.rd_blocks > 0 && (int)blockIdx.x >= p.main_blocks) {   // rider blocks sit behind the (padded) main grid
     lr_rider_block(p, (int)blockIdx.x - p.main_blocks, tiles, lds_red);
     return;
   }
   int item;
-  if (!xcd_work_item(G * p.S * mbs * KSL, item)) return;       // block-uniform
+  if (!xcd_work_item(G * SU * mbs * KSL, item)) return;        // block-uniform
   const int ks = item % KSL, unit = item / KSL;
-  const int g = unit / (p.S * mbs), s = (unit / mbs) % p.S, mb = unit % mbs;
+  const int g = unit / (SU * mbs), s = (unit / mbs) % SU, mb = unit % mbs;
   const int n0 = g * 32, m0 = mb * 128;
   const int mtiles = min(8, (B - m0 + 15) >> 4);
   const int ksteps = (K + 31) >> 5;
@@ -720,6 +729,20 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
         s_s2 = __builtin_fmaf(bsig, bsig, s_s2);
         s_m2 = __builtin_fmaf(bmu_pre, bmu_pre, s_m2);
       }
+      for (int se = 1; se < ES; ++se) {                        // the other samples' biases (sample 0's is `b`)
+        float be = 0.f;
+        if (p.eps_mode == BNN_EPS_PHILOX) {
+          float e4[4];
+          philox_normal4((uint32_t)(n >> 2), gs + (uint32_t)se, p.layer_id * 4u + 1u, p.k0, p.k1, e4);   // (no sample groups here)
+          be = (n & 3) == 0 ? e4[0] : (n & 3) == 1 ? e4[1] : (n & 3) == 2 ? e4[2] : e4[3];
+        } else if (p.eps_mode == BNN_EPS_MEMORY) {
+          be = p.eps_b[(size_t)se * N + n];
+        }
+        if (p.eps_b_dump && mb == 0 && ks == 0) p.eps_b_dump[(size_t)se * N + n] = be;
+        lds_bias[se * 32 + lane] = __builtin_fmaf(bsig, be, bmu_pre);
+      }
+    } else {
+      for (int se = 1; se < ES; ++se) lds_bias[se * 32 + lane] = 0.f;
     }
     lds_bias[lane] = b;
   }
@@ -870,6 +893,15 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
     for (int ft = 0; ft < 2; ++ft) {
       const int nb = n0 + ft * 16 + q * 4;
       if (nb < N) lr_epilogue_item(p, s, gs, brow, nb, acc[ft][0], acc[ft][1], lds_bias + ft * 16 + q * 4, eps_pre[ft]);
+    }
+#pragma nounroll
+    for (int se = 1; se < ES; ++se) {                          // the other samples of a shared-input unit: noise, bias, stores
+      const uint32_t gse = gs + (uint32_t)se;                  // (shared input: no sample groups; lr_global_sample would re-read the counter)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const int nb = n0 + ft * 16 + q * 4;
+        if (nb < N) lr_epilogue_item(p, se, gse, brow, nb, acc[ft][0], acc[ft][1], lds_bias + se * 32 + ft * 16 + q * 4);
+      }
     }
   }
   LR_STAMP(7);
@@ -1791,7 +1823,7 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.xg = a->x_per_sample > 0 ? a->x_per_sample : 1;
   k.sgrp = a->sample_group; k.sgrp_stride = a->sample_group_stride;
-  k.ksl = 1; k.nst = 0; k.ks_ticket = nullptr; k.ks_part = nullptr;
+  k.ksl = 1; k.nst = 0; k.es = 1; k.ks_ticket = nullptr; k.ks_part = nullptr;
   k.rd_blocks = 0; k.main_blocks = 0;
   if (a->rider) {
     const bnn_lr_rider* rd = a->rider;
@@ -1834,7 +1866,13 @@ struct LrPlan {
   long total;       // blocks
   size_t lds;
   int ksl, nst;     // K3s: slices per unit, k-steps per slice
+  int es;           // K3s: samples per unit (shared input), 1 otherwise
 };
+
+// K3s over ONE input for all samples (x_per_sample == 0, 2 .. kLrsMaxShared samples): the unit's two products are made once
+static bool lr_shared_input(const bnn_lr_fwd_args* a) {
+  return a->x_per_sample == 0 && a->n_samples > 1 && a->n_samples <= kLrsMaxShared && a->sample_group == 0;
+}
 
 static size_t lr_ticket_bytes(long units) { return (((size_t)units * 4 + 255) / 256) * 256; }
 static long lr_split_units(int n_samples, int batch, int out_features) {
@@ -1850,9 +1888,15 @@ extern "C" size_t bnn_lr_split_scratch_bytes(int32_t n_samples, int32_t batch, i
   return lr_ticket_bytes(units) + (size_t)units * kLrsMaxSlices * (8 * 4 * 64 * 16);
 }
 
+static int lr_kslice_plan(const bnn_lr_fwd_args* a, LrPlan& pl);
+
 static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const int K = a->in_features, N = a->out_features, mbs = (a->batch + 127) / 128;
   const long gemm_blocks = (long)((N + 63) / 64) * a->n_samples * mbs;
+  pl.es = 1;
+  // all samples on one input: the K-sliced form makes the products once -- ahead of the block-GEMM form, which would
+  // make them per sample
+  if (lr_shared_input(a) && a->form == BNN_FORM_AUTO && lr_kslice_plan(a, pl) == BNN_OK) return BNN_OK;
   // K3b needs bf16 x AND x^2 streams; the saved variance (v_out) is a K3a epilogue
   const bool can = !a->v_out && !a->y_bf16_copy && !a->hfac_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
@@ -1873,34 +1917,8 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   // K3s: few samples on a wide layer -- 32-feature groups x K slices, so that ~150-300 blocks exist and each pulls
   // whole parameter lines and a slice of x through its CU (see lr_fwd_kslice_kernel)
   pl.ksl = 1; pl.nst = 0;
-  {
-    const long units = lr_split_units(a->n_samples, a->batch, N);
-    const int ksteps = (K + 31) / 32;
-    const bool ok = a->math == BNN_MATH_BF16 && (K % 8 == 0) && K >= 64 && (N % 4 == 0) && N >= 64 &&
-                    a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
-                    a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(a->n_samples, a->batch, N) &&
-                    !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
-                    (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE) && units <= 160;
-    if (ok) {
-      int ksl = (int)(160 / units);
-      ksl = ksl < 1 ? 1 : ksl > kLrsMaxSlices ? kLrsMaxSlices : ksl;
-#if defined(BNN_TUNE) || defined(BNN_STAMPS)
-      if (const char* v = getenv("BNN_TUNE_LRKSL")) { const int f = atoi(v); if (f >= 1 && f <= kLrsMaxSlices) ksl = f; }
-#endif
-      while (ksl < kLrsMaxSlices && (ksteps + ksl - 1) / ksl > kLrsMaxSteps) ++ksl;
-      const int nst = (ksteps + ksl - 1) / ksl;
-      ksl = (ksteps + nst - 1) / nst;                          // no empty slices
-      if (nst <= kLrsMaxSteps && units * ksl <= 256) {          // one round of blocks: slices that queue behind each other gain nothing
-        pl.form = BNN_FORM_GEMM_KSLICE;
-        pl.R = 1; pl.MT = 8; pl.nw = 8;
-        pl.ksl = ksl; pl.nst = nst;
-        pl.total = units * ksl;
-        pl.lds = (size_t)kLrsMaxSteps * 4096 + (32 + 24 + 1) * sizeof(float);
-        return BNN_OK;
-      }
-    }
-    if (a->form == BNN_FORM_GEMM_KSLICE) return BNN_ERR_ENUM;  // asked for, not possible
-  }
+  if (lr_kslice_plan(a, pl) == BNN_OK) return BNN_OK;
+  if (a->form == BNN_FORM_GEMM_KSLICE) return BNN_ERR_ENUM;  // asked for, not possible
   int R = 1;
   while (R < 4 && (long)((N + 16 / R - 1) / (16 / R)) * a->n_samples * mbs < 120) R *= 2;
 #ifdef BNN_TUNE
@@ -1929,6 +1947,36 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   pl.R = R; pl.MT = MT; pl.nw = nw;
   pl.total = (long)((N + F - 1) / F) * a->n_samples * ((a->batch + 16 * MT - 1) / (16 * MT));
   pl.lds = ((size_t)nw * MT * 64 * 4 + 16 + 3 * nw) * sizeof(float);
+  return BNN_OK;
+}
+
+// K3s geometry; BNN_OK when the K-sliced form applies (pl filled), BNN_ERR_ENUM otherwise
+static int lr_kslice_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
+  const int K = a->in_features, N = a->out_features;
+  const bool shared = lr_shared_input(a);
+  const long units = lr_split_units(shared ? 1 : a->n_samples, a->batch, N);
+  const int ksteps = (K + 31) / 32;
+  const bool ok = a->math == BNN_MATH_BF16 && (K % 8 == 0) && K >= 64 && (N % 4 == 0) && N >= 64 &&
+                  a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
+                  a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(shared ? 1 : a->n_samples, a->batch, N) &&
+                  !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
+                  (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE) && units <= 160;
+  if (!ok) return BNN_ERR_ENUM;
+  int ksl = (int)(160 / units);
+  ksl = ksl < 1 ? 1 : ksl > kLrsMaxSlices ? kLrsMaxSlices : ksl;
+#if defined(BNN_TUNE) || defined(BNN_STAMPS)
+  if (const char* v = getenv("BNN_TUNE_LRKSL")) { const int f = atoi(v); if (f >= 1 && f <= kLrsMaxSlices) ksl = f; }
+#endif
+  while (ksl < kLrsMaxSlices && (ksteps + ksl - 1) / ksl > kLrsMaxSteps) ++ksl;
+  const int nst = (ksteps + ksl - 1) / ksl;
+  ksl = (ksteps + nst - 1) / nst;                          // no empty slices
+  if (nst > kLrsMaxSteps || units * ksl > 256) return BNN_ERR_ENUM;   // one round of blocks: slices that queue behind each other gain nothing
+  pl.form = BNN_FORM_GEMM_KSLICE;
+  pl.R = 1; pl.MT = 8; pl.nw = 8;
+  pl.ksl = ksl; pl.nst = nst;
+  pl.es = shared ? a->n_samples : 1;
+  pl.total = units * ksl;
+  pl.lds = (size_t)kLrsMaxSteps * 4096 + (kLrsMaxShared * 32 + 24 + 1) * sizeof(float);
   return BNN_OK;
 }
 
@@ -1983,7 +2031,7 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
   }
   if (pl.form == BNN_FORM_GEMM_KSLICE) {
     char* base = reinterpret_cast<char*>(a->split_scratch);
-    k.ksl = pl.ksl; k.nst = pl.nst;
+    k.ksl = pl.ksl; k.nst = pl.nst; k.es = pl.es;
     k.ks_ticket = reinterpret_cast<uint32_t*>(base);
     k.ks_part = reinterpret_cast<float4*>(base + lr_ticket_bytes(pl.total / pl.ksl));
 #define BNN_LRS(XF)                                                                                             \

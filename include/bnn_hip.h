@@ -356,7 +356,12 @@ typedef struct bnn_lr_fwd_args {
                                (the kernel leaves them zero): lets a launch of 1-3 samples on a wide layer split the K
                                range of a 32-feature group over several blocks that meet through it (BNN_FORM_GEMM_KSLICE;
                                bf16 math on bf16 x, in_features % 8 == 0, out_features % 4 == 0).  One launch at a time
-                               per scratch. */
+                               per scratch.
+                               With x_per_sample == 0 and 2 .. 23 samples (no sample groups) -- the first layer of
+                               sample_elbo_lr / predict, where the reference runs forward(x) per sample on the same x
+                               (networks.py:211-225) -- the two products x M and x^2 sigma^2 are made ONCE per launch and
+                               only the bias, the activation noise and the stores run per sample; the scratch then only
+                               needs the sizes of n_samples = 1. */
   size_t split_scratch_bytes;
 } bnn_lr_fwd_args;
 

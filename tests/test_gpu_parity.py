@@ -1095,10 +1095,13 @@ def test_c5_wide_bbb_layer_against_oracle(dev, form):
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 1200, 1200), (1, 128, 784, 1200), (2, 128, 1200, 1200), (3, 100, 264, 72),
-                                   (1, 20, 1000, 1200), (1, 128, 64, 4096)])
+                                   (1, 20, 1000, 1200), (1, 128, 64, 4096), (10, 128, 784, 1200), (23, 100, 264, 136)])
 def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
     """K3s (lr_fwd_kslice_kernel, BNN_FORM_GEMM_KSLICE): 32-feature groups x K slices meeting through a scratch, for 1-2
-    samples on a wide [in,out] layer (more where the layer is narrower).  y, y^2, the saved variance and the backward factor against the oracle
+    samples on a wide [in,out] layer (more where the layer is narrower) -- and for 2 .. 23 samples on ONE input (the first
+    layer of sample_elbo_lr / predict, networks.py:211-225: the reference runs forward(x) per sample on the same x), where a
+    unit's two products are made once and its epilogue runs per sample (the S > 1 shapes here: x is [batch, in]).
+    y, y^2, the saved variance and the backward factor against the oracle
     (networks.py:116-138) and against K3a on the same inputs; the KL sums; twice the same bits (the slices are added in
     slice order whoever arrives last); ragged batch, K tail inside a k-step, a slice count that does not divide the
     k-steps, N % 32 != 0."""
@@ -1123,10 +1126,13 @@ def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
     torch.set_num_threads(1)
     kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.float32, eps_mode=L.EPS_PHILOX, seed=seed,
               layer_id=2, sample_offset=off, want_kl=True, want_scalars=True, want_v=True, want_hfac=True, want_y16=True)
-    scratch = ops.lr_split_scratch(S, B, N, dev)
+    SU = 1                                                      # samples a unit counts: they all read the one x
+    scratch = ops.lr_split_scratch(SU, B, N, dev)
     plan = ops.lr_plan(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw)
     assert plan["form"] == L.FORM_GEMM_KSLICE and plan["features_per_block"] == 32, plan
-    assert plan["blocks"] == ((N + 31) // 32) * S * ((B + 127) // 128) * plan["k_slices"], plan
+    assert plan["blocks"] == ((N + 31) // 32) * SU * ((B + 127) // 128) * plan["k_slices"], plan
+    if S > 1:                                                   # without being asked for, ahead of the per-sample forms
+        assert ops.lr_plan(x16, *dw, form=L.FORM_AUTO, split_scratch=scratch, **kw)["form"] == L.FORM_GEMM_KSLICE
     sq = lambda: torch.empty((S, B, N), dtype=torch.bfloat16, device=dev)
     a = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
     a2 = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=sq(), **kw)
@@ -1151,10 +1157,18 @@ def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
         assert torch.equal(frag.view(torch.int32), ref_frag.view(torch.int32)), fm
         assert float((ws_sum(wsr) - ws_sum(ref_ws)).abs().max()) <= 1e-5 * float(ws_sum(ref_ws).abs().max()), fm
         assert torch.equal(a4["y"], (a if fm == L.FORM_GEMM_KSLICE else b)["y"]), fm
-    zero = L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4
+    zero = L.load().bnn_lr_split_scratch_zero_bytes(SU, B, N) // 4
     assert int(scratch[:zero].abs().sum()) == 0                # the arrival counters are left at zero
     for key in ("y", "y_sq", "v", "hfac", "y16", "kl3"):
         assert torch.equal(a[key], a2[key]), key               # reproducible bit for bit
+    if S > 1:
+        # the shared products: every sample's saved variance is the same tile, and each sample alone (its own launch at its own
+        # Philox offset, one unit per sample) gives the same bits
+        assert all(torch.equal(a["v"][0], a["v"][s]) for s in range(1, S))
+        for s in (0, S - 1):
+            one = ops.lr_linear_fwd(x16, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, out_sq=torch.empty((1, B, N), dtype=torch.bfloat16, device=dev),
+                                    **dict(kw, n_samples=1, sample_offset=off + s))
+            assert torch.equal(one["y"][0], a["y"][s]) and torch.equal(one["hfac"][0], a["hfac"][s]), s
     close(a["kl3"][0], ref[0][1], rtol=1e-5)
     close(a["kl3"][0], float(b["kl3"][0]), rtol=1e-6)
     for s in range(S):
@@ -1236,7 +1250,8 @@ def test_lr_k_sliced_form_over_random_shapes_against_k3a(dev):
         assert torch.isfinite(a["y"]).all(), (S, B, K, N)
         assert float((a["y"] - b["y"]).abs().max()) <= 3e-3 * scale, (S, B, K, N, plan, float((a["y"] - b["y"]).abs().max()), scale)
         close(a["kl3"][0], float(b["kl3"][0]), rtol=2e-6)
-        assert int(scratch[:L.load().bnn_lr_split_scratch_zero_bytes(S, B, N) // 4].abs().sum()) == 0
+        SU = 1 if x.dim() == 2 else S                           # samples on one input share a unit (and its arrival counter)
+        assert int(scratch[:L.load().bnn_lr_split_scratch_zero_bytes(SU, B, N) // 4].abs().sum()) == 0
         done += 1
     assert done >= 25, done
 

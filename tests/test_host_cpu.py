@@ -327,8 +327,8 @@ def test_launch_plans_are_a_function_of_the_shape():
         assert lib.bnn_bbb_plan(C.byref(a), C.byref(pl)) == 0
         return pl
 
-    def lr(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, sq=False, frag=False, scratch=False):
-        a = _plan_args(L.LrFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
+    def lr(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, sq=False, frag=False, scratch=False, xps=0):
+        a = _plan_args(L.LrFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, x_per_sample=xps, w_mu=P, w_rho=P,
                        b_mu=P, b_rho=P, math=math, y=P, form=form, x_sq=P if sq else None, w_frag=P if frag else None,
                        split_scratch=P if scratch else None,
                        split_scratch_bytes=lib.bnn_lr_split_scratch_bytes(S, B, N) if scratch else 0)
@@ -380,9 +380,16 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert (pl.form, pl.k_slices, pl.blocks, pl.features_per_block, pl.waves) == (L.FORM_GEMM_KSLICE, 4, 152, 32, 8)
     pl = lr(1, 128, 784, 1200, scratch=True)
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 4, 152)
-    pl = lr(2, 128, 1200, 1200, scratch=True)
+    pl = lr(2, 128, 1200, 1200, scratch=True, xps=1)
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 228)
-    assert lr(3, 128, 1200, 1200, scratch=True).form == L.FORM_TILE
+    assert lr(3, 128, 1200, 1200, scratch=True, xps=1).form == L.FORM_TILE
+    # 2 .. 23 samples on ONE input (x_per_sample = 0: the first layer of sample_elbo_lr / predict): the units count one sample --
+    # their products are made once, the epilogue runs per sample; from 24 samples on the per-sample forms (K3b over fragments)
+    for S in (2, 10, 23):
+        pl = lr(S, 128, 784, 1200, scratch=True, xdt=L.F32)
+        assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 4, 152), S
+    assert lr(24, 128, 784, 1200, scratch=True).form == L.FORM_TILE and lr(10, 128, 784, 1200).form == L.FORM_TILE
+    assert lr(10, 128, 784, 1200, scratch=True, form=L.FORM_TILE).form == L.FORM_TILE
     assert lr(1, 128, 784, 1200, scratch=True, xdt=L.F32).form == L.FORM_GEMM_KSLICE        # the first layer reads the fp32 minibatch itself
     assert lr(1, 128, 1200, 1200, scratch=True, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE and lr(1, 128, 1200, 10, scratch=True).form == L.FORM_TILE
     assert lr(1, 128, 1204, 1200, scratch=True).form == L.FORM_TILE and lr(1, 128, 1200, 1202, scratch=True).form == L.FORM_TILE
