@@ -99,10 +99,10 @@ def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
 SIGMA_HOIST_BIG_LAYER = 4_000_000
 SIGMA_HOIST_MIN_SAMPLES_BIG = 24
 SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per evaluation from here on
-LR_PREPARE_MIN_SAMPLES = 24   # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on
+LR_PREPARE_MIN_SAMPLES = 8    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
 
 
-LR_SHARED_MAX_SAMPLES = 23    # csrc/lr_linear.hip: kLrsMaxShared (from LR_PREPARE_MIN_SAMPLES on K3b is the faster way)
+LR_SHARED_MAX_SAMPLES = 23    # csrc/lr_linear.hip: kLrsMaxShared (beyond: K3b over fragments is the faster first layer too)
 
 
 def lr_unit_samples(samples: int, shared: bool) -> int:
@@ -137,7 +137,7 @@ def lr_kslice_expected(in_features: int, out_features: int, samples: int, batch:
 def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
     """True when the LR throughput kernel (block GEMM) will run for this layer and enough samples share the
     prepared weights to pay for the extra pass (mirrors the launcher's geometry rule)."""
-    return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 300
+    return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 150
 
 
 def wide_nll(specs, batch: int) -> bool:
@@ -247,7 +247,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 want_sq = lr_sq and not last
                 wfrag, ws_pre = (None, None)
                 shared_i = i == 0 and first_shared
-                if lr_sq and want_stats and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]) and not shared_i:
+                if lr_sq and lr_use_prepare(sp.in_out[1], n_local, h.shape[-2]) and not shared_i:
                     wfrag, ws_pre = ops.lr_prepare(*pd)
                 if last and fin_kw is not None and want_stats and eps_mode == L.EPS_PHILOX and fin_kw.get("scratch") is not None \
                         and not wide_nll(layers, h.shape[-2]) and all(q.lr for q in layers):

@@ -1901,12 +1901,21 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   const bool can = !a->v_out && !a->y_bf16_copy && !a->hfac_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
   // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
-  if (can && (a->form == BNN_FORM_GEMM || (a->form == BNN_FORM_AUTO && gemm_blocks >= 300))) {
+  // (over prepared fragments the block form pays from 8 samples on: 1200 x 1200, 10 samples 29 us + a 6 us prepare launch against
+  // K3a's 49; 16 samples 33 against 80 -- tools/lr_mid_sweep.py, profiles/r03_lr_mid_sweep.log)
+  if (can && (a->form == BNN_FORM_GEMM ||
+              (a->form == BNN_FORM_AUTO && (gemm_blocks >= 300 || (a->w_frag && a->n_samples >= 8 && gemm_blocks >= 150))))) {
     pl.form = BNN_FORM_GEMM;
     pl.R = 1; pl.MT = 8;
     // prepared fragments, wide layer: 8 waves share each x / x^2 tile (twice the MFMA work per LDS-DMA round trip)
     // ... 16 waves on a layer of >= 512 features: the x / x^2 tiles serve 256 features, a quarter less L2 traffic per MFMA
     pl.nw = (a->w_frag && N >= 512) ? 16 : (a->w_frag && N >= 128) ? 8 : 4;
+    // ... but few samples want the chip covered first: the narrowest block whose launch is still one round of <= 256 blocks
+    // (measured at 8 / 16 / 24 / 32 samples: 4 / 8 / 8 / 16 waves -- 152 / 160 / 240 / 160 blocks -- are the fastest)
+    if (a->w_frag && N >= 128) {
+      for (int w = 4; w < pl.nw; w *= 2)
+        if ((long)((N + 16 * w - 1) / (16 * w)) * a->n_samples * mbs <= 256) { pl.nw = w; break; }
+    }
 #ifdef BNN_TUNE
     if (const char* v = getenv("BNN_TUNE_LRNW")) { const int f = atoi(v); if (a->w_frag && (f == 4 || f == 8 || f == 16)) pl.nw = f; }
 #endif

@@ -958,11 +958,12 @@ def test_timed_path_against_oracle_on_philox_eps(dev, variant, G, S, pairs):
     idx = np.arange(total) if pairs is None else np.asarray(pairs)
     want, want_logits, w16, w16_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx, bf16=True,
                                                        sq_carried=(total >= engine.LR_SQUARES_MIN_SAMPLES))
-    if lr and engine.LR_SQUARES_MIN_SAMPLES <= total < engine.LR_PREPARE_MIN_SAMPLES:
-        # 8 .. 23 pairs: the evaluator carries bf16(x^2) between layers, but the tile form of a layer (K3a) squares the
-        # bf16 fragment it loaded and ignores the carried squares, the row-split output layer reads them: a mixture of the
-        # two documented roundings of x^2, decided by the launch plans.  Both pure variants are computed (they differ by
-        # < 1e-4 in the NLL) and the launch is held to the nearer one.
+    if lr and total >= engine.LR_SQUARES_MIN_SAMPLES and (total < engine.LR_PREPARE_MIN_SAMPLES or
+                                                        (G == 1 and 2 <= S <= engine.LR_SHARED_MAX_SAMPLES)):
+        # the evaluator carries bf16(x^2) between layers and the block form (K3b) and the row-split output layer read them,
+        # but the latency forms of a layer (K3a; K3s -- the first layer of 2 .. 23 samples on one minibatch) square the bf16
+        # fragment they loaded: a mixture of the two documented roundings of x^2, decided by the launch plans.  Both pure
+        # variants are computed (they differ by < 1e-4 in the NLL) and the launch is held to the nearer one.
         _, _, w16b, w16b_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx, bf16=True, sq_carried=False)
         got_ = ev.out["nll"].double().cpu().numpy()[idx]
         nearer = np.abs(got_ - w16b[:, 2]) < np.abs(got_ - w16[:, 2])

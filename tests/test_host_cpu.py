@@ -371,7 +371,13 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert lr(1, 128, 1200, 1200).form == L.FORM_TILE and lr(64, 128, 1200, 1200).form == L.FORM_TILE
     pl = lr(64, 128, 1200, 1200, sq=True)
     assert (pl.form, pl.waves) == (L.FORM_GEMM, 4)
-    assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 16 and lr(64, 128, 1200, 256, sq=True, frag=True).waves == 8
+    assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 16 and lr(64, 128, 1200, 256, sq=True, frag=True).waves == 4
+    # over prepared fragments the block form runs from 8 samples (per-sample inputs: xps), in the narrowest blocks whose launch
+    # is still one round of <= 256 (the measured optima of tools/lr_mid_sweep.py)
+    for S, waves, blocks in ((8, 4, 152), (10, 4, 190), (16, 8, 160), (24, 8, 240), (32, 16, 160), (64, 16, 320)):
+        pl = lr(S, 128, 1200, 1200, sq=True, frag=True, xps=1)
+        assert (pl.form, pl.waves, pl.blocks) == (L.FORM_GEMM, waves, blocks), (S, pl.form, pl.waves, pl.blocks)
+    assert lr(7, 128, 1200, 1200, sq=True, frag=True, xps=1).form == L.FORM_TILE and lr(10, 128, 1200, 1200, sq=True, xps=1).form == L.FORM_TILE
     pl = lr(1, 128, 1200, 10)
     assert (pl.form, pl.batch_rows, pl.k_classes) == (L.FORM_TILE, 32, 4)
     # K3s: with a split scratch, 1-2 samples on the wide layers run as 32-feature groups x K slices in ONE round of blocks
