@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   __shared__ __attribute__((aligned(16))) float4 sm_all[NB * (NF * 256 + SB * 512) + NW * 4];
   float4 (*sm)[NF * 256 + SB * 512] = reinterpret_cast<float4 (*)[NF * 256 + SB * 512]>(sm_all);
   float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + NB * (NF * 256 + SB * 512));
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the staging bases below live in SGPRs)
   const int fw = wave % NF, sb = wave / NF;
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
@@ -1294,7 +1294,34 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   size_t xrow[XPW];
 #pragma unroll
   for (int i = 0; i < XPW; ++i) xrow[i] = (size_t)min(m0 + (fw + i * NF) * 16 + r, B - 1) * K;
-  auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+  // The same pieces for a k-step whose 32 k lie inside K, with NO per-step vector arithmetic: the per-lane byte offsets are
+  // loop-invariant 32-bit VGPRs, the step moves the 64-bit SCALAR base (global_load_lds with an SGPR base), the LDS
+  // destination (M0) is a scalar sum.  As the compiler writes the builtin form below, a step's four pieces cost ~14 vector
+  // instructions of address arithmetic plus 4 v_readfirstlane -- an eighth of the loop's vector issue, and the loop is bound
+  // by exactly that (tools/k1b_ablate.py: the launch without its DMA is 70 us shorter, most of it these instructions).
+  const uint32_t voff_w = ((uint32_t)nc * (uint32_t)K + (uint32_t)(q * 8)) * 4u;
+  uint32_t voff_x[XPW];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[0][0];
+  constexpr uint32_t kBufBytes = (NF * 256 + SB * 512) * 16;
+  const bool fast_ok = ((size_t)N * K * 4 < 0xffffffffull) && ((size_t)B * K * 2 < 0xffffffffull);   // 32-bit offsets (block-uniform)
+  auto stage_fast = [&](int t, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int j = sb * WPW + i;                               // wave-uniform
+      const char* base = reinterpret_cast<const char*>((j & 2) ? p.w_sigma : p.w_mu) + (size_t)t * 128 + (j & 1) * 16;
+      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((fw * 4 + j) * 64 * 16);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_w), "s"(base), "s"(m0v) : "memory", "m0");
+    }
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const char* base = reinterpret_cast<const char*>(xs) + (size_t)t * 64;
+      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + (sb * 8 + fw + i * NF) * 64) * 16);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
+    }
+  };
+  auto stage_slow = [&](int t, int buf) __attribute__((always_inline)) {
     const int kk = min(t * 32 + q * 8, K - 8);
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
@@ -1312,6 +1339,10 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
                                        (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + (sb * 8 + fw + i * NF) * 64], 16, 0, 0);
     }
+  };
+  auto stage = [&](int t, int buf) __attribute__((always_inline)) {
+    if (fast_ok && (t + 1) * 32 <= K) stage_fast(t, buf);        // block-uniform
+    else stage_slow(t, buf);                                      // the K tail inside a k-step: clamped per-lane addresses
   };
 
   // bias of this wave's tile: eps now, applied in the epilogue
@@ -1349,7 +1380,13 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
     const bool lane_ok = FULL || (n_ok && k < K);
     // the buffer staged here was last read in step t - 1 (barrier since)
     const bool staged = t + NB - 1 < ksteps;                     // block-uniform
+#ifdef BNN_TUNE
+    // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 0 = no barrier, 1 = no waits, 3 = no DMA (the LDS
+    // reads of the parameters stay: stale bytes, the same vector work), 4 = no x reads, 5 = no MFMAs
+    if (staged && !(p.tune & 8)) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+#else
     if (staged) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+#endif
     // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
     // flight that may alias it -- s_waitcnt vmcnt(0) right behind the prefetch this step has just issued -- although
     // buffer t & 1 was complete at the last barrier.  The "+v" operands of the wait tie the consumers to it; the outputs
@@ -1414,28 +1451,47 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
       wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
     }
     const uint32_t xa = lbase + (uint32_t)((NF * 256 + sb * 512 + q * 16 + r) * 16);
+#ifdef BNN_TUNE
+    const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
+#else
+    constexpr bool tune_nolds = false, tune_nomfma = false;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x4 x0, x1, x2, x3;
-      if (h == 0)
+      if (tune_nolds) {
+        x0 = x1 = x2 = x3 = m_lo;
+      } else if (h == 0)
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
                      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
       else
         asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
                      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-      acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
-      acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
-      acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
-      acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+      if (!tune_nomfma) {
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+      } else {
+        asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(wa));
+      }
     }
     // this wave's DMA pieces of step t + 1 have landed and its LDS reads of buffer `cur` are back; then the block meets
     // (a bare s_barrier: __syncthreads()'s fence would add the same vmcnt(0)).  With three buffers the pieces of step
     // t + 2, issued at the top of this step, stay in flight: vector-memory operations complete in issue order, and
     // WPW + XPW of them are younger than step t + 1's pieces whenever this step staged anything.
+#ifdef BNN_TUNE
+    if (!(p.tune & 2)) {
+      if (NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if (!(p.tune & 1)) __builtin_amdgcn_s_barrier();
+#else
     if (NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   };
   {

@@ -34,6 +34,8 @@ for name, kw in (("philox, stats, hoisted sigma", dict(eps_mode=L.EPS_PHILOX, wa
         tunes = [0, 1, 3, 4, 8, 12, 16, 32, 48, 60, 63]
     elif os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and name.startswith("philox") and "hoisted" in name and plan["waves"] == 4:
         tunes = [0, 12, 60, 63]      # the generator (and the statistics) with the memory path / everything else compiled out
+    elif os.environ.get("BNN_HIP_LIB", "").endswith("tune.so") and "hoisted" in name and plan["waves"] == 8:
+        tunes = [0, 8, 56, 59]       # K1b2: no DMA; also no x reads, no MFMAs; also no barrier, no waits (its in-situ vector floor)
     for tn in tunes:
         os.environ["BNN_TUNE_K1B"] = str(tn)
         us = kernel_alone_us(lambda: ops.bbb_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, **common), torch.cuda.current_stream(), per_graph=8, reps=10)
