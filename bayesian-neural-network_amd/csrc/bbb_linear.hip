@@ -938,7 +938,7 @@ __global__ __launch_bounds__(768) void bbb_input_grad_kernel(const BbbK p) {
 // there on all of them: every wave drained the prefetch it had just issued BEFORE its generator work instead of behind it.
 template <int NW, bool SIG, int EPS>
 __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64], float (*bias_s)[16]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int K = p.K, N = p.N, B = p.B;
   const int tbs = (N + 16 * NW - 1) / (16 * NW), mbs = (B + 127) >> 7;
@@ -969,12 +969,23 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   size_t xrow[8 / NW];
 #pragma unroll
   for (int i = 0; i < 8 / NW; ++i) xrow[i] = (size_t)min(m0 + (wave + i * NW) * 16 + r, B - 1) * K;
-  auto stage_dma = [&](int t, int buf) {
-    const int kk = min(t * 32 + q * 8, K - 8);
+  // Addresses as a SCALAR base + a 32-bit lane offset (global_load[_lds] with an SGPR base): the lane offsets are
+  // loop-invariant, a step costs one add and one min (the K tail inside a k-step re-reads the row's last 8) instead of the
+  // 64-bit per-lane address arithmetic and v_readfirstlane the pointer forms compile to -- vector issue is what these
+  // launches are made of (K1b2's stage_fast).  The plan takes these forms only where the tensors' byte spans fit 32 bits.
+  const uint32_t voff_w = ((uint32_t)nc * (uint32_t)K + (uint32_t)(q * 8)) * 4u, voff_w_max = ((uint32_t)nc * (uint32_t)K + (uint32_t)(K - 8)) * 4u;
+  uint32_t voff_x[8 / NW], voff_x_max[8 / NW];
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) {
+    voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
+    voff_x_max[i] = ((uint32_t)xrow[i] + (uint32_t)(K - 8)) * 2u;
+  }
+  auto stage_dma = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 8 / NW; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
-                                       (__attribute__((address_space(3))) void*)&xt[buf][(wave + i * NW) * 64], 16, 0, 0);
+      const uint32_t vo = min(voff_x[i] + (uint32_t)t * 64u, voff_x_max[i]);
+      const uint32_t m0v = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&xt[buf][(wave + i * NW) * 64];
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(xs), "s"(m0v) : "memory", "m0");
     }
   };
 
@@ -983,9 +994,9 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   // them s_waitcnt vmcnt(0) -- right behind the loads, ahead of the generator work the prefetch was meant to overlap.
   struct PSet { float4 m_lo, m_hi, g_lo, g_hi; };
   auto load_params = [&](int t, PSet& P) __attribute__((always_inline)) {
-    const size_t woff = (size_t)nc * K + min(t * 32 + q * 8, K - 8);
-    const float4* pm = reinterpret_cast<const float4*>(p.w_mu + woff);
-    const float4* pg = reinterpret_cast<const float4*>((SIG ? p.w_sigma : p.w_rho) + woff);
+    const uint32_t woff = min(voff_w + (uint32_t)t * 128u, voff_w_max);     // (the K tail re-reads the row's last 8)
+    const float4* pm = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.w_mu) + woff);
+    const float4* pg = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(SIG ? p.w_sigma : p.w_rho) + woff);
     P.m_lo = pm[0]; P.m_hi = pm[1]; P.g_lo = pg[0]; P.g_hi = pg[1];
   };
 
@@ -1011,11 +1022,13 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s_e2 = 0.f, s_a = 0.f, s_ls = 0.f;
 
-  // one k-step over the parameters in P (loaded a step ago); `more`: step t + 1 exists and its loads go to Pn
-  auto step = [&](int t, const PSet& P, PSet& Pn) __attribute__((always_inline)) {
+  // one k-step over the parameters in P (loaded a step ago); MORE: step t + 1 exists and its loads go to Pn -- a
+  // compile-time fact of the call site: issued under a run-time branch, the loads made the compiler wait for them
+  // (vmcnt(0)) where the step first reads P, behind the generator work they were meant to overlap
+  auto step = [&](int t, const PSet& P, PSet& Pn, auto more_) __attribute__((always_inline)) {
+    constexpr bool more = decltype(more_)::value;
     const int k = t * 32 + q * 8;
     const bool lane_ok = n_ok && k < K;
-    const bool more = t + 1 < t_hi;
 #ifdef BNN_TUNE
     // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 2 = no parameter loads in the loop, bit 3 = no x
     // DMA, bit 4 = no LDS reads, bit 5 = no MFMAs
@@ -1112,11 +1125,16 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
   {
     int t = t_lo;
 #pragma nounroll
-    for (; t + 1 < t_hi; t += 2) {
-      step(t, PA, PB);
-      step(t + 1, PB, PA);
+    for (; t + 2 < t_hi; t += 2) {
+      step(t, PA, PB, std::true_type{});
+      step(t + 1, PB, PA, std::true_type{});
     }
-    if (t < t_hi) step(t, PA, PB);
+    if (t + 1 < t_hi) {
+      step(t, PA, PB, std::true_type{});
+      step(t + 1, PB, PA, std::false_type{});
+    } else if (t < t_hi) {
+      step(t, PA, PB, std::false_type{});
+    }
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
@@ -1305,7 +1323,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   for (int i = 0; i < XPW; ++i) voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[0][0];
   constexpr uint32_t kBufBytes = (NF * 256 + SB * 512) * 16;
-  const bool fast_ok = ((size_t)N * K * 4 < 0xffffffffull) && ((size_t)B * K * 2 < 0xffffffffull);   // 32-bit offsets (block-uniform)
+  // (the plan takes this form only where the tensors' byte spans fit 32 bits)
   auto stage_fast = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
@@ -1341,7 +1359,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
     }
   };
   auto stage = [&](int t, int buf) __attribute__((always_inline)) {
-    if (fast_ok && (t + 1) * 32 <= K) stage_fast(t, buf);        // block-uniform
+    if ((t + 1) * 32 <= K) stage_fast(t, buf);                   // block-uniform
     else stage_slow(t, buf);                                      // the K tail inside a k-step: clamped per-lane addresses
   };
 
@@ -1770,7 +1788,9 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
     return BNN_OK;
   }
   const long gemm_blocks = (long)((N + 63) / 64) * S * mbs;
-  const bool gemm_ok = al && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && K >= 8;
+  // (the block-GEMM kernels address with a scalar base + 32-bit lane offsets: the tensors' byte spans must fit)
+  const bool gemm_ok = al && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && K >= 8 &&
+                       (double)N * K * 4.0 < 4294967295.0 && (double)B * K * 2.0 < 4294967295.0;
   const bool slice_ok = gemm_ok && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
                         a->split_scratch_bytes >= bnn_bbb_split_scratch_bytes(S, B, N);
   int forced = 0;
