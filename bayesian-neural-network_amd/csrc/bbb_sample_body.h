@@ -43,7 +43,8 @@ struct SampleK {
 };
 
 // the mixture density (argument of the log; accumulated with add_log: explicit contraction, see bnn_device.h)
-__device__ __forceinline__ float sample_mix_p(const SampleL& L, float w) {
+struct SampleMix { float inv2var1, c1, inv2var2, c2, pi; };
+__device__ __forceinline__ float sample_mix_p(const SampleMix& L, float w) {
   const float w2 = w * w;
   const float p1 = fast_exp(__builtin_fmaf(-w2, L.inv2var1, L.c1));
   const float p2 = fast_exp(__builtin_fmaf(-w2, L.inv2var2, L.c2));
@@ -82,6 +83,10 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
   const int s0 = grp * kSampleGroup;
   const int ns = min(kSampleGroup, p.S - s0);              // samples of this block (block-uniform)
   const int K = L.K, N = L.N;
+  // the layer's prior in registers, and ONE branch on its kind per octet: read per weight from the parameter block (the
+  // layer index is a run-time value) the kind cost a scalar load, a wait and a branch for each of the 16 weights of a sample
+  const bool gauss = L.prior_kind == BNN_PRIOR_GAUSS;      // block-uniform
+  const SampleMix mix = {L.inv2var1, L.c1, L.inv2var2, L.c2, L.pi};
   const int opr = K >> 3;                                  // octets per row
   const long total = (long)N * opr;
   const uint32_t gs_base = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
@@ -159,8 +164,13 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
       for (int j = 0; j < 8; ++j) {
         w[j] = __builtin_fmaf(sg[u][j], e[j], mu[u][j]);
         e2 = __builtin_fmaf(e[j], e[j], e2);
-        if (L.prior_kind == BNN_PRIOR_GAUSS) a = __builtin_fmaf(w[j], w[j], a);
-        else a = add_log(a, sample_mix_p(L, w[j]));
+      }
+      if (gauss) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = __builtin_fmaf(w[j], w[j], a);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a = add_log(a, sample_mix_p(mix, w[j]));
       }
       s_e2 += ok ? e2 : 0.f;
       s_a += ok ? a : 0.f;
@@ -179,7 +189,7 @@ __device__ __forceinline__ void sample_block(const SampleK& p, int block, float*
       const float b = __builtin_fmaf(bsg, e, bmu);
       L.b_out[(size_t)s * N + bn] = b;
       s_e2 = __builtin_fmaf(e, e, s_e2);
-      s_a = (L.prior_kind == BNN_PRIOR_GAUSS) ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(L, b));
+      s_a = gauss ? __builtin_fmaf(b, b, s_a) : add_log(s_a, sample_mix_p(mix, b));
       if (do_ls) s_ls = add_log(s_ls, bsg);
     }
     const float a0 = wave_sum(s_e2), a1 = wave_sum(s_a), a2 = wave_sum(s_ls);
