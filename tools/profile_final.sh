@@ -9,7 +9,6 @@ TAG=${1:-rXX}
 P="bash tools/profile_round.sh $TAG"
 PMC="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 mkdir -p gpurun_out/profiles && echo '{}' > gpurun_out/profiles/pmc.json
-$P statsfull steps20 --steps 20 --warmup 5 --no-extras --no-cpu-baseline &&
 $P stats bbb_g256 &&
 $P stats lr_g256_l2 --variant lr &&
 $P stats bbb_S8 --samples 8 --group 1 &&
@@ -24,7 +23,8 @@ $P traffic lrS1 lr_1200_n1_b128_bf16 lr_fwd_kslice_kernel --variant lr --samples
 $P traffic wide4096 block_gemm_4096_n4_b4096_bf16 bbb_block_gemm_kernel --net wide --batch 4096 --samples 4 --group 1 &&
 $P pmc bbb256 bbb_g256 "$PMC" &&
 $P pmc lr256 lr_g256 "$PMC" --variant lr &&
-$P pmc wide4096 wide_B4096 "$PMC" --net wide --batch 4096 --samples 4 --group 1
+$P pmc wide4096 wide_B4096 "$PMC" --net wide --batch 4096 --samples 4 --group 1 &&
+$P statsfull steps20 --steps 20 --warmup 5 --no-extras --no-cpu-baseline    # last: its bench line carries the traffic / counters collected above
 # harness logs behind DESIGN.md 4 (development binaries are built in the container and travel with the snapshot)
 PROF=gpurun_out/profiles
 ( tools/ubench.out > $PROF/${TAG}_ubench_generator.log 2>&1 ) || true
