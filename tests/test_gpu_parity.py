@@ -873,6 +873,36 @@ def test_split_sampling_then_matmul_equals_the_fused_layer(dev, prior, shape):
     close(sls, float(fls), rtol=2e-5)
 
 
+@pytest.mark.parametrize("prior", [ops.PriorSpec(False, 0.9), ops.PriorSpec(True, 1.0, 0.4, 1.1, 0.05)])
+@pytest.mark.parametrize("S", [2, 4, 5, 7, 9])
+def test_sampling_in_sample_groups_equals_one_sample_launches(dev, prior, S):
+    """K1s serves a group of four MC samples from one read of (mu, rho) and one softplus (a last group of 1..3 where S % 4 != 0):
+    every sample's bf16 weights, fp32 biases and statistics entries are bit for bit those of its own one-sample launch at
+    its own Philox offset -- two layers in one launch (odd shapes: a chunk that ends inside the matrix, biases spread over
+    the chunks)."""
+    rs = np.random.RandomState(100 + S)
+    mk = lambda *sh, lo=-0.3, hi=0.3: torch.from_numpy(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+    shapes = [(200, 136), (24, 1000)]                           # (out, in): in % 8 == 0
+    layers = [dict(w_mu=mk(n, k), w_rho=mk(n, k, lo=-5, hi=-2), b_mu=mk(n), b_rho=mk(n, lo=-5, hi=-2), prior=prior, layer_id=1 + i)
+              for i, (n, k) in enumerate(shapes)]
+    grp = ops.bbb_sample_weights([dict(l) for l in layers], n_samples=S, seed=5, sample_offset=40)
+    for s_ in range(S):
+        one = ops.bbb_sample_weights([dict(l) for l in layers], n_samples=1, seed=5, sample_offset=40 + s_)
+        for li, (n, k) in enumerate(shapes):
+            assert torch.equal(grp[li]["w"][s_].view(torch.int16), one[li]["w"][0].view(torch.int16)), (S, s_, li)
+            assert torch.equal(grp[li]["b"][s_], one[li]["b"][0]), (S, s_, li)
+            T = int(grp[li]["workspace"][:1].view(torch.int32)[0])
+            assert T == int(one[li]["workspace"][:1].view(torch.int32)[0])
+            g = grp[li]["workspace"][4:4 + 4 * S * T].view(S, T, 4)[s_]
+            o = one[li]["workspace"][4:4 + 4 * T].view(T, 4)
+            # {sum eps^2, sum w^2 | sum log p_mix} per chunk; sum log sigma belongs to global sample index 0 of a launch only
+            assert torch.equal(g[:, :2], o[:, :2]), (S, s_, li)
+            if s_ == 0:
+                assert torch.equal(g[:, 2], o[:, 2])
+            else:
+                assert float(g[:, 2].abs().max()) == 0.0
+
+
 def _oracle_pairs(p, xs, ys, seed, base, S, pairs=None, bf16=False, sq_carried=True):
     """Oracle scalars of (minibatch m, MC sample j) pairs on the eps the device generator draws for global sample index
     base + m * S + j: rows of (log p | KL, log q | 0, nll), plus the logits.  `pairs`: flat indices m * S + j (default
