@@ -593,7 +593,15 @@ def main():
             e4, rate1, us1 = timed_config(engine, net_lr, x, y, 1, 1, 400)
             r4 = layer2_roofline(e4, net_lr, dims, args.batch, True, args.math)
             del e4
+            # ... and MC-batched evaluations of ONE minibatch (sample_elbo_lr's own loop: networks.py:211-225): the first layer's two
+            # products are made once for all samples up to 23, the hidden layer runs over prepared fragments from 8
+            mc_lr = []
+            for (S, steps) in ((2, 400), (8, 200), (64, 60)):
+                e7, rate7, us7 = timed_config(engine, net_lr, x, y, S, 1, steps)
+                mc_lr.append({"mc_samples_per_evaluation": S, "samples_per_s": rate7, "us_per_evaluation": us7})
+                del e7
             extras["lr_variant"] = {"samples_per_s": rate, "us_per_minibatch": us, "minibatches_per_launch_group": G,
+                                    "mc_batched_one_minibatch": mc_lr,
                                     "roofline": attach_traffic(r3),
                                     "single_evaluation_in_flight": {"samples_per_s": rate1, "us_per_evaluation": us1,
                                                                     "layer2_us_per_launch": r4["avg_launch_us"],
