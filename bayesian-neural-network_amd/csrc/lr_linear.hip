@@ -597,6 +597,12 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
   // forward(x) `samples` times on the same x): m = x M and v = x^2 sigma^2 do not depend on the sample, only the bias and
   // the activation noise do.  The units then count one sample, and whoever runs a unit's epilogue runs it ES times.
   const int ES = p.es, SU = ES > 1 ? 1 : p.S;
+  // From four samples on the epilogues of a shared-input unit are SPREAD over its slice blocks (sample se runs in the block
+  // of slice se % KSL) instead of all running in the block that arrives last: every block then waits (a bounded poll) until
+  // all slices of the unit have arrived and adds them up itself, in slice order -- the same bits in every block.  Legal
+  // because the plan launches these kernels as ONE round of blocks (every block is resident, nobody waits for a block that
+  // has not started); costs each block the other slices' tiles and ~2 us of poll, saves (ES - ES / KSL) epilogues in a row.
+  const bool spread = ES >= 4 && KSL > 1;                     // block-uniform
   const int G = (N + 31) >> 5, mbs = (B + 127) >> 7;
   if (p.rd_blocks > 0 && (int)blockIdx.x >= p.main_blocks) {   // rider blocks sit behind the (padded) main grid
     lr_rider_block(p, (int)blockIdx.x - p.main_blocks, tiles, lds_red);
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
         s_m2 = __builtin_fmaf(bmu_pre, bmu_pre, s_m2);
       }
       for (int se = 1; se < ES; ++se) {                        // the other samples' biases (sample 0's is `b`)
+        if (spread && se % KSL != ks) continue;                // (spread: the samples whose epilogue runs in this block)
         float be = 0.f;
         if (p.eps_mode == BNN_EPS_PHILOX) {
           float e4[4];
@@ -851,13 +858,26 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t tk = __hip_atomic_fetch_add(p.ks_ticket + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last_s = (tk == (uint32_t)KSL - 1u) ? 1u : 0u;
+      last_s = ((tk & 0xffffu) == (uint32_t)KSL - 1u) ? 1u : 0u;
+      if (spread) {
+        // arrivals in the low half of the word, departures in the high half; the poll is bounded (a launch that could not
+        // make progress ends with wrong numbers, not with a hung device)
+        uint32_t seen = tk + 1u;
+        for (int it = 0; (seen & 0xffffu) < (uint32_t)KSL && it < (1 << 22); ++it) {
+          __builtin_amdgcn_s_sleep(4);
+          seen = __hip_atomic_load(p.ks_ticket + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t dp = __hip_atomic_fetch_add(p.ks_ticket + unit, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((dp >> 16) == (uint32_t)KSL - 1u)                  // the last to leave puts the word back to zero
+          __hip_atomic_store(p.ks_ticket + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = 1u;                                           // every block of the unit runs its share of the epilogues
+      }
     }
     __syncthreads();
     LR_STAMP(5);
     LR_STAMP_RT(9);
     if (last_s == 0u) return;                                  // block-uniform
-    if (threadIdx.x == 0) __hip_atomic_store(p.ks_ticket + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!spread && threadIdx.x == 0) __hip_atomic_store(p.ks_ticket + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x4 part[kLrsMaxSlices][4];
 #pragma unroll
     for (int sl = 0; sl < kLrsMaxSlices; ++sl) {               // every other slice's tiles, one round of loads
@@ -870,7 +890,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
         for (int m = 0; m < 4; ++m) part[sl][m] = acc[m >> 1][m & 1];
       }
     }
-    if (p.eps_mode == BNN_EPS_PHILOX) draw_eps();
+    if (p.eps_mode == BNN_EPS_PHILOX && !spread) draw_eps();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 sum[4];
 #pragma unroll
@@ -889,13 +909,15 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
   LR_STAMP(6);
   // ---- epilogue: lane (r, q) of feature tile ft holds batch row m0 + 16 wave + r, features n0 + 16 ft + 4 q ..
   if (wave < mtiles && brow < B) {
+    if (!spread) {
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const int nb = n0 + ft * 16 + q * 4;
-      if (nb < N) lr_epilogue_item(p, s, gs, brow, nb, acc[ft][0], acc[ft][1], lds_bias + ft * 16 + q * 4, eps_pre[ft]);
+      for (int ft = 0; ft < 2; ++ft) {
+        const int nb = n0 + ft * 16 + q * 4;
+        if (nb < N) lr_epilogue_item(p, s, gs, brow, nb, acc[ft][0], acc[ft][1], lds_bias + ft * 16 + q * 4, eps_pre[ft]);
+      }
     }
 #pragma nounroll
-    for (int se = 1; se < ES; ++se) {                          // the other samples of a shared-input unit: noise, bias, stores
+    for (int se = spread ? ks : 1; se < ES; se += spread ? KSL : 1) {   // the other samples of a shared-input unit (spread: this block's share)
       const uint32_t gse = gs + (uint32_t)se;                  // (shared input: no sample groups; lr_global_sample would re-read the counter)
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
