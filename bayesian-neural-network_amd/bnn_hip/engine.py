@@ -102,7 +102,7 @@ SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per e
 LR_PREPARE_MIN_SAMPLES = 8    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
 
 
-LR_SHARED_MAX_SAMPLES = 23    # csrc/lr_linear.hip: kLrsMaxShared (beyond: K3b over fragments is the faster first layer too)
+LR_SHARED_MAX_SAMPLES = 64    # csrc/lr_linear.hip: kLrsMaxShared (tools/lr_shared_sweep.py: faster than K3b + prepare + cast up to there)
 
 
 def lr_unit_samples(samples: int, shared: bool) -> int:
@@ -200,7 +200,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     # LR: and its elementwise square) and sigma = softplus(rho) of the layers that will run a block-GEMM form
     want_cast = hidden_dtype == torch.bfloat16 and x.dtype == torch.float32 and n_local >= CAST_INPUT_MIN_SAMPLES  # (eager
     # calls are host-bound: the one-sample LR cast of GraphedElbo would only add a launch here)
-    # LR, 2 .. 23 samples on one minibatch: the first layer's K3s makes its products once for all of them and reads the fp32
+    # LR, 2 .. 64 samples on one minibatch: the first layer's K3s makes its products once for all of them and reads the fp32
     # minibatch itself
     first_shared = (layers[0].lr and x.dim() == 2 and not differentiable and hidden_dtype == torch.bfloat16 and len(layers) > 1 and
                     lr_unit_samples(n_local, True) == 1 and lr_kslice_expected(*layers[0].in_out, n_local, x.shape[-2], True))
@@ -526,7 +526,7 @@ class GraphedElbo:
             if lb:
                 self.ws[i] = ops.sample_workspace(S, sp.in_out[0], sp.in_out[1], dev)
         # LR, 1-2 samples: the first layer's K-sliced form (K3s) reads the fp32 minibatch itself -- no cast launch ahead of it
-        # (2 .. 23 samples of one minibatch share that layer's products: lr_unit_samples)
+        # (2 .. 64 samples of one minibatch share that layer's products: lr_unit_samples)
         shared0 = self.lr and not self.G > 1 and lr_unit_samples(S, True) == 1
         k3s_first = (self.lr and hid == torch.bfloat16 and len(self.specs) > 1 and self.specs[0].in_out[0] % 8 == 0 and
                      lr_use_split(self.specs[0].in_out[1], S, B, shared0) and not self.G > 1)

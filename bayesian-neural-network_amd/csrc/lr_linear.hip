@@ -574,9 +574,10 @@ __device__ __forceinline__ void lr_rider_block(const LrK& p, int rb, char* lds_i
 
 constexpr int kLrsMaxSteps = 13;   // k-steps per slice (x fragments a wave keeps in registers)
 constexpr int kLrsMaxSlices = 8;
-constexpr int kLrsMaxShared = 23;  // samples that may share one unit's products (their biases wait in LDS).  The unit's epilogues
-                                   // all run in the block that arrives last (38 blocks on a 1200-wide layer, ~1.6 us per sample):
-                                   // from 24 samples on the block-GEMM form over prepared fragments (K3b) is the faster way
+constexpr int kLrsMaxShared = 64;  // samples that may share one unit's products (their biases wait in LDS).  With the epilogues spread
+                                   // over the unit's slice blocks a further sample costs ~0.45 us (784 x 1200: 4 / 16 / 64 samples
+                                   // 18 / 24 / 45 us against K3b's 20 / 25 / 67 + 8.5 us of prepare and cast launches:
+                                   // tools/lr_shared_sweep.py, profiles/r03_lr_shared_sweep.log)
 
 // XF32: the layer input is fp32 (the first layer of an evaluation: the minibatch as it arrives -- no cast launch ahead of it);
 // a fragment is then two 16-byte loads, rounded to bf16 in registers where the cast kernel would have rounded it

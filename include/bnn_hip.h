@@ -357,7 +357,7 @@ typedef struct bnn_lr_fwd_args {
                                range of a 32-feature group over several blocks that meet through it (BNN_FORM_GEMM_KSLICE;
                                bf16 math on bf16 x, in_features % 8 == 0, out_features % 4 == 0).  One launch at a time
                                per scratch.
-                               With x_per_sample == 0 and 2 .. 23 samples (no sample groups) -- the first layer of
+                               With x_per_sample == 0 and 2 .. 64 samples (no sample groups) -- the first layer of
                                sample_elbo_lr / predict, where the reference runs forward(x) per sample on the same x
                                (networks.py:211-225) -- the two products x M and x^2 sigma^2 are made ONCE per launch and
                                only the bias, the activation noise and the stores run per sample; the scratch then only

@@ -991,7 +991,7 @@ def test_timed_path_against_oracle_on_philox_eps(dev, variant, G, S, pairs):
     if lr and total >= engine.LR_SQUARES_MIN_SAMPLES and (total < engine.LR_PREPARE_MIN_SAMPLES or
                                                         (G == 1 and 2 <= S <= engine.LR_SHARED_MAX_SAMPLES)):
         # the evaluator carries bf16(x^2) between layers and the block form (K3b) and the row-split output layer read them,
-        # but the latency forms of a layer (K3a; K3s -- the first layer of 2 .. 23 samples on one minibatch) square the bf16
+        # but the latency forms of a layer (K3a; K3s -- the first layer of 2 .. 64 samples on one minibatch) square the bf16
         # fragment they loaded: a mixture of the two documented roundings of x^2, decided by the launch plans.  Both pure
         # variants are computed (they differ by < 1e-4 in the NLL) and the launch is held to the nearer one.
         _, _, w16b, w16b_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx, bf16=True, sq_carried=False)
@@ -1126,10 +1126,10 @@ def test_c5_wide_bbb_layer_against_oracle(dev, form):
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 1200, 1200), (1, 128, 784, 1200), (2, 128, 1200, 1200), (3, 100, 264, 72),
-                                   (1, 20, 1000, 1200), (1, 128, 64, 4096), (10, 128, 784, 1200), (23, 100, 264, 136)])
+                                   (1, 20, 1000, 1200), (1, 128, 64, 4096), (10, 128, 784, 1200), (23, 100, 264, 136), (64, 128, 784, 1200)])
 def test_lr_k_sliced_form_against_oracle_and_tile_form(dev, shape):
     """K3s (lr_fwd_kslice_kernel, BNN_FORM_GEMM_KSLICE): 32-feature groups x K slices meeting through a scratch, for 1-2
-    samples on a wide [in,out] layer (more where the layer is narrower) -- and for 2 .. 23 samples on ONE input (the first
+    samples on a wide [in,out] layer (more where the layer is narrower) -- and for 2 .. 64 samples on ONE input (the first
     layer of sample_elbo_lr / predict, networks.py:211-225: the reference runs forward(x) per sample on the same x), where a
     unit's two products are made once and its epilogue runs per sample (the S > 1 shapes here: x is [batch, in]).
     y, y^2, the saved variance and the backward factor against the oracle

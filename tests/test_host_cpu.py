@@ -389,12 +389,12 @@ def test_launch_plans_are_a_function_of_the_shape():
     pl = lr(2, 128, 1200, 1200, scratch=True, xps=1)
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 228)
     assert lr(3, 128, 1200, 1200, scratch=True, xps=1).form == L.FORM_TILE
-    # 2 .. 23 samples on ONE input (x_per_sample = 0: the first layer of sample_elbo_lr / predict): the units count one sample --
-    # their products are made once, the epilogue runs per sample; from 24 samples on the per-sample forms (K3b over fragments)
-    for S in (2, 10, 23):
+    # 2 .. 64 samples on ONE input (x_per_sample = 0: the first layer of sample_elbo_lr / predict): the units count one sample --
+    # their products are made once, the epilogue runs per sample; beyond 64 the per-sample forms
+    for S in (2, 10, 23, 64):
         pl = lr(S, 128, 784, 1200, scratch=True, xdt=L.F32)
         assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 4, 152), S
-    assert lr(24, 128, 784, 1200, scratch=True).form == L.FORM_TILE and lr(10, 128, 784, 1200).form == L.FORM_TILE
+    assert lr(65, 128, 784, 1200, scratch=True).form == L.FORM_TILE and lr(10, 128, 784, 1200).form == L.FORM_TILE
     assert lr(10, 128, 784, 1200, scratch=True, form=L.FORM_TILE).form == L.FORM_TILE
     assert lr(1, 128, 784, 1200, scratch=True, xdt=L.F32).form == L.FORM_GEMM_KSLICE        # the first layer reads the fp32 minibatch itself
     assert lr(1, 128, 1200, 1200, scratch=True, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE and lr(1, 128, 1200, 10, scratch=True).form == L.FORM_TILE
