@@ -441,3 +441,40 @@ def test_bench_roofline_bookkeeping_without_a_device(tmp_path, monkeypatch):
         json.dump({"bbb_1200_n256_b128_bf16": {"hbm_bytes_per_launch": 123.0, "source_hash": h}}, open(tmp_path / "profiles" / "traffic.json", "w"))
         got = bench.attach_traffic({"traffic": None, "traffic_key": "bbb_1200_n256_b128_bf16"})
         assert got["traffic"] == want and ("traffic_note" in got) == (want is None)
+
+
+def test_kernels_with_hand_issued_loads_do_not_spill(tmp_path):
+    """The block-GEMM / K-sliced kernels issue some of their loads in inline assembly and wait for them by hand (the
+    compiler's own wait-count bookkeeping drains the prefetch: DESIGN 4).  A register whose hand-issued load is still in
+    flight must never be spilled and handed to another value -- an address, in the case that faulted -- so these kernels
+    must compile without scratch.  Compiles the two sources to gfx950 assembly (no GPU needed) and reads the metadata."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(REPO, "bayesian-neural-network_amd", "csrc")
+    # (K3b, lr_fwd_gemm_kernel, is not in the list: what it reads by hand are LDS fragments waited for inside the same
+    # straight-line group of MFMAs; its 16-wave form has carried 16 bytes of scratch since round 2)
+    watched = ("bbb_fwd_gemm_kernel", "bbb_fwd_gemm2_kernel", "bbb_fwd_gemm_rider_kernel", "bbb_block_gemm_kernel",
+               "lr_fwd_kslice_kernel")
+    seen = set()
+    procs = []
+    for src in ("bbb_linear.hip", "lr_linear.hip"):
+        out = tmp_path / (src + ".s")
+        procs.append((out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-S",
+                                             "--offload-device-only", os.path.join(csrc, src), "-o", str(out)],
+                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for out, pr in procs:
+        assert pr.wait() == 0
+        name = None
+        for line in open(out):
+            m = re.match(r"^(_ZN3bnn\S+):", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"^; ScratchSize: (\d+)", line)
+            if m and name:
+                hit = [w for w in watched if re.search(r"\d+" + w + r"I", name)]
+                if hit:
+                    seen.add(hit[0])
+                    assert int(m.group(1)) == 0, (name, int(m.group(1)))
+                name = None
+    assert seen == set(watched), seen
