@@ -746,7 +746,7 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
         } else if (p.eps_mode == BNN_EPS_MEMORY) {
           be = p.eps_b[(size_t)se * N + n];
         }
-        if (p.eps_b_dump && mb == 0 && ks == 0) p.eps_b_dump[(size_t)se * N + n] = be;
+        if (p.eps_b_dump && mb == 0 && (spread || ks == 0)) p.eps_b_dump[(size_t)se * N + n] = be;   // (spread: the one slice block that draws it)
         lds_bias[se * 32 + lane] = __builtin_fmaf(bsig, be, bmu_pre);
       }
     } else {

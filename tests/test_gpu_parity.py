@@ -1253,6 +1253,35 @@ def test_lr_k_sliced_form_per_sample_inputs_and_injected_eps(dev):
         assert torch.equal(g["y"][s], one["y"][0]), s
 
 
+def test_lr_k_sliced_shared_input_with_injected_eps(dev):
+    """Samples on ONE input (the unit's products made once; from four samples on the epilogues spread over the slice blocks)
+    with epsilon from memory -- the seam the reference's stubbed `.normal` goes through: the on-chip draw dumped by one launch
+    and injected into the next gives the same bits, K3a on the same injected epsilon agrees to summation order, and the
+    samples differ from each other only by their noise (zero epsilon: every sample the same tile)."""
+    for S, B, K, N in ((6, 77, 392, 328), (3, 128, 784, 1200), (10, 128, 784, 1200)):
+        rs = np.random.RandomState(S)
+        mk = lambda *sh, lo=-0.3, hi=0.3: t(rs.uniform(lo, hi, sh).astype(np.float32)).to(dev)
+        dw = [mk(K, N), mk(K, N, lo=-5, hi=-4), mk(N), mk(N, lo=-5, hi=-4)]
+        x = mk(B, K, lo=0, hi=1)                                # fp32, [batch, in]: shared by all samples
+        kw = dict(n_samples=S, sigma_p=1.0, math_mode=L.MATH_BF16, relu=True, y_dtype=torch.float32, seed=11, layer_id=0, sample_offset=3,
+                  want_kl=True, want_scalars=True)
+        scratch = ops.lr_split_scratch(1, B, N, dev)
+        ks = dict(form=L.FORM_GEMM_KSLICE, split_scratch=scratch)
+        assert ops.lr_plan(x, *dw, eps_mode=L.EPS_PHILOX, **ks, **kw)["blocks"] == ((N + 31) // 32) * ((B + 127) // 128) * \
+            ops.lr_plan(x, *dw, eps_mode=L.EPS_PHILOX, **ks, **kw)["k_slices"]
+        a = ops.lr_linear_fwd(x, *dw, eps_mode=L.EPS_PHILOX, dump_eps=True, **ks, **kw)
+        b = ops.lr_linear_fwd(x, *dw, eps_mode=L.EPS_MEMORY, eps_act=a["eps_act"], eps_b=a["eps_b"], **ks, **kw)
+        c = ops.lr_linear_fwd(x.to(torch.bfloat16), *dw, eps_mode=L.EPS_MEMORY, eps_act=a["eps_act"], eps_b=a["eps_b"], form=L.FORM_TILE, **kw)
+        d = ops.lr_linear_fwd(x.to(torch.bfloat16), *dw, eps_mode=L.EPS_PHILOX, dump_eps=True, form=L.FORM_TILE, **kw)
+        assert torch.equal(a["y"], b["y"]) and torch.equal(a["kl3"], b["kl3"]), S
+        assert torch.equal(a["eps_act"], d["eps_act"]) and torch.equal(a["eps_b"], d["eps_b"]), S     # the same epsilon map
+        scale = float(c["y"].abs().max())
+        assert float((a["y"] - c["y"]).abs().max()) <= 3e-3 * scale, S
+        z = ops.lr_linear_fwd(x, *dw, eps_mode=L.EPS_MEMORY, eps_act=torch.zeros_like(a["eps_act"]), eps_b=torch.zeros_like(a["eps_b"]), **ks, **kw)
+        assert all(torch.equal(z["y"][0], z["y"][s_]) for s_ in range(1, S)) and not torch.equal(a["y"][0], a["y"][1])
+        assert int(scratch[:L.load().bnn_lr_split_scratch_zero_bytes(1, B, N) // 4].abs().sum()) == 0
+
+
 def test_lr_k_sliced_form_over_random_shapes_against_k3a(dev):
     """K3s against K3a over shapes drawn at random among those its plan accepts (batch 1..300: ragged 16-row tiles and several
     batch blocks; K any multiple of 8 from 64: K tails inside a k-step, 1..8 slices, slices of unequal length; N any multiple
