@@ -305,6 +305,33 @@ def test_c1_regression_elbo_and_grads(g_c1, dev, variant):
     assert n_grad >= 2
 
 
+def test_lr_network_six_samples_on_one_minibatch_with_stubbed_normal(dev):
+    """sample_elbo_lr with 6 samples and the layers' `.normal` stubbed (the reference's seam, networks.py:100): in bf16 math the
+    first layer runs K3s over the one minibatch for all samples (products once, epilogues spread) on INJECTED epsilon; against
+    the exact-fp32 math mode on the same epsilon (itself pinned by the golden vectors): KL to fp32 rounding, NLL within the
+    operand-rounding bound of DESIGN 2, and against the oracle's fp32 arithmetic."""
+    S, B = 6, 128
+    x, y = synth.synth_batch("classification", B, 784, 10)
+    xd, yd = t(x).to(dev), t(y).to(dev)
+    got = {}
+    for math_mode in ("f32", "bf16"):
+        bnn_hip.set_math(math_mode)
+        net, sd = build_net(dev, True, (784, 1200, 10), "classification")
+        install_eps(net, B, S, True)
+        with torch.no_grad():
+            got[math_mode] = [v.double().cpu().numpy() for v in net.sample_elbo_lr(xd, yd, 0.25, S)]
+    bnn_hip.set_math("bf16")
+    p = O.NetParams.from_state_dict(sd, "classification", 784, True, O.Prior.from_init([1.0], False))
+    eps = [[t(a) for a in synth.synth_eps(p.eps_shapes(B), s_)] for s_ in range(S)]
+    torch.set_num_threads(8)
+    ref = [v.double().numpy() for v in O.sample_elbo_lr(p, t(x), t(y), 0.25, S, eps=eps)]
+    torch.set_num_threads(1)
+    for i in range(3):
+        close(got["f32"][i], ref[i], rtol=3e-5)
+    close(got["bf16"][1], got["f32"][1], rtol=2e-5)                        # KL: fp32 statistics in both modes
+    close(got["bf16"][2], got["f32"][2], rtol=BF16_NLL_RTOL_GOLDEN)        # NLL: bf16 operands
+
+
 # ------------------------------------------------------------------ whole network, C2 (golden G6)
 @pytest.mark.parametrize("variant", ["bbb", "mix", "lr"])
 @pytest.mark.parametrize("math_mode", ["f32", "bf16"])
