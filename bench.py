@@ -347,6 +347,12 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
                           "floor_us_at_2p4GHz": cycles / (1024 * 2.4e9) * 1e6,
                           "source": "profiles/isa_mix.json (static instruction mix of the k-step loop, tools/make_isa_mix.py; issue costs from "
                                     "tools/ubench.hip); frac = that issue time at 1024 SIMDs x 2.4 GHz over the measured launch time"}})
+    try:       # the measured floor: the same kernel with everything but its vector work compiled out (tools/make_valu_floor.py)
+        vf = json.load(open(os.path.join(REPO, "profiles", "valu_floor.json")))
+        if roof["plan"]["waves"] == 8 and vf.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
+            roof["valu"]["in_situ"] = {k: vf[k] for k in ("full_launch_us", "vector_work_only_us", "without_dma_us", "frac", "source")}
+    except Exception:
+        pass
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))
         for k, v in pm.items():

@@ -29,6 +29,7 @@ $P statsfull steps20 --steps 20 --warmup 5 --no-extras --no-cpu-baseline    # la
 PROF=gpurun_out/profiles
 ( tools/ubench.out > $PROF/${TAG}_ubench_generator.log 2>&1 ) || true
 ( for pz in 1 0; do echo "== BNN_TUNE_PAIRS=$pz (1: K1b2, 0: K1b)"; BNN_TUNE_PAIRS=$pz BNN_HIP_LIB=$PWD/bayesian-neural-network_amd/bnn_hip/libbnn_hip_tune.so python3 tools/k1b_ablate.py 2>&1 | grep -v amdgpu.ids; done > $PROF/${TAG}_k1b_ablate.log 2>&1 ) || true
+( python3 tools/make_valu_floor.py $PROF/${TAG}_k1b_ablate.log > /dev/null 2>&1 && cp profiles/valu_floor.json $PROF/valu_floor.json ) || true
 ( python3 tools/block_gemm_vs_library.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_block_gemm_vs_library.log ) || true
 ( for b in 0 8 1 2 3 7 15 31 27; do echo "== BG_ABL=$b (1 no LDS reads after the first K-tile, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no y stores, 16 no read code in the loop)"; tools/bg_ph2_abl$b.out 4 1024 4096 4096 20 1 | tail -1; done; echo "== four-phase form"; tools/block_gemm_bench_ph4.out 4 1024 4096 4096 20 1 | tail -1; echo "== K sweep (per-K-tile slope and fixed cost)"; tools/gpu_bg_ksweep.sh tools/bg_ph2_abl0.out tools/bg_ph2_abl31.out ) > $PROF/${TAG}_block_gemm_ablation.log 2>&1 || true
 ( for m in 0 1; do tools/mfma_ceiling.out $m; done > $PROF/${TAG}_mfma_ceiling_run.log 2>&1 ) || true
