@@ -230,7 +230,8 @@ int bnn_bbb_plan(const bnn_bbb_fwd_args* args, bnn_plan* plan);
  * fp32 w, as K1 does) in each layer's workspace in K1's format, so bnn_elbo_finalize / bnn_bbb_final_fwd consume
  * them unchanged.  The matmuls then run as bnn_bbb_linear_fwd(w_sampled, b_sampled).  Sampling depends on no
  * activation: out of the layer-after-layer chain of a few-sample evaluation it is one streaming pass over the
- * parameters (8 B read + 2 B written per weight).  in_features % 8 == 0; 16-byte aligned pointers.
+ * parameters (8 B read per weight and group of four samples -- a block serves the group from one read and one softplus --
+ * + 2 B written per weight and sample).  in_features % 8 == 0; 16-byte aligned pointers.
  * ---------------------------------------------------------------------------------- */
 #define BNN_SAMPLE_MAX_LAYERS 8
 typedef struct bnn_bbb_sample_layer {
