@@ -66,10 +66,30 @@ class FusedAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
-        """torch's format.  The device words of a capturable group are updated IN PLACE: a captured training step
-        (train.GraphedTrainStep) holds their addresses, so dropping them would leave its replays reading freed memory and
-        its bias correction at the old step; groups that have no words yet get them at their next step."""
+        """torch's format.  Everything a captured training step (train.GraphedTrainStep) holds the ADDRESS of survives the
+        load: the device words of a capturable group are updated in place, and so are its moment tensors --
+        torch.optim.Optimizer.load_state_dict replaces state[p]['exp_avg'] / ['exp_avg_sq'] with new tensors, which would
+        leave the graph's replays updating the old (freed) buffers and ignoring the loaded moments.  The loaded values are
+        copied into the tensors that existed before the load, and state[p] points at those again.  Groups that have no
+        words yet get them at their next step."""
+        keep = {}
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._dev or group.get("capturable"):
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and "exp_avg" in st:
+                        keep[p] = (st["exp_avg"], st["exp_avg_sq"])
         super().load_state_dict(state_dict)
+        for p, (m, v) in keep.items():
+            st = self.state.get(p)
+            if not st or "exp_avg" not in st:
+                continue
+            if st["exp_avg"] is not m:
+                m.copy_(st["exp_avg"])
+                st["exp_avg"] = m
+            if st["exp_avg_sq"] is not v:
+                v.copy_(st["exp_avg_sq"])
+                st["exp_avg_sq"] = v
         for gi, group in enumerate(self.param_groups):
             if gi not in self._dev:
                 continue

@@ -211,9 +211,12 @@ class BayesianNetwork(nn.Module):
         built = [layer(i, o, self.mu_init, self.rho_init, self.prior_init, self.mixture_prior) for i, o in dims]
         for idx, l in enumerate(built):
             l._layer_id = idx
-        self.l1, self.l2, self.l3 = built
+        # registered in the reference's order (networks.py:160-164): children() yields l1, l1_act, l2, l2_act, l3
+        self.l1 = built[0]
         self.l1_act = nn.ReLU()
+        self.l2 = built[1]
         self.l2_act = nn.ReLU()
+        self.l3 = built[2]
 
     def _specs(self):
         lr = bool(self.local_reparam)

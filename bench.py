@@ -25,10 +25,15 @@ scalars per launch group.  `c4` in the output is BASELINE configs[3] as SURVEY ย
 512) MC samples split over the ranks, one all-reduce of the 4-vector PER EVALUATION.
 
 Prints ONE JSON line (rank 0).  value = total MC samples / s over all ranks; `roofline` is the dominant kernel (layer
-2, 1200x1200 weights) against the roof that binds it -- vector issue for K1b, whose on-chip generator costs ~80 VALU
-instructions per 8 weights (counters: VALU 79 % busy, MFMA 9 %), with SURVEY ยง8(d)'s HBM figure in algorithmic bytes
-beside it (`hbm_algorithmic`) and the fabric traffic counters measured (`traffic`); `cpu_baseline` is the parity-pinned
-CPU oracle timed on this host (fastest thread count, all cores, one thread); `extras` are the other BASELINE configs.
+2, 1200x1200 weights) against the roof that binds it -- vector issue for K1b2, whose on-chip generator is most of the
+~160 VALU instructions per 8 sampled weights (instruction mix: profiles/isa_mix.json; counters: profiles/pmc.json), with the
+ALGORITHMIC lane-op count of the epsilon map beside the compiled loop's (`valu.algorithmic`: derived from the map in
+include/bnn_hip.h, not from the kernel), SURVEY ยง8(d)'s HBM figure in algorithmic bytes (`hbm_algorithmic`), the bf16 MFMA
+fraction (`mfma_frac_of_bf16_peak`) and the fabric traffic counters measured (`traffic`); `cpu_baseline` is the
+parity-pinned CPU oracle timed on this host (fastest thread count, all cores, one thread); `extras` are the other BASELINE
+configs and the other math modes of the headline workload (`math_modes`: f32 = the exact-fp32 matrix core, bf16x3 = split
+bf16 operands on the bf16 matrix core -- the two modes that meet ELBO rtol 1e-4 against the reference's arithmetic at
+every beta).
 """
 import argparse
 import hashlib
@@ -60,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--net", default="mnist", choices=list(DIMS))
     ap.add_argument("--variant", default="bbb", choices=["bbb", "lr"])
-    ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--math", default="bf16", choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -105,16 +110,24 @@ def algorithmic_bytes_layer(fin, fout, batch, x_bytes, y_bytes):
     return 8 * (fin * fout + fout) + batch * fin * x_bytes + batch * fout * y_bytes
 
 
+def sampling_bytes(fin, fout, n_samples):
+    """K1s (bnn_bbb_sample_weights): a block serves a GROUP of four samples from one read of (mu, rho) -- 8 B per weight
+    and group -- and writes each sample's bf16 weights -- 2 B per weight and sample (the biases likewise: fp32 out)."""
+    groups = (n_samples + 3) // 4
+    return (8 * groups + 2 * n_samples) * fin * fout + (8 * groups + 4 * n_samples) * fout
+
+
 def n_stochastic(dims):
     return sum(i * o + o for i, o in ((dims[0], dims[1]), (dims[1], dims[1]), (dims[1], dims[2])))
 
 
 # the source files a kernel family is built from: entries of profiles/traffic.json, pmc.json and isa_mix.json carry the
 # hash of their family's files and are ignored (reported as null) once those have changed
+# (../../include/bnn_hip.h: BNN_PHILOX_ROUNDS, the largest driver of the generator's instruction mix, lives there)
 KERNEL_SOURCES = {
-    "bbb": ("bbb_linear.hip", "bnn_device.h", "bbb_sample_body.h", "bnn_fin.h"),
-    "lr": ("lr_linear.hip", "bnn_device.h", "bnn_fin.h"),
-    "block_gemm": ("bbb_block_gemm.h", "bnn_device.h"),
+    "bbb": ("bbb_linear.hip", "bnn_device.h", "bbb_sample_body.h", "bnn_fin.h", "../../include/bnn_hip.h"),
+    "lr": ("lr_linear.hip", "bnn_device.h", "bnn_fin.h", "../../include/bnn_hip.h"),
+    "block_gemm": ("bbb_block_gemm.h", "bnn_device.h", "../../include/bnn_hip.h"),
 }
 
 
@@ -255,7 +268,7 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
         us_s = kernel_alone_us(smp, torch.cuda.current_stream(), per_graph=10, reps=10)
         us_g = kernel_alone_us(gemm, torch.cuda.current_stream(), per_graph=4, reps=10)
         flops = 2.0 * n * batch * dims[1] * dims[1]
-        sbytes = n * 10 * (dims[1] * dims[1] + dims[1])
+        sbytes = sampling_bytes(dims[1], dims[1], n)
         tf = flops / (us_g * 1e-6) / 1e12
         return {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": None, "traffic_key": f"block_gemm_{dims[1]}_n{n}_b{batch}_{math_name}",
@@ -315,6 +328,30 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
 
 
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+ISSUE_CYCLES = {"valu": 2, "trans": 8, "imul": 7}      # per-class issue cost per wave-instruction and SIMD (tools/ubench.hip)
+
+
+def algorithmic_valu_per_normal(philox_rounds=7, sigma_hoisted=True, x3=False):
+    """Vector work per SAMPLED WEIGHT that the epsilon map of include/bnn_hip.h and the layer's arithmetic REQUIRE,
+    counted from the map -- not from the compiled loop -- as wave-instructions per lane-element by class:
+      Philox4x32-R, 4 normals per call: per round 2 32x32->64 multiplies and 4 xors (the key schedule is wave-uniform:
+        scalar unit); round 1's product of the constant counter word is wave-uniform too -> 2R - 1 multiplies, 4R xors;
+      Box-Muller, 2 normals per pair of words: 2 int->float conversions + 2 fma (u in (0,1]), log2, one multiply
+        (-2 ln 2), sqrt, sin, cos, 2 multiplies = 7 plain + 4 transcendental;
+      the layer: w = fma(sigma, eps, mu), sum eps^2, sum w^2 (3 fma, two weights per v_pk_fma_f32 = 1.5 instructions),
+        half a packed bf16 conversion; softplus when sigma
+        is not hoisted (+ 2 transcendental + 5 plain); the split-bf16 mode's low part (+ 1 subtract, 1 unpack, half a
+        conversion).
+    Returns ({class: instructions per weight}, issue cycles per weight at ISSUE_CYCLES)."""
+    per4 = {"imul": 2 * philox_rounds - 1, "valu": 4 * philox_rounds + 2 * 7, "trans": 2 * 4}
+    c = {k: v / 4.0 for k, v in per4.items()}
+    c["valu"] += 2.0
+    if not sigma_hoisted:
+        c["valu"] += 5
+        c["trans"] += 2
+    if x3:
+        c["valu"] += 2.5
+    return c, sum(ISSUE_CYCLES[k] * v for k, v in c.items())
 
 
 def valu_bound(roof, fin, fout, n, batch, us, sig):
@@ -347,6 +384,21 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
                           "floor_us_at_2p4GHz": cycles / (1024 * 2.4e9) * 1e6,
                           "source": "profiles/isa_mix.json (static instruction mix of the k-step loop, tools/make_isa_mix.py; issue costs from "
                                     "tools/ubench.hip); frac = that issue time at 1024 SIMDs x 2.4 GHz over the measured launch time"}})
+    # the same roof from the ALGORITHMIC count (the map's arithmetic per weight, independent of how the loop was compiled: a
+    # fatter loop scores higher on the instruction-mix figure above, not on this one)
+    try:
+        import re as _re
+        hdr = open(os.path.join(REPO, "include", "bnn_hip.h")).read()
+        rounds = int(_re.search(r"#\s*define\s+BNN_PHILOX_ROUNDS\s+(\d+)", hdr).group(1))
+    except Exception:
+        rounds = 7
+    cls_w, cyc_w = algorithmic_valu_per_normal(rounds, sig, roof.get("math") == "bf16x3")
+    weights = float(fin) * fout * n * ((batch + 127) // 128)          # sampled once per (pair, batch block)
+    alg_floor_us = weights / 64.0 * cyc_w / (1024 * 2.4e9) * 1e6
+    roof["valu"]["algorithmic"] = {"wave_instructions_per_weight": cls_w, "issue_cycles_per_weight": cyc_w, "philox_rounds": rounds,
+                                   "issue_cycles_per_kstep_per_wave": cyc_w * 8, "floor_us_at_2p4GHz": alg_floor_us, "frac": alg_floor_us / us,
+                                   "source": "bench.algorithmic_valu_per_normal: the epsilon map's arithmetic per sampled weight "
+                                             "(Philox rounds, Box-Muller, w / statistics FMAs, bf16 pack), not the compiled loop"}
     try:       # the measured floor: the same kernel with everything but its vector work compiled out (tools/make_valu_floor.py)
         vf = json.load(open(os.path.join(REPO, "profiles", "valu_floor.json")))
         if roof["plan"]["waves"] == 8 and vf.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
@@ -436,9 +488,9 @@ def cpu_baseline(dims, lr, batch, budget_s=15.0):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": 1.0 / med, "unit": "MC-samples/s", "cores": best_t, "kind": "port",
+    return {"value": 1.0 / med, "unit": "MC-samples/s", "cores": best_t, "threads": best_t, "usable_cores": ncpu, "kind": "port",
             "sample": f"{calls} sample_elbo(S=1) calls of the CPU oracle (fp32, no_grad, incl. eps draw) in {secs:.1f} s, median "
-                      f"{med*1e3:.2f} ms, at the fastest intra-op thread count of {cands} (= `cores`, 1.2 s probe each); "
+                      f"{med*1e3:.2f} ms, at the fastest intra-op thread count of {cands} (= `cores` = `threads`: the threads actually used, 1.2 s probe each); "
                       f"usable cores (affinity) = {ncpu}, os.cpu_count() = {os.cpu_count()}; {model}",
             "all_cores": {"threads": ncpu, "value": 1.0 / probe[ncpu][0], "median_ms": probe[ncpu][0] * 1e3, "calls": probe[ncpu][1]},
             "one_thread": {"threads": 1, "value": 1.0 / probe[1][0], "median_ms": probe[1][0] * 1e3, "calls": probe[1][1]},
@@ -579,6 +631,8 @@ def main():
                 "layer2": {k: v for k, v in layer2_roofline(e1, net, dims, args.batch, False, args.math).items()
                            if k in ("kernel", "avg_launch_us", "frac", "plan")},
                 "note": "same network, ONE minibatch, one hipGraph replayed back to back on one stream (latency of one ELBO evaluation)"}
+            out["single_evaluation_us"] = us                        # (flat copies: the driver's parser keeps scalars)
+            out["single_evaluation_samples_per_s"] = rate
             del e1
             # MC-batched evaluations of ONE minibatch (C4's per-GPU share is 8 samples; 64 = C4 on one GPU)
             mc = []

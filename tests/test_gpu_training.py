@@ -569,12 +569,20 @@ def test_graphed_train_step_equals_eager_steps(local_reparam, autograd):
         # (step count -> bias correction, learning rate), and the next replay is torch.optim.Adam's update from that state
         sd = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()} for k, st in ob.state_dict()["state"].items()},
               "param_groups": [dict(g) for g in ob.state_dict()["param_groups"]]}
+        # ... with moments that DIFFER from the live ones (2 m, 3 v): torch's load_state_dict swaps in new tensors, the
+        # captured graphs hold the old addresses -- the loaded values must land in the tensors the graphs update
         for st in sd["state"].values():
             st["step"] = 3
+            st["exp_avg"] = st["exp_avg"] * 2.0
+            st["exp_avg_sq"] = st["exp_avg_sq"] * 3.0
         sd["param_groups"][0]["lr"] = 7e-4
         words = [id(w) for w in ob._dev[0][:2]]
+        moments = [(ob.state[p]["exp_avg"].data_ptr(), ob.state[p]["exp_avg_sq"].data_ptr()) for p in net_b.parameters()]
         ob.load_state_dict(sd)
         assert [id(w) for w in ob._dev[0][:2]] == words and ob.device_step() == 3
+        assert moments == [(ob.state[p]["exp_avg"].data_ptr(), ob.state[p]["exp_avg_sq"].data_ptr()) for p in net_b.parameters()]
+        for p, st in zip(net_b.parameters(), sd["state"].values()):
+            assert torch.equal(ob.state[p]["exp_avg"], st["exp_avg"]) and torch.equal(ob.state[p]["exp_avg_sq"], st["exp_avg_sq"])
         ref = torch.optim.Adam(net_a.parameters(), lr=7e-4)
         net_a.load_state_dict(net_b.state_dict())
         ref.load_state_dict({"state": {k: {"step": torch.tensor(3.0), "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}

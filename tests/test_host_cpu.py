@@ -128,6 +128,7 @@ def test_drop_in_surface():
     assert tuple(net.l1.weight_mu.shape) == (1200, 784) and tuple(net.l3.bias_rho.shape) == (10,)
     assert net.l1.weight.mu is net.l1.weight_mu and net.l1.bias.rho is net.l1.bias_rho
     assert all(isinstance(c, (networks.BayesianLinear, torch.nn.ReLU)) for c in net.children())
+    assert [n for n, _ in net.named_children()] == ["l1", "l1_act", "l2", "l2_act", "l3"]      # networks.py:160-164
     assert net.batch_size == 128 and net.l1.log_prior == 0 and net.l1.log_variational_posterior == 0
     lr = networks.BayesianNetwork(dict(mp, local_reparam=True))
     assert tuple(lr.l1.weight_mu.shape) == (784, 1200) and lr.l1.kl_cost == 0 and lr.l1.weight_prior == [0, 1.0]
@@ -430,10 +431,21 @@ def test_bench_roofline_bookkeeping_without_a_device(tmp_path, monkeypatch):
         assert out["achieved"] == pytest.approx(want) and 0.0 < out["frac"] < 1.0
     else:
         assert out["achieved"] is None and "valu_note" in out
+    # the algorithmic count (from the epsilon map, not from the compiled loop) sits beside the instruction-mix figure
+    if out["achieved"] is not None:
+        alg = out["valu"]["algorithmic"]
+        assert alg["philox_rounds"] == 7 and alg["wave_instructions_per_weight"]["imul"] == pytest.approx(13 / 4)
+        assert alg["floor_us_at_2p4GHz"] == pytest.approx(1200 * 1200 * 256 / 64 * alg["issue_cycles_per_weight"] / (1024 * 2.4e9) * 1e6)
+        assert 0.0 < alg["frac"] < 1.0
+    # K1s' bytes: (mu, rho) once per group of four samples + every sample's bf16 weights -- never above the HBM figure
+    assert bench.sampling_bytes(4096, 4096, 4) == (8 + 2 * 4) * 4096 * 4096 + (8 + 4 * 4) * 4096
+    assert bench.sampling_bytes(4096, 4096, 4) / 55.7e-6 / 1e9 / bench.HBM_PEAK_GBS < 1.0
+    assert "../../include/bnn_hip.h" in bench.KERNEL_SOURCES["bbb"]         # BNN_PHILOX_ROUNDS is part of every family's hash
     # a traffic entry is attached only while its family's sources hash to the recorded value
     monkeypatch.setattr(bench, "REPO", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
     os.makedirs(tmp_path / "bayesian-neural-network_amd" / "csrc")
+    os.makedirs(tmp_path / "include")
     for f in bench.KERNEL_SOURCES["bbb"]:
         (tmp_path / "bayesian-neural-network_amd" / "csrc" / f).write_text("// " + f)
     good = bench.source_hash(bench.KERNEL_SOURCES["bbb"])
