@@ -7,11 +7,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1
-MATH_F32, MATH_BF16 = 0, 1
+MATH_F32, MATH_BF16, MATH_BF16X3 = 0, 1, 2
 EPS_PHILOX, EPS_MEMORY, EPS_ZERO = 0, 1, 2
 PRIOR_GAUSS, PRIOR_MIXTURE = 0, 1
 NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
@@ -53,7 +53,7 @@ class BbbFwdArgs(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("form", C.c_int32),
         ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t), ("w_sigma", C.c_void_p),
         ("w_sampled", C.c_void_p), ("b_sampled", C.c_void_p), ("rider", C.c_void_p), ("y_bf16_copy", C.c_void_p),
-        ("w_sampled_t_out", C.c_void_p),
+        ("w_sampled_t_out", C.c_void_p), ("x_lo", C.c_void_p), ("y_lo", C.c_void_p),
     ]
 
 
@@ -194,7 +194,8 @@ PREPARE_MAX = 8
 class PrepareArgs(C.Structure):
     _fields_ = [("struct_bytes", C.c_uint32), ("n_softplus", C.c_int32),
                 ("rho", C.c_void_p * PREPARE_MAX), ("sigma", C.c_void_p * PREPARE_MAX), ("n", C.c_int64 * PREPARE_MAX),
-                ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_dst_sq", C.c_void_p), ("cast_n", C.c_int64)]
+                ("cast_src", C.c_void_p), ("cast_dst", C.c_void_p), ("cast_dst_sq", C.c_void_p), ("cast_n", C.c_int64),
+                ("cast_dst_lo", C.c_void_p)]
 
 
 class BnnHipError(RuntimeError):

@@ -48,7 +48,8 @@ PRESAMPLE_HIDDEN_MAX_SAMPLES = 0
 
 def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
     """The output layer of this evaluation can take the pre-sampled row-split form."""
-    if len(specs) < 2 or any(sp.lr for sp in specs) or hidden_dtype != torch.bfloat16 or state.form != L.FORM_AUTO:
+    if len(specs) < 2 or any(sp.lr for sp in specs) or hidden_dtype != torch.bfloat16 or state.form != L.FORM_AUTO or \
+            state.math != L.MATH_BF16:                  # (the pre-sampled forms carry bf16 weights: plain bf16 math only)
         return False
     k_last, n_last = specs[-1].in_out
     return 0 < n_samples <= FINAL_ROWS_MAX_SAMPLES and n_last <= 16 and batch <= 128 and k_last % 8 == 0
@@ -64,7 +65,7 @@ BLOCK_GEMM_MIN_BATCH = 512
 
 def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:
     return (not sp.lr) and hidden_dtype == torch.bfloat16 and batch >= BLOCK_GEMM_MIN_BATCH and sp.in_out[0] % 8 == 0 and \
-        state.form == L.FORM_AUTO
+        state.form == L.FORM_AUTO and state.math == L.MATH_BF16
 
 
 def presample_from(specs, n_samples: int, batch: int, hidden_dtype) -> int:
@@ -81,7 +82,7 @@ def presample_from(specs, n_samples: int, batch: int, hidden_dtype) -> int:
 def use_split(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
     units = ((fout + 63) // 64) * n_samples * ((batch + 127) // 128)
     return fout > 16 and fin % 8 == 0 and fin * fout >= SPLIT_MIN_WEIGHTS and n_samples >= SPLIT_MIN_SAMPLES and \
-        units <= SPLIT_MAX_UNITS
+        units <= SPLIT_MAX_UNITS and state.math == L.MATH_BF16
 
 
 def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
@@ -91,7 +92,7 @@ def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
     units = ((fout + 63) // 64) * n_samples * ((batch + 127) // 128)
     enough = n_samples >= (SIGMA_HOIST_MIN_SAMPLES if fin * fout < SIGMA_HOIST_BIG_LAYER else SIGMA_HOIST_MIN_SAMPLES_BIG)
     return fout > 16 and fin % 8 == 0 and fin * fout >= SPLIT_MIN_WEIGHTS and enough and \
-        (units >= 450 or n_samples >= SPLIT_MIN_SAMPLES)
+        (units >= 450 or (n_samples >= SPLIT_MIN_SAMPLES and state.math == L.MATH_BF16))      # (bf16x3: no K-sliced form)
 
 
 # measured: the pass costs ~1.6 us per million weights; what it saves per sample shrinks as more waves per SIMD cover the
@@ -147,6 +148,12 @@ def wide_nll(specs, batch: int) -> bool:
     return n_out > 32 and batch * n_out >= 32768
 
 
+def effective_math(any_lr: bool) -> int:
+    """The math mode the launches of a network run in: the split-bf16 mode exists for the BBB forward kernels; the
+    local-reparameterisation layers run it as exact fp32 (the mode's promise is the reference's fp32 arithmetic)."""
+    return L.MATH_F32 if (state.math == L.MATH_BF16X3 and any_lr) else state.math
+
+
 def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of global sample indices owned by `rank`: [first, first+count).
     The first (n_samples % world) ranks own one extra sample."""
@@ -191,10 +198,11 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
     """Push `n_local` MC samples through the stack.  Returns (logits[S,B,C] fp32,
     per-layer stats).  Stats are (log_prior[S], log_q[S]) or kl3[3] tensors on the
     differentiable path and raw workspaces on the forward-only path."""
-    math_mode = state.math
-    hidden_dtype = torch.float32 if (differentiable or math_mode == L.MATH_F32) else torch.bfloat16
-    h, h_sq = x, None
     any_lr = any(sp.lr for sp in layers)
+    math_mode = effective_math(any_lr)
+    x3 = math_mode == L.MATH_BF16X3
+    hidden_dtype = torch.float32 if (differentiable or math_mode == L.MATH_F32) else torch.bfloat16
+    h, h_sq, h_lo = x, None, None                  # h_lo: the low plane of a bf16 activation in split-bf16 math
     lr_sq = (not differentiable) and hidden_dtype == torch.bfloat16 and n_local >= LR_SQUARES_MIN_SAMPLES and any_lr
     # everything that depends on no activation, in one launch: the input batch in bf16 (every layer then streams 2-byte x;
     # LR: and its elementwise square) and sigma = softplus(rho) of the layers that will run a block-GEMM form
@@ -211,11 +219,12 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
         hoisted = {i: None for i, sp in enumerate(layers)
                    if not sp.lr and hoist_sigma(*sp.in_out, n_local, x.shape[-2]) and not use_block_gemm(sp, x.shape[-2], hidden_dtype)}
     if want_cast or hoisted:
+        c16lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_cast and x3) else None
         sig, c16, c16sq = ops.eval_prepare([layers[i].m.weight_rho.detach() for i in hoisted],
-                                           cast=x if want_cast else None, want_sq=lr_sq and want_cast)
+                                           cast=x if want_cast else None, want_sq=lr_sq and want_cast, cast_out_lo=c16lo)
         hoisted = dict(zip(hoisted, sig))
         if want_cast:
-            h, h_sq = c16, c16sq
+            h, h_sq, h_lo = c16, c16sq, c16lo
     stats = []
     # forward-only ELBO with on-chip eps: the output layer may take the pre-sampled row-split form (final_rows_ok)
     pre_from = presample_from(layers, n_local, x.shape[-2], hidden_dtype) \
@@ -273,6 +282,8 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                 kw = dict(n_samples=n_local, prior=call.prior, math_mode=math_mode, relu=sp.relu, y_dtype=call.y_dtype,
                           eps_mode=eps_mode, eps_w=e_w, eps_b=e_b, seed=state.seed, layer_id=sp.layer_id,
                           sample_offset=first_sample, want_stats=want_stats, form=state.form)
+                if x3 and h.dtype == torch.bfloat16:
+                    kw["x_lo"] = h_lo
                 if eps_mode == L.EPS_PHILOX and use_block_gemm(sp, h.shape[-2], hidden_dtype):
                     if h.dtype != torch.bfloat16:
                         h = ops.cast_bf16(h)
@@ -311,6 +322,7 @@ def run_layers(layers: Sequence[LayerSpec], x: torch.Tensor, n_local: int, first
                          for q in layers[i + 1:]], n_samples=n_local, seed=state.seed, sample_offset=first_sample)
                     presampled = {i + 1 + j: r for j, r in enumerate(kw["rider"][1])}
                 out = ops.bbb_linear_fwd(h, *pd, **kw)
+                h_lo = out.get("y_lo")
             h = out["y"]
             stats.append(out["workspace"])
     return h, stats
@@ -502,13 +514,16 @@ class GraphedElbo:
         self.counter = torch.tensor([first], dtype=torch.int32, device=dev)
         S = self.n_local
         B = self.x.shape[-2]
-        math_mode = state.math
+        math_mode = self.math = effective_math(self.lr)
+        self.x3 = math_mode == L.MATH_BF16X3
         hid = torch.float32 if math_mode == L.MATH_F32 else torch.bfloat16
-        self.bufs, self.ws = [], []
+        self.bufs, self.ws, self.bufs_lo = [], [], []
         for i, sp in enumerate(self.specs):
             fin, fout = sp.in_out
             last = i == len(self.specs) - 1
             self.bufs.append(torch.empty((S, B, fout), dtype=torch.float32 if last else hid, device=dev))
+            # split-bf16 math: the low plane of every bf16 activation
+            self.bufs_lo.append(torch.empty((S, B, fout), dtype=torch.bfloat16, device=dev) if (self.x3 and not last) else None)
             self.ws.append(ops.lr_workspace(fout, dev) if self.lr else ops.bbb_workspace(S, fout, dev))
         keys = ("kl",) if self.lr else ("log_prior", "log_q")
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
@@ -535,6 +550,7 @@ class GraphedElbo:
                     if (hid == torch.bfloat16 and self.x.dtype == torch.float32 and
                         (self.lib[0] or S >= (CAST_INPUT_MIN_SAMPLES_LR if self.lr else CAST_INPUT_MIN_SAMPLES)) and
                         not k3s_first) else None)
+        self.x16_lo = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if (self.x3 and self.x16 is not None) else None
         self.lr_sq = self.lr and (self.x16 is not None or (k3s_first and hid == torch.bfloat16)) and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and self.x16 is not None) else None
         self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
@@ -593,17 +609,17 @@ class GraphedElbo:
 
     def _enqueue(self):
         """One evaluation of all local (minibatch, MC sample) pairs."""
-        math_mode = state.math
-        h_sq = None
+        math_mode = self.math
+        h_sq, h_lo = None, None
         # one launch for everything that depends on no activation: the bf16 input batch (+ squares), the hoisted sigmas
         hoist = [i for i, w in enumerate(self.wsigma) if w is not None]
         h = self.x
         if self.x16 is not None or hoist:
             ops.eval_prepare([self.specs[i].m.weight_rho.detach() for i in hoist], [self.wsigma[i] for i in hoist],
                              cast=self.x if self.x16 is not None else None, cast_out=self.x16,
-                             cast_out_sq=self.x16_sq)
+                             cast_out_sq=self.x16_sq, cast_out_lo=self.x16_lo)
             if self.x16 is not None:
-                h, h_sq = self.x16, self.x16_sq
+                h, h_sq, h_lo = self.x16, self.x16_sq, self.x16_lo
         last = len(self.specs) - 1
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
@@ -639,6 +655,8 @@ class GraphedElbo:
                     ops.elbo_finalize(workspaces=self.ws, logits=self.bufs[i], **fin_kw)
             else:
                 kw = dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], w_sigma=self.wsigma[i], **common)
+                if self.x3:
+                    kw.update(x_lo=h_lo if h.dtype == torch.bfloat16 else None, out_lo=self.bufs_lo[i])
                 if i == last and self.rows:
                     ops.bbb_final_fwd((h, None, None, None, None),
                                       dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
@@ -659,7 +677,7 @@ class GraphedElbo:
                              for j, q in enumerate(self.specs) if j > i],
                             n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
                     ops.bbb_linear_fwd(h, *p, **kw)
-            h = self.bufs[i]
+            h, h_lo = self.bufs[i], self.bufs_lo[i]
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
 

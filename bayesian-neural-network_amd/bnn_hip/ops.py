@@ -67,6 +67,12 @@ def _dt(t: torch.Tensor) -> int:
     raise BnnHipError(f"activations must be float32 or bfloat16, got {t.dtype}")
 
 
+def _exact_unless_bf16(math_mode: int) -> int:
+    """The split-bf16 mode (MATH_BF16X3) exists for the BBB forward kernels; every other launch of a job in that mode --
+    the local-reparameterisation layers, the backward kernels -- runs the exact-fp32 matrix core."""
+    return L.MATH_F32 if math_mode == L.MATH_BF16X3 else math_mode
+
+
 def _x3(x: torch.Tensor, n_samples: int):
     """Returns (contiguous x, batch, in_features, x_per_sample): 0 = one x for all samples, g >= 1 = sample s reads
     x[s // g] (x [rows, batch, in] with rows * g == n_samples: g = 1 is one x per sample, g = S is one x per minibatch
@@ -165,7 +171,8 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
                layer_id: int = 0, sample_offset: int = 0, want_stats: bool = True,
                want_scalars: bool = False, dump_eps: bool = False, workspace=None, sample_counter=None,
                out=None, split_scratch=None, w_sigma=None, form: int = 0, sample_group: int = 0,
-               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None, want_y16: bool = False, wt_out=None):
+               sample_group_stride: int = 0, w_sampled=None, b_sampled=None, rider=None, want_y16: bool = False, wt_out=None,
+               x_lo=None, out_lo=None):
     """Argument block of K1 + the tensors it points at (kept alive by the caller).  `w_sampled` / `b_sampled` (bf16
     [S,out,in] / fp32 [S,out] from bbb_sample_weights): the matmul-only form, the parameter tensors may then be None.
     `rider` = the (args, results, keep) of build_sample_job: an independent sampling job carried by the launch."""
@@ -233,6 +240,19 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
     a.workspace_bytes = workspace.numel() * 4 if (want_stats and workspace is not None) else 0
     a.log_prior, a.log_q = _ptr(lp), _ptr(lq)
     a.y, a.y_dtype = y.data_ptr(), _dt(y)
+    y_lo = None
+    if math_mode == L.MATH_BF16X3:
+        # split-bf16 math: a bf16 activation is a PAIR of planes (hi = x / y, lo = x_lo / out_lo), fp32 ones are split on chip
+        if xs.dtype == torch.bfloat16:
+            if x_lo is None or x_lo.dtype != torch.bfloat16 or tuple(x_lo.shape) != tuple(x.shape) or not x_lo.is_contiguous():
+                raise BnnHipError("bf16x3 math on bf16 x needs x_lo: the contiguous bf16 low plane, shaped like x")
+            require_device(x_lo)
+            a.x_lo = x_lo.data_ptr()
+        if y.dtype == torch.bfloat16:
+            y_lo = out_lo if out_lo is not None else torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=dev)
+            if y_lo.dtype != torch.bfloat16 or y_lo.numel() != y.numel() or not y_lo.is_contiguous():
+                raise BnnHipError("out_lo must be a contiguous bf16 tensor shaped like y")
+            a.y_lo = y_lo.data_ptr()
     if w_sigma is not None:
         a.w_sigma = w_sigma.data_ptr()
     if split_scratch is not None:
@@ -240,8 +260,8 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
     if rider is not None:
         a.rider = C.addressof(rider[0])
-    res = dict(y=y, y16=_y16(a, y) if want_y16 else None, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma, rider)
+    res = dict(y=y, y16=_y16(a, y) if want_y16 else None, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db, y_lo=y_lo)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma, rider, x_lo, y_lo)
     return a, res, keep
 
 
@@ -355,6 +375,7 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     """Argument block of K3 + the result dict + the tensors it points at.  `rider`: dict(w_mu, w_rho, b_mu, b_rho, w_frag,
     workspace) of a narrow LR layer whose operands this launch prepares on the side (bnn_lr_rider)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
+    math_mode = _exact_unless_bf16(math_mode)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     K, N = w_mu.shape
@@ -664,7 +685,7 @@ def bbb_linear_bwd(x, gy, y, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior:
         y = _f32c(y, "y")
         a.y = y.data_ptr()
     a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
-    a.eps_mode, a.math = eps_mode, math_mode
+    a.eps_mode, a.math = eps_mode, _exact_unless_bf16(math_mode)
     if eps_mode == L.EPS_MEMORY:
         eps_w, eps_b = _f32c(eps_w, "eps_w"), _f32c(eps_b, "eps_b")
         a.eps_w, a.eps_b = eps_w.data_ptr(), eps_b.data_ptr()
@@ -736,7 +757,7 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
         y = _f32c(y, "y")
         a.y = y.data_ptr()
     a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
-    a.eps_mode, a.math = eps_mode, int(math_mode)
+    a.eps_mode, a.math = eps_mode, _exact_unless_bf16(int(math_mode))
     if eps_mode == L.EPS_MEMORY:
         eps_act, eps_b = _f32c(eps_act, "eps_act"), _f32c(eps_b, "eps_b")
         a.eps_act, a.eps_b = eps_act.data_ptr(), eps_b.data_ptr()
@@ -915,9 +936,10 @@ def softplus(rho: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
 
 
 def eval_prepare(rhos=(), sigmas=None, cast: Optional[torch.Tensor] = None, cast_out: Optional[torch.Tensor] = None,
-                 cast_out_sq: Optional[torch.Tensor] = None, want_sq: bool = False):
+                 cast_out_sq: Optional[torch.Tensor] = None, want_sq: bool = False, cast_out_lo: Optional[torch.Tensor] = None):
     """bnn_eval_prepare: sigma = softplus(rho) for every tensor of `rhos` and (optionally) the bf16 cast of `cast`
-    (+ its squares) in ONE launch -- everything of an evaluation that depends on no activation.
+    (+ its squares; + `cast_out_lo`, the low plane bf16(x - bf16(x)) of the split-bf16 math mode) in ONE launch --
+    everything of an evaluation that depends on no activation.
     Returns (list of sigma tensors, cast_out, cast_out_sq)."""
     lib = L.load()
     rhos = [_f32c(r, "rho") for r in rhos]
@@ -940,6 +962,11 @@ def eval_prepare(rhos=(), sigmas=None, cast: Optional[torch.Tensor] = None, cast
         if want_sq and cast_out_sq is None:
             cast_out_sq = torch.empty(cast.shape, dtype=torch.bfloat16, device=cast.device)
         a.cast_src, a.cast_dst, a.cast_dst_sq, a.cast_n = cast.data_ptr(), cast_out.data_ptr(), _ptr(cast_out_sq), cast.numel()
+        if cast_out_lo is not None:
+            if cast_out_lo.dtype != torch.bfloat16 or cast_out_lo.numel() != cast.numel() or not cast_out_lo.is_contiguous():
+                raise BnnHipError("eval_prepare: cast_out_lo must be a contiguous bf16 tensor of the input's size")
+            require_device(cast_out_lo)
+            a.cast_dst_lo = cast_out_lo.data_ptr()
     if not rhos and cast is None:
         return [], None, None
     L.check(lib.bnn_eval_prepare(C.byref(a), _stream()), "bnn_eval_prepare")

@@ -3,6 +3,9 @@ arguments (networks.py:50, :92, :142), so build-side settings live here and in e
 
   BNN_HIP_MATH   bf16 (default; bf16 MFMA operands, fp32 accumulate, fp32 statistics)
                  f32  (exact fp32 MFMA; the parity mode)
+                 bf16x3 (split-bf16 operands, three bf16 MFMAs per product: the reference's fp32 F.linear to ~1e-5 of
+                         the output scale at 3/16 of the exact mode's matrix-core time; BBB forward paths, the
+                         local-reparameterisation layers and every backward run it as f32)
   BNN_HIP_SEED   64-bit Philox key (default 2026)
   BNN_HIP_EPS    device (default; on-chip Philox)  |  host (draw eps with torch's CPU
                  generator in the reference's order, networks.py:42, then copy H2D)
@@ -19,8 +22,8 @@ _lock = threading.Lock()
 
 class _State:
     def __init__(self):
-        self.math = L.MATH_F32 if os.environ.get("BNN_HIP_MATH", "bf16").lower() in ("f32", "fp32", "float32") \
-            else L.MATH_BF16
+        m = os.environ.get("BNN_HIP_MATH", "bf16").lower()
+        self.math = L.MATH_F32 if m in ("f32", "fp32", "float32") else L.MATH_BF16X3 if m in ("bf16x3", "x3") else L.MATH_BF16
         self.seed = int(os.environ.get("BNN_HIP_SEED", "2026"))
         self.host_eps = os.environ.get("BNN_HIP_EPS", "device").lower() == "host"
         self.counter = 0            # next unused GLOBAL MC sample index
@@ -35,18 +38,20 @@ state = _State()
 
 
 def set_math(mode: str):
-    """'bf16' or 'f32'."""
+    """'bf16', 'f32' or 'bf16x3'."""
     m = mode.lower()
     if m in ("bf16", "bfloat16"):
         state.math = L.MATH_BF16
     elif m in ("f32", "fp32", "float32"):
         state.math = L.MATH_F32
+    elif m in ("bf16x3", "x3"):
+        state.math = L.MATH_BF16X3
     else:
         raise ValueError(f"unknown math mode {mode!r}")
 
 
 def get_math() -> str:
-    return "bf16" if state.math == L.MATH_BF16 else "f32"
+    return {L.MATH_BF16: "bf16", L.MATH_F32: "f32", L.MATH_BF16X3: "bf16x3"}[state.math]
 
 
 def manual_seed(seed: int, counter: int = 0):

@@ -74,6 +74,8 @@ struct BbbK {
   int xg;                                 // samples sharing one x row block (x index = s / xg); x_sstride = 0: one x for all
   uint32_t sgrp, sgrp_stride;             // sample groups (bnn_bbb_fwd_args.sample_group): 0 = none
   float inv2var1, c1, inv2var2, c2, pi;   // mixture: log N(w;0,s_i) = c_i - w^2 * inv2var_i
+  const void* x_lo;                       // BNN_MATH_BF16X3, bf16 x: the low plane of x (strided like x)
+  void* y_lo;                             // BNN_MATH_BF16X3, bf16 y: the low plane of y
 #ifdef BNN_STAMPS
   unsigned long long* dbg;   // diagnostic build only: [block][16] shader-clock stamps of wave 0
 #endif
@@ -254,6 +256,19 @@ __device__ __forceinline__ void epilogue_store(const BbbK& p, const f32x4* __res
         for (int i = 0; i < 4; ++i)
           if (nb + i < N) yp[i] = (__bf16)v[i];
       }
+      if (p.y_lo) {                                // split-bf16 math: the low plane, bf16(v - hi)
+        __bf16* lp = reinterpret_cast<__bf16*>(p.y_lo) + yoff;
+        bf16x4 l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l[i] = (__bf16)(v[i] - (float)(__bf16)v[i]);
+        if (vec_ok) {
+          *reinterpret_cast<bf16x4*>(lp) = l;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < N) lp[i] = l[i];
+        }
+      }
     } else {
       float* yp = reinterpret_cast<float*>(p.y) + yoff;
       if (vec_ok) {
@@ -336,6 +351,10 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
   const int gpr = (K + 3) >> 2;
   const uint32_t wid = p.layer_id * 4u;
   const char* xs = reinterpret_cast<const char*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride * (XDT == BNN_F32 ? 4 : 2);
+  // split-bf16 math (BNN_MATH_BF16X3): bf16 activations are a pair of planes, fp32 activations are split in registers
+  constexpr bool X3 = MATH == BNN_MATH_BF16X3;
+  static_assert(!X3 || (!TRANS && !PRE && !WT), "the split-bf16 mode is a forward sampling form");
+  const char* xs_lo = (X3 && XDT == BNN_BF16) ? reinterpret_cast<const char*>(p.x_lo) + (size_t)(s / p.xg) * (size_t)p.x_sstride * 2 : nullptr;
 
   float* lds_bias = lds + (size_t)nw * MT * 64 * 4;   // 16 floats
   float* lds_red = lds_bias + 16;                    // 3 * nw floats
@@ -399,7 +418,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
     const int k = (t * R + c) * 32 + q * 8;
     const int valid = n_ok ? min(8, K - k) : 0;     // ALIGNED: 8 or <= 0
     // ---- x fragments of the first batch-tile chunk, issued ahead of the generator work.
-    constexpr int FR = (XDT == BNN_F32) ? 2 : 1;                  // 16-byte loads per fragment
+    constexpr int FR = (XDT == BNN_F32 || X3) ? 2 : 1;            // 16-byte loads per fragment (X3 on bf16 x: hi, lo)
     constexpr int MC0 = (8 / (R * FR)) < 1 ? 1 : (8 / (R * FR));
     constexpr int MC = MC0 > MT ? MT : MC0;                       // batch tiles staged at once
     float4 xraw[MC * R * FR];
@@ -416,6 +435,9 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
               const float4* px = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xs) + off);
               xraw[(mm * R + cc) * 2 + 0] = px[0];
               xraw[(mm * R + cc) * 2 + 1] = px[1];
+            } else if (X3) {
+              xraw[(mm * R + cc) * 2 + 0] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xs) + off);
+              xraw[(mm * R + cc) * 2 + 1] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xs_lo) + off);
             } else {
               xraw[mm * R + cc] = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(xs) + off);
             }
@@ -432,7 +454,16 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
               for (int j = 0; j < 8; ++j)
                 vb[j] = (j < xvalid) ? (reinterpret_cast<const __bf16*>(xs) + off)[j] : (__bf16)0.0f;
-              xraw[mm * R + cc] = __builtin_bit_cast(float4, vb);
+              if (X3) {
+                bf16x8 vl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  vl[j] = (j < xvalid) ? (reinterpret_cast<const __bf16*>(xs_lo) + off)[j] : (__bf16)0.0f;
+                xraw[(mm * R + cc) * 2 + 0] = __builtin_bit_cast(float4, vb);
+                xraw[(mm * R + cc) * 2 + 1] = __builtin_bit_cast(float4, vl);
+              } else {
+                xraw[mm * R + cc] = __builtin_bit_cast(float4, vb);
+              }
             }
           }
         }
@@ -514,7 +545,15 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       for (int j = 0; j < 8; ++j) w[j] = 0.f;
     }
     if (t == t_lo + wave) { asm volatile("" :: "v"(w[0]), "v"(w[7])); BNN_STAMP(2); }
-    bf16x8 wa, wz;
+    bf16x8 wa, wz, wl;
+    if (X3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wa[j] = (__bf16)w[j];
+        wl[j] = split_lo(w[j], wa[j]);
+        wz[j] = (__bf16)0.f;
+      }
+    }
     if (MATH == BNN_MATH_BF16) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -541,7 +580,25 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
 #pragma unroll
           for (int cc = 0; cc < R; ++cc) {
             const int m = ch * MC + mm;
-            if (MATH == BNN_MATH_BF16) {
+            if (X3) {
+              bf16x8 xh, xl;
+              if (XDT == BNN_F32) {
+                const float4 lo = xraw[(mm * R + cc) * 2], hi = xraw[(mm * R + cc) * 2 + 1];
+                const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  xh[j] = (__bf16)xv[j];
+                  xl[j] = split_lo(xv[j], xh[j]);
+                }
+              } else {
+                xh = __builtin_bit_cast(bf16x8, xraw[(mm * R + cc) * 2]);
+                xl = __builtin_bit_cast(bf16x8, xraw[(mm * R + cc) * 2 + 1]);
+              }
+              const bool mine = R == 1 || c == cc;
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? wa : wz, xh, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? wl : wz, xh, acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? wa : wz, xl, acc[m], 0, 0, 0);
+            } else if (MATH == BNN_MATH_BF16) {
               bf16x8 xb;
               if (XDT == BNN_F32) {
                 const float4 lo = xraw[(mm * R + cc) * 2], hi = xraw[(mm * R + cc) * 2 + 1];
@@ -1265,18 +1322,24 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 //   bytes lane l of the consuming wave reads back with one ds_read_b128 (conflict-free by construction).
 // Everything else -- epsilon map, statistics, epilogue -- is K1b's; the per-step statistics are summed two lanes-worth at a
 // time (packed fp32 FMAs), so they agree with K1b's to fp32 summation order, the outputs bit for bit.
-template <int NF, int SB, int EPS, int NB = 2>
-__global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
+// X3 (BNN_MATH_BF16X3): split-bf16 operands.  x arrives as two planes (hi, lo): a pair's tile of a k-step is 16 KiB
+// ([hi | lo][8 batch tiles][64 lanes] x 16 B), the sampled weight fragment is split in registers (wa = bf16(w), wl =
+// bf16(w - wa)), and every (batch tile, k-step) takes three MFMAs: wa . xh + wl . xh + wa . xl.  The staging buffers then
+// hold 48 KiB each (96 KiB per block: one 8-wave block per CU, two waves per SIMD, up to 256 VGPRs).
+template <int NF, int SB, int EPS, int NB = 2, bool X3 = false>
+__global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
   constexpr int NW = NF * SB;
   static_assert(NB == 2 || NB == 3, "staging buffers (NB - 1 k-steps of DMA run-ahead)");
   constexpr int WPW = 4 / SB;                 // parameter pieces (of a tile's four) each of the SB waves of a tile brings
   constexpr int XPW = 8 / NF;                 // x pieces (batch tiles of its pair) each of the NF waves of a pair brings
+  constexpr int XT = X3 ? 1024 : 512;         // float4s of one pair's x tile (X3: the hi plane's 8 pieces, then the lo plane's)
   static_assert(SB == 1 || SB == 2 || SB == 4, "pairs per block");
   static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
+  static_assert(!X3 || NB == 2, "split-bf16 form: two staging buffers");
   // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
-  __shared__ __attribute__((aligned(16))) float4 sm_all[NB * (NF * 256 + SB * 512) + NW * 4];
-  float4 (*sm)[NF * 256 + SB * 512] = reinterpret_cast<float4 (*)[NF * 256 + SB * 512]>(sm_all);
-  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + NB * (NF * 256 + SB * 512));
+  __shared__ __attribute__((aligned(16))) float4 sm_all[NB * (NF * 256 + SB * XT) + NW * 4];
+  float4 (*sm)[NF * 256 + SB * XT] = reinterpret_cast<float4 (*)[NF * 256 + SB * XT]>(sm_all);
+  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + NB * (NF * 256 + SB * XT));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the staging bases below live in SGPRs)
   const int fw = wave % NF, sb = wave / NF;
   const int r = lane & 15, q = lane >> 4;
@@ -1302,6 +1365,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   const int gpr = (K + 3) >> 2;
   const uint32_t wid = p.layer_id * 4u;
   const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+  const __bf16* xs_lo = X3 ? reinterpret_cast<const __bf16*>(p.x_lo) + (size_t)(s / p.xg) * (size_t)p.x_sstride : nullptr;
   const int T = (N + 15) >> 4;
 
   if (do_stats && tb == 0 && unit == 0 && fw == 0 && lane == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
@@ -1322,7 +1386,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
 #pragma unroll
   for (int i = 0; i < XPW; ++i) voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[0][0];
-  constexpr uint32_t kBufBytes = (NF * 256 + SB * 512) * 16;
+  constexpr uint32_t kBufBytes = (NF * 256 + SB * XT) * 16;
   // (the plan takes this form only where the tensors' byte spans fit 32 bits)
   auto stage_fast = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1335,8 +1399,16 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
       const char* base = reinterpret_cast<const char*>(xs) + (size_t)t * 64;
-      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + (sb * 8 + fw + i * NF) * 64) * 16);
+      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + sb * XT + (fw + i * NF) * 64) * 16);
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
+    }
+    if (X3) {
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        const char* base = reinterpret_cast<const char*>(xs_lo) + (size_t)t * 64;
+        const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + sb * XT + 512 + (fw + i * NF) * 64) * 16);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
+      }
     }
   };
   auto stage_slow = [&](int t, int buf) __attribute__((always_inline)) {
@@ -1355,7 +1427,14 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
-                                       (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + (sb * 8 + fw + i * NF) * 64], 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + sb * XT + (fw + i * NF) * 64], 16, 0, 0);
+    }
+    if (X3) {
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_lo + xrow[i] + kk),
+                                         (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + sb * XT + 512 + (fw + i * NF) * 64], 16, 0, 0);
+      }
     }
   };
   auto stage = [&](int t, int buf) __attribute__((always_inline)) {
@@ -1462,13 +1541,17 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
       s_a += lane_ok ? a : 0.f;
       s_ls += lane_ok ? ls : 0.f;
     }
-    bf16x8 wa;
+    bf16x8 wa, wl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       wa[2 * j] = lane_ok ? (__bf16)w2[j][0] : (__bf16)0.f;
       wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
+      if (X3) {                                   // the low part of the split pair: bf16(w - bf16(w)), exact difference
+        wl[2 * j] = lane_ok ? (__bf16)(w2[j][0] - (float)wa[2 * j]) : (__bf16)0.f;
+        wl[2 * j + 1] = lane_ok ? (__bf16)(w2[j][1] - (float)wa[2 * j + 1]) : (__bf16)0.f;
+      }
     }
-    const uint32_t xa = lbase + (uint32_t)((NF * 256 + sb * 512 + q * 16 + r) * 16);
+    const uint32_t xa = lbase + (uint32_t)((NF * 256 + sb * XT + q * 16 + r) * 16);
 #ifdef BNN_TUNE
     const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
 #else
@@ -1485,6 +1568,32 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
       else
         asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
                      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
+      if (X3) {
+        // the lo plane's four fragments are requested behind the hi plane's: the hi products (two MFMAs per batch tile) run
+        // while they are in flight
+        f32x4 l0, l1, l2, l3;
+        if (h == 0)
+          asm volatile("ds_read_b128 %0, %4 offset:8192\n\tds_read_b128 %1, %4 offset:9216\n\tds_read_b128 %2, %4 offset:10240\n\tds_read_b128 %3, %4 offset:11264"
+                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
+        else
+          asm volatile("ds_read_b128 %0, %4 offset:12288\n\tds_read_b128 %1, %4 offset:13312\n\tds_read_b128 %2, %4 offset:14336\n\tds_read_b128 %3, %4 offset:15360"
+                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l3), acc[h * 4 + 3], 0, 0, 0);
+        continue;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
       if (!tune_nomfma) {
         acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
@@ -1554,15 +1663,28 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
         const size_t yoff = ((size_t)s * B + brow) * N + nb;
         if (p.y_bf16) {
           __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
-          if (vec_ok) {
-            bf16x4 o;
+          bf16x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          if (vec_ok) {
             *reinterpret_cast<bf16x4*>(yp) = o;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (nb + i < N) yp[i] = (__bf16)v[i];
+              if (nb + i < N) yp[i] = o[i];
+          }
+          if (X3) {                                  // the low plane of the split pair
+            __bf16* lp = reinterpret_cast<__bf16*>(p.y_lo) + yoff;
+            bf16x4 l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = (__bf16)(v[i] - (float)o[i]);
+            if (vec_ok) {
+              *reinterpret_cast<bf16x4*>(lp) = l;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (nb + i < N) lp[i] = l[i];
+            }
           }
         } else {
           float* yp = reinterpret_cast<float*>(p.y) + yoff;
@@ -1676,6 +1798,7 @@ constexpr size_t kL2WeightBudget = 2560 * 1024;   // of an XCD's 4 MiB L2: the (
 constexpr int kGemmPairs = BNN_GEMM_PAIRS;   // K1b2: units that share a block's parameter tiles
 constexpr int kGemmRing = BNN_GEMM_RING;     // K1b2: LDS staging buffers (k-steps of DMA run-ahead + 1); 2 x 2 is the measured
                                              // best of {2, 4} pairs x {2, 3} buffers (profiles/r03_k1b2_variants.log)
+constexpr int kGemmPairsX3 = 2;              // ... of the split-bf16 variant (48 KiB per staging buffer)
 constexpr int kGemmMinBlocks = 450;          // block-GEMM form from this many (64-feature group x sample x batch block) items
 constexpr int kSliceMaxBlocks = 2048;        // K-range slices are considered up to this many blocks (1024 are resident at once)
 constexpr long kSliceMinWeights = 250000;    // ... for layers of at least this many weights
@@ -1789,9 +1912,13 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
   }
   const long gemm_blocks = (long)((N + 63) / 64) * S * mbs;
   // (the block-GEMM kernels address with a scalar base + 32-bit lane offsets: the tensors' byte spans must fit)
-  const bool gemm_ok = al && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && K >= 8 &&
-                       (double)N * K * 4.0 < 4294967295.0 && (double)B * K * 2.0 < 4294967295.0;
-  const bool slice_ok = gemm_ok && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
+  // split-bf16 math: the block-GEMM form exists as K1b2 only (hoisted sigma, no rider, pairs of units; no K slices)
+  const bool x3 = a->math == BNN_MATH_BF16X3;
+  const bool gemm_ok = al && (a->math == BNN_MATH_BF16 || x3) && a->x_dtype == BNN_BF16 && K >= 8 &&
+                       (double)N * K * 4.0 < 4294967295.0 && (double)B * K * 2.0 < 4294967295.0 &&
+                       (!x3 || (a->w_sigma && !a->rider && (long)S * mbs >= 2 * kGemmPairsX3 && !(reinterpret_cast<uintptr_t>(a->x_lo) & 15) &&
+                                (a->y_dtype != BNN_BF16 || !(reinterpret_cast<uintptr_t>(a->y_lo) & 7))));
+  const bool slice_ok = gemm_ok && !x3 && a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
                         a->split_scratch_bytes >= bnn_bbb_split_scratch_bytes(S, B, N);
   int forced = 0;
 #ifdef BNN_TUNE
@@ -1824,11 +1951,16 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
 #ifdef BNN_TUNE
   if (const char* v = getenv("BNN_TUNE_PAIRS")) pairs_on = atoi(v) != 0;
 #endif
-  if (pairs_on && form == BNN_FORM_GEMM && a->w_sigma && !a->rider && (long)S * mbs >= 2 * kGemmPairs) {
-    pl.pairs = kGemmPairs;
-    pl.nw = 4 * kGemmPairs;
-    pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + kGemmPairs - 1) / kGemmPairs);
-    pl.lds = kGemmRing * (4 * 256 + kGemmPairs * 512) * 16 + pl.nw * 16 * sizeof(float);
+  const int pairs = x3 ? kGemmPairsX3 : kGemmPairs;
+  if (pairs_on && form == BNN_FORM_GEMM && a->w_sigma && !a->rider && (long)S * mbs >= 2 * pairs) {
+    pl.pairs = pairs;
+    pl.nw = 4 * pairs;
+    pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + pairs - 1) / pairs);
+    pl.lds = (x3 ? 2 : kGemmRing) * (4 * 256 + pairs * (x3 ? 1024 : 512)) * 16 + pl.nw * 16 * sizeof(float);
+  }
+  if (x3 && pl.pairs == 1) {                 // (the plain block-GEMM kernel has no split-bf16 variant)
+    tile_plan(S, B, K, N, al, 8, pl);
+    return BNN_OK;
   }
   return BNN_OK;
 }
@@ -1854,7 +1986,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
       return BNN_ERR_SHAPE;
     if (!aligned16(a->x) || !aligned16(a->w_sampled)) return BNN_ERR_ALIGN;
   }
-  if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u ||
+  if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 2u || (unsigned)a->eps_mode > 2u ||
       (unsigned)a->prior.kind > 1u || (unsigned)a->form > 4u)
     return BNN_ERR_ENUM;
   if (!pre && a->eps_mode == BNN_EPS_MEMORY && (!a->eps_w || !a->eps_b)) return BNN_ERR_NULL;
@@ -1864,6 +1996,21 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
     if (!aligned16(a->workspace)) return BNN_ERR_ALIGN;
   }
   if ((a->log_prior || a->log_q) && !a->want_stats) return BNN_ERR_WORKSPACE;
+  k.x_lo = nullptr; k.y_lo = nullptr;
+  if (a->math == BNN_MATH_BF16X3) {
+    // split-bf16 math: bf16 activations are pairs of planes; a forward sampling form only
+    if (pre || a->y_bf16_copy || a->rider) return BNN_ERR_ENUM;
+    if (a->x_dtype == BNN_BF16) {
+      if (!a->x_lo) return BNN_ERR_NULL;
+      if (reinterpret_cast<uintptr_t>(a->x_lo) & 1) return BNN_ERR_ALIGN;
+      k.x_lo = a->x_lo;
+    }
+    if (a->y_dtype == BNN_BF16) {
+      if (!a->y_lo) return BNN_ERR_NULL;
+      if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y_lo) & 7)) return BNN_ERR_ALIGN;
+      k.y_lo = a->y_lo;
+    }
+  }
   k.x = a->x;
   k.x_sstride = a->x_per_sample ? (long)a->batch * a->in_features : 0;
   k.xg = a->x_per_sample > 0 ? a->x_per_sample : 1;
@@ -1900,7 +2047,7 @@ static int prepare(const bnn_bbb_fwd_args* a, BbbK& k, bool& al) {
     k.inv2var1 = k.inv2var2 = k.c1 = k.c2 = 0.f;
   }
   const int K = a->in_features;
-  al = (K % 8 == 0) && aligned16(a->x) && aligned16(a->w_mu) && aligned16(a->w_rho);
+  al = (K % 8 == 0) && aligned16(a->x) && aligned16(a->w_mu) && aligned16(a->w_rho) && (!k.x_lo || aligned16(k.x_lo));
   if (pre) {
     k.w_pre = reinterpret_cast<const __bf16*>(a->w_sampled);
     k.b_pre = a->b_sampled;
@@ -2021,7 +2168,11 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
       const int ub = (int)(((long)a->n_samples * ((a->batch + 127) / 128) + pl.pairs - 1) / pl.pairs);
       k.xc = xcd2d_make((a->out_features + 63) / 64, ub, 1, (size_t)64 * K * 8, kL2WeightBudget);
       const dim3 grid2((unsigned)(((pl.blocks + 7) / 8) * 8)), block2(pl.nw * 64);
-      if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_PHILOX, kGemmRing>), grid2, block2, 0, stream, k);
+      if (math == BNN_MATH_BF16X3) {
+        if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairsX3, BNN_EPS_PHILOX, 2, true>), grid2, block2, 0, stream, k);
+        else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairsX3, BNN_EPS_MEMORY, 2, true>), grid2, block2, 0, stream, k);
+        else hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairsX3, BNN_EPS_ZERO, 2, true>), grid2, block2, 0, stream, k);
+      } else if (k.eps_mode == BNN_EPS_PHILOX) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_PHILOX, kGemmRing>), grid2, block2, 0, stream, k);
       else if (k.eps_mode == BNN_EPS_MEMORY) hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_MEMORY, kGemmRing>), grid2, block2, 0, stream, k);
       else hipLaunchKernelGGL((bbb_fwd_gemm2_kernel<4, kGemmPairs, BNN_EPS_ZERO, kGemmRing>), grid2, block2, 0, stream, k);
     } else if (ride) {
@@ -2081,6 +2232,8 @@ static int bbb_linear_fwd_impl(const bnn_bbb_fwd_args* a, void* stream_, bool no
   } while (0)
     if (math == BNN_MATH_BF16) {
       if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_BF16, BNN_F32); else BNN_GO_R(BNN_MATH_BF16, BNN_BF16);
+    } else if (math == BNN_MATH_BF16X3) {
+      if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_BF16X3, BNN_F32); else BNN_GO_R(BNN_MATH_BF16X3, BNN_BF16);
     } else {
       if (xdt == BNN_F32) BNN_GO_R(BNN_MATH_F32, BNN_F32); else BNN_GO_R(BNN_MATH_F32, BNN_BF16);
     }
@@ -2233,6 +2386,8 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   } while (0)
   if (a->math == BNN_MATH_BF16) {
     if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_BF16, BNN_F32); else BNN_FIN(BNN_MATH_BF16, BNN_BF16);
+  } else if (a->math == BNN_MATH_BF16X3) {
+    if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_BF16X3, BNN_F32); else BNN_FIN(BNN_MATH_BF16X3, BNN_BF16);
   } else {
     if (a->x_dtype == BNN_F32) BNN_FIN(BNN_MATH_F32, BNN_F32); else BNN_FIN(BNN_MATH_F32, BNN_BF16);
   }

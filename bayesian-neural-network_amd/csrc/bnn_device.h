@@ -180,32 +180,44 @@ inline Xcd2D xcd2d_make(int G, int U, int inner, size_t group_bytes, size_t l2_b
   return m;
 }
 
+// The split-bf16 pair of BNN_MATH_BF16X3 (include/bnn_hip.h): hi = bf16(v), lo = bf16(v - hi), both RNE.
+// (split_lo takes the already rounded hi: vector elements do not bind to references)
+__device__ __forceinline__ __bf16 split_lo(float v, __bf16 hi) { return (__bf16)(v - (float)hi); }
+
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
 // the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
+// dsq (optional): the squares; dlo (optional): the low plane of the split-bf16 pair.
 __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,
-                                               __bf16* __restrict__ dsq, long n, int vec_ok, long tid, long nt) {
+                                               __bf16* __restrict__ dsq, long n, int vec_ok, long tid, long nt,
+                                               __bf16* __restrict__ dlo = nullptr) {
   if (vec_ok) {
     const long n8 = n >> 3;
     for (long i = tid; i < n8; i += nt) {
       const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
       const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      bf16x8 v, q;
+      bf16x8 v, q, l;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         v[j] = (__bf16)f[j];
+        l[j] = split_lo(f[j], v[j]);
         q[j] = (__bf16)(f[j] * f[j]);
       }
       reinterpret_cast<bf16x8*>(dst)[i] = v;
       if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
+      if (dlo) reinterpret_cast<bf16x8*>(dlo)[i] = l;
     }
     for (long i = (n8 << 3) + tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
+      const __bf16 h = (__bf16)src[i], l = split_lo(src[i], h);
+      dst[i] = h;
       if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+      if (dlo) dlo[i] = l;
     }
   } else {
     for (long i = tid; i < n; i += nt) {
-      dst[i] = (__bf16)src[i];
+      const __bf16 h = (__bf16)src[i], l = split_lo(src[i], h);
+      dst[i] = h;
       if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+      if (dlo) dlo[i] = l;
     }
   }
 }

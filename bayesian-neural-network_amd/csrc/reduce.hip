@@ -247,6 +247,7 @@ struct PrepK {
   const float* cast_src;
   __bf16* cast_dst;
   __bf16* cast_dsq;
+  __bf16* cast_dlo;
   long cast_n;
   int cast_vec;
 };
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256) void eval_prepare_kernel(const PrepK p) {
     const long cnt = min((long)kPrepPerBlock, p.cast_n - lo);
     // a block-local span: the vector path needs the span's start 16-byte aligned in all three arrays (lo is a
     // multiple of 4096 elements)
-    cast_bf16_span(p.cast_src + lo, p.cast_dst + lo, p.cast_dsq ? p.cast_dsq + lo : nullptr, cnt, p.cast_vec, threadIdx.x, 256);
+    cast_bf16_span(p.cast_src + lo, p.cast_dst + lo, p.cast_dsq ? p.cast_dsq + lo : nullptr, cnt, p.cast_vec, threadIdx.x, 256,
+                   p.cast_dlo ? p.cast_dlo + lo : nullptr);
     return;
   }
   int j = 0;
@@ -692,12 +694,13 @@ extern "C" int bnn_eval_prepare(const bnn_prepare_args* a, void* stream_) {
   if (a->cast_n > 0) {
     if (!a->cast_src || !a->cast_dst) return BNN_ERR_NULL;
     if ((reinterpret_cast<uintptr_t>(a->cast_src) & 3) || (reinterpret_cast<uintptr_t>(a->cast_dst) & 1) ||
-        (reinterpret_cast<uintptr_t>(a->cast_dst_sq) & 1))
+        (reinterpret_cast<uintptr_t>(a->cast_dst_sq) & 1) || (reinterpret_cast<uintptr_t>(a->cast_dst_lo) & 1))
       return BNN_ERR_ALIGN;
     k.cast_src = a->cast_src; k.cast_dst = reinterpret_cast<__bf16*>(a->cast_dst);
     k.cast_dsq = reinterpret_cast<__bf16*>(a->cast_dst_sq); k.cast_n = (long)a->cast_n;
+    k.cast_dlo = reinterpret_cast<__bf16*>(a->cast_dst_lo);
     k.cast_vec = !((reinterpret_cast<uintptr_t>(a->cast_src) | reinterpret_cast<uintptr_t>(a->cast_dst) |
-                    reinterpret_cast<uintptr_t>(a->cast_dst_sq)) & 15);
+                    reinterpret_cast<uintptr_t>(a->cast_dst_sq) | reinterpret_cast<uintptr_t>(a->cast_dst_lo)) & 15);
     blocks += (a->cast_n + kPrepPerBlock - 1) / kPrepPerBlock;
     if (blocks > 0x3fffffff) return BNN_ERR_SHAPE;
   }

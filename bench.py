@@ -51,6 +51,7 @@ sys.path.insert(0, REPO)
 DIMS = {"mnist": (784, 1200, 10), "wide": (4096, 4096, 4096), "reg": (1, 50, 1)}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32: the fp32 vector rate (MI355X_MICROARCH.md)
 
 
 def parse_args(argv=None):
@@ -253,7 +254,7 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     import bnn_hip
     from bnn_hip import ops, _lib as L
     n = ev.n_local
-    hid_b = 4 if math_name == "f32" else 2
+    hid_b = 2 if math_name == "bf16" else 4           # (bf16x3: a bf16 activation is a pair of planes)
     l2 = net.l2
     pd = tuple(t.detach() for t in (l2.weight_mu, l2.weight_rho, l2.bias_mu, l2.bias_rho))
     xin, ws, out = ev.bufs[0], ev.ws[1], ev.bufs[1]
@@ -288,6 +289,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
         launch = lambda: ops.lr_linear_fwd(xin, *pd, **kw)
     else:
         kw = dict(prior=l2._prior_spec, want_stats=True, w_sigma=ev.wsigma[1], split_scratch=ev.split[1], **common)
+        if math_name == "bf16x3":
+            kw.update(x_lo=ev.bufs_lo[0], out_lo=ev.bufs_lo[1])
         plan = ops.bbb_plan(xin, *pd, **kw)
         launch = lambda: ops.bbb_linear_fwd(xin, *pd, **kw)
     us = kernel_alone_us(launch, torch.cuda.current_stream())
@@ -302,7 +305,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     flops = n * (4 if lr else 2) * batch * dims[1] * dims[1]
     form = {1: "tile", 2: "gemm", 3: "gemm_kslice"}[plan["form"]]
     kname = {("bbb", "tile"): "K1a bbb_fwd_kernel",
-             ("bbb", "gemm"): "K1b2 bbb_fwd_gemm2_kernel (parameters and x through LDS, 2 pairs per block)" if plan["waves"] == 8 else "K1b bbb_fwd_gemm_kernel",
+             ("bbb", "gemm"): ("K1b2 bbb_fwd_gemm2_kernel<X3> (split-bf16 operands: three bf16 MFMAs per product; parameters and the x plane pair through LDS, 2 pairs per block)"
+                               if math_name == "bf16x3" else "K1b2 bbb_fwd_gemm2_kernel (parameters and x through LDS, 2 pairs per block)") if plan["waves"] == 8 else "K1b bbb_fwd_gemm_kernel",
              ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
              ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel",
              ("lr", "gemm_kslice"): "K3s lr_fwd_kslice_kernel (32-feature groups x K slices, whole parameter lines, slices meet through a scratch)"}[("lr" if lr else "bbb", form)]
@@ -313,7 +317,16 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
             "mfma_tflops": flops / (us * 1e-6) / 1e12, "mfma_frac_of_bf16_peak": flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
             "note": "HIP events around back-to-back graph launches of this kernel alone on its stream (incl. the "
                     "dependent-launch boundary); " + note}
-    if not lr and form in ("gemm", "gemm_kslice") and math_name == "bf16":
+    roof["math"] = math_name
+    if math_name == "f32":
+        # the exact-fp32 matrix core (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate): 2 * batch flops per sampled weight
+        tf = flops / (us * 1e-6) / 1e12
+        roof["hbm_algorithmic"] = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
+        roof.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS})
+    elif math_name == "bf16x3":
+        roof["mfma_flops_issued_per_launch"] = 3 * flops            # three bf16 MFMAs per product
+        roof["mfma_issued_frac_of_bf16_peak"] = 3 * flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+    if not lr and form in ("gemm", "gemm_kslice") and math_name in ("bf16", "bf16x3"):
         roof = valu_bound(roof, dims[1], dims[1], n, batch, us, ev.wsigma[1] is not None)
     elif lr and form == "gemm" and math_name == "bf16":
         # K3b: two bf16 GEMMs (mean, variance) over parameters the launch's pairs share -- the matrix cores are its busiest
@@ -360,6 +373,8 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
     kernel's own instruction mix (profiles/isa_mix.json, tools/make_isa_mix.py): issue cycles of one k-step of one wave
     x the wave-steps of the launch, against 1024 SIMDs x 2.4 GHz; the SURVEY 8(d) HBM figure stays beside it."""
     key = "bbb_fwd_gemm2_kernel<4,2,philox>" if roof["plan"]["waves"] == 8 else f"bbb_fwd_gemm_kernel<4,{'true' if sig else 'false'},philox>"
+    if roof.get("math") == "bf16x3":
+        key = "bbb_fwd_gemm2_kernel<4,2,philox,x3>"
     hbm = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
     hbm["note"] = "SURVEY 8(d) algorithmic bytes (un-amortised: 8 B/param per (minibatch, sample) pair) over the launch time: an accounting " \
                   "convention, not the binding resource -- the pairs of a launch share (mu, sigma) through L2 (see traffic)"
@@ -596,7 +611,7 @@ def main():
         else f"MC-forward-samples/sec + KL-elements/sec, {layers} BNN",
         "value": value, "unit": "MC-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "us_per_minibatch": dt * 1e6 / (args.steps * G), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "f32": "f32", "bf16x3": "bf16x3 (split-bf16 operands, fp32-equivalent products)"}[args.math], "data": "synthetic",
         **({"rehearsal": "all ranks on cuda:0 over gloo; NOT a measurement"} if rehearsal else {}),
         "config": {"workload": f"{layers} {'LR' if lr else 'BBB'} forward-only ELBO evaluation of a stream of independent "
                                f"minibatches (3-layer forward with freshly sampled weights + log p/log q reductions over "
@@ -645,6 +660,21 @@ def main():
                            "layer2_hbm_algorithmic_frac": r2.get("hbm_algorithmic", r2)["frac"]})
                 del e2
             extras["mc_batched_one_minibatch"] = mc
+            # the headline workload in the two math modes that meet ELBO rtol 1e-4 against the reference's fp32 arithmetic at
+            # EVERY beta (plain bf16 does for beta >= 2^-6 only: DESIGN.md 2): exact-fp32 matrix core, split-bf16 operands
+            modes = {}
+            for mname in ("f32", "bf16x3"):
+                if mname == args.math:
+                    continue
+                bnn_hip.set_math(mname)
+                em, rate, us = timed_config(engine, net, x, y, 1, G, 4 * G if mname == "f32" else 8 * G)
+                rm = attach_traffic(layer2_roofline(em, net, dims, args.batch, False, mname))
+                modes[mname] = {"samples_per_s": rate, "us_per_minibatch": us, "kl_elements_per_s": rate * nst, "vs_headline": rate / value,
+                                "minibatches_per_launch_group": G, "roofline": rm}
+                out[f"{mname}_math_samples_per_s"] = rate            # (flat copies: the driver's parser keeps scalars)
+                del em
+            bnn_hip.set_math(args.math)
+            extras["math_modes"] = modes
             # C3: the local-reparameterisation variant, same workload as the headline and one evaluation at a time
             net_lr, _, _ = build_net(dims, True, args.batch, dev, mode, n_minibatches=1)
             e3, rate, us = timed_config(engine, net_lr, x, y, 1, G, max(4 * G, 1024))

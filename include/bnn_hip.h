@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 5
+#define BNN_HIP_ABI_VERSION 6
 #define BNN_EPS_MAP_VERSION 2     /* 1: Philox4x32-10 (rounds 1-2); 2: Philox4x32-7 */
 #define BNN_PHILOX_ROUNDS 7
 
@@ -70,7 +70,15 @@ enum bnn_dtype { BNN_F32 = 0, BNN_BF16 = 1 };
  * k-ordered fmaf chain) — the parity mode.  BNN_MATH_BF16: operands rounded to bf16 (RNE),
  * fp32 accumulate (v_mfma_f32_16x16x32_bf16) — the throughput mode.  Statistics (log-probs,
  * KL) are always formed in fp32 from the un-rounded fp32 weights. */
-enum bnn_math { BNN_MATH_F32 = 0, BNN_MATH_BF16 = 1 };
+enum bnn_math { BNN_MATH_F32 = 0, BNN_MATH_BF16 = 1, BNN_MATH_BF16X3 = 2 };
+/* BNN_MATH_BF16X3 (BBB forward): split-bf16 operands on the bf16 matrix core.  Every matmul operand v is carried as the pair
+ *     hi = bf16(v),   lo = bf16(v - hi)            (both round-to-nearest-even; v - hi is exact in fp32)
+ * and a product a . b is accumulated in fp32 as  a_hi b_hi + a_lo b_hi + a_hi b_lo  (three v_mfma_f32_16x16x32_bf16 per tile
+ * and k-step; the lo.lo term, 2^-16 of the product, is dropped): |a b - (...)| <= ~2^-15 |a b| per product against 2^-8 for
+ * BNN_MATH_BF16, i.e. the reference's fp32 F.linear (networks.py:88) to ~1e-5 of the output scale -- ELBO rtol 1e-4 at every
+ * beta of classification/class_task.py:70 -- at 3/16 of the matrix-core time of the exact-fp32 MFMA.  bf16 activations of
+ * this mode are PAIRS of planes: x / x_lo and y / y_lo below (fp32 activations are split in registers).  Statistics are
+ * fp32 from the un-rounded weights as in every mode. */
 
 enum bnn_eps_mode {
   BNN_EPS_PHILOX = 0,   /* generated on chip (map above); never touches HBM */
@@ -213,6 +221,9 @@ typedef struct bnn_bbb_fwd_args {
   void* w_sampled_t_out;    /* optional, with w_sampled and bf16 x: bf16 [n_samples,in,out], the same weights TRANSPOSED,
                                written by this launch.  The layer's backward (bnn_bbb_bwd_args.w_sampled_t) then computes its input
                                gradient as this same matmul-only launch instead of gathering along the reduction */
+  const void* x_lo;         /* BNN_MATH_BF16X3 with x_dtype == BNN_BF16: the low plane of x (shaped and strided like x), i.e.
+                               bf16(x_fp32 - x) as bnn_eval_prepare (cast_dst_lo) or a previous layer's y_lo left it */
+  void* y_lo;               /* BNN_MATH_BF16X3 with y_dtype == BNN_BF16: the low plane of y, bf16(y_fp32 - y) after bias / ReLU */
 } bnn_bbb_fwd_args;
 
 size_t bnn_bbb_linear_fwd_workspace_bytes(int32_t n_samples, int32_t out_features);
@@ -750,6 +761,7 @@ typedef struct bnn_prepare_args {
   void* cast_dst;                         /* bf16 */
   void* cast_dst_sq;                      /* optional bf16: src * src */
   int64_t cast_n;
+  void* cast_dst_lo;                      /* optional bf16: the low plane bf16(src - cast_dst) of BNN_MATH_BF16X3 */
 } bnn_prepare_args;
 int bnn_eval_prepare(const bnn_prepare_args* args, void* stream);
 

@@ -302,6 +302,38 @@ def network_forward_bf16(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tens
     return (x, a, None) if p.local_reparam else (x, a, b)
 
 
+def _split_bf16(t: torch.Tensor):
+    """The split pair of the device's BNN_MATH_BF16X3 mode (include/bnn_hip.h): hi = bf16(v), lo = bf16(v - hi), both RNE."""
+    hi = _bf16(t)
+    return hi, _bf16(t - hi)
+
+
+def linear_bf16x3(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """F.linear(x, w, b) (networks.py:88) with the rounding points of the split-bf16 mode: both operands as (hi, lo) pairs,
+    x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 (the lo . lo term is dropped), fp32 bias."""
+    xh, xl = _split_bf16(x)
+    wh, wl = _split_bf16(w)
+    return torch.nn.functional.linear(xh, wh) + torch.nn.functional.linear(xh, wl) + torch.nn.functional.linear(xl, wh) + b
+
+
+def network_forward_bf16x3(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tensor]):
+    """(logits, log_prior, log_q) like network_forward for a BBB network, with the rounding points of the device's
+    split-bf16 math mode and nothing else changed (statistics from the un-rounded fp32 weights)."""
+    assert not p.local_reparam, "the split-bf16 mode is a BBB forward mode (LR layers run exact fp32)"
+    if p.mode == "classification":
+        x = x.view(-1, p.input_shape)
+    a, b = 0, 0
+    for i, (wm, wr, bm, br) in enumerate(p.layers):
+        w = sample_gaussian(wm, wr, eps[2 * i])
+        bb = sample_gaussian(bm, br, eps[2 * i + 1])
+        a = a + (p.prior.log_prob(w).sum() + p.prior.log_prob(bb).sum())
+        b = b + (log_q(w, wm, wr).sum() + log_q(bb, bm, br).sum())
+        x = linear_bf16x3(x, w, bb)
+        if i < 2:
+            x = torch.relu(x)
+    return x, a, b
+
+
 def sample_elbo(p: NetParams, x: torch.Tensor, target: torch.Tensor, beta: float, samples: int,
                 sigma: float = 1.0, eps: Optional[Sequence[Sequence[torch.Tensor]]] = None,
                 gen: Optional[torch.Generator] = None):

@@ -1579,3 +1579,160 @@ def test_c5_wide_bbb_layer_batch_1024_block_form_against_oracle(dev):
         close(n_el * c0 - 0.5 * per[s, 1], float(lp), rtol=1e-5)             # Gaussian prior, sigma_p = 1 (networks.py:67-68)
         close(n_el * c0 - sls - 0.5 * per[s, 0], float(lq), rtol=1e-5)       # networks.py:46 at w = mu + sigma eps
     torch.set_num_threads(1)
+
+
+# ------------------------------------------------------------------ split-bf16 math (BNN_MATH_BF16X3)
+# The mode's promise is the reference's fp32 F.linear (networks.py:88) to ~1e-5 of the output scale: every product runs as
+# x_hi w_hi + x_hi w_lo + x_lo w_hi with (hi, lo) = (bf16(v), bf16(v - hi)), i.e. <= ~2^-15 relative per product against 2^-8
+# in plain bf16 math.  Two bounds: (i) the KERNELS against the CPU restatement with the same rounding points
+# (O.linear_bf16x3 / O.network_forward_bf16x3: fp32 accumulation order is all that differs), (ii) the MODE against the fp32
+# oracle = the reference's arithmetic -- NLL rtol 1e-4, which makes the ELBO rtol 1e-4 at every beta of class_task.py:70.
+X3_POINTS_RTOL = 2e-5          # of the output scale, kernels vs the rounding-point restatement
+X3_NLL_RTOL = 1e-4             # the north star's tolerance, against the fp32 oracle
+
+
+def _split(x):
+    hi = x.to(torch.bfloat16)
+    return hi, (x - hi.float()).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("shape", [(1200, 1200, 128, 6), (784, 1200, 128, 5), (200, 1000, 100, 9), (256, 200, 257, 3), (72, 40, 300, 5),
+                                   (33, 65, 5, 2), (1, 7, 3, 1), (1200, 10, 128, 4)])
+def test_split_bf16_layer_forms_against_the_rounding_point_oracle(dev, shape):
+    """One BayesianLinear layer in split-bf16 math through every form it has -- the tile form on fp32 activations (split in
+    registers) and on bf16 plane pairs (x / x_lo), the block-GEMM form K1b2<X3> (hoisted sigma, pairs of units) -- on
+    injected epsilon against O.linear_bf16x3 over the oracle's sampled weights, against the fp32 F.linear of networks.py:88,
+    the statistics against the fp32 oracle; the bf16 output planes (y / y_lo) must be the split of the fp32 output."""
+    K, N, B, S = shape
+    gen = torch.Generator(device="cpu").manual_seed(K * 17 + N + S)
+    x = torch.rand(S, B, K, generator=gen)
+    wm = ((torch.rand((N, K), generator=gen) - 0.5) * 0.4)
+    wr = (torch.rand((N, K), generator=gen) - 5.0)
+    bm = ((torch.rand(N, generator=gen) - 0.5) * 0.4)
+    br = (torch.rand(N, generator=gen) - 5.0)
+    ew, eb = torch.randn(S, N, K, generator=gen), torch.randn(S, N, generator=gen)
+    prior = O.Prior.from_init([0.9], False)
+    want3, want32, lp, lq = [], [], [], []
+    for s in range(S):
+        w, b = O.sample_gaussian(wm, wr, ew[s]), O.sample_gaussian(bm, br, eb[s])
+        want3.append(torch.relu(O.linear_bf16x3(x[s], w, b)))
+        want32.append(torch.relu(torch.nn.functional.linear(x[s], w, b)))
+        lp.append(float(prior.log_prob(w).sum() + prior.log_prob(b).sum()))
+        lq.append(float(O.log_q(w, wm, wr).sum() + O.log_q(b, bm, br).sum()))
+    want3, want32 = torch.stack(want3).numpy(), torch.stack(want32).numpy()
+    scale = float(np.abs(want32).max()) + 1e-6
+    assert np.abs(want3 - want32).max() <= 4e-5 * scale                # the restatement itself: the mode's arithmetic
+    d = lambda a: a.to(dev)
+    xd, (xh, xl) = d(x), _split(d(x))
+    kw = dict(n_samples=S, prior=ops.PriorSpec(False, 0.9), math_mode=L.MATH_BF16X3, relu=True, eps_mode=L.EPS_MEMORY, eps_w=d(ew),
+              eps_b=d(eb), want_stats=True, want_scalars=True)
+    sig = ops.softplus(d(wr))
+    runs = [("tile/f32 x", xd, dict(form=L.FORM_TILE)), ("tile/plane pair", xh, dict(form=L.FORM_TILE, x_lo=xl))]
+    if K % 8 == 0 and K >= 8:
+        runs.append(("block GEMM", xh, dict(form=L.FORM_GEMM, x_lo=xl, w_sigma=sig)))
+    for name, xin, extra in runs:
+        for y_dtype in (torch.float32, torch.bfloat16):
+            plan = ops.bbb_plan(xin, d(wm), d(wr), d(bm), d(br), y_dtype=y_dtype, **kw, **extra)
+            if name == "block GEMM" and S * ((B + 127) // 128) >= 4:
+                assert plan["form"] == L.FORM_GEMM and plan["waves"] == 8 and plan["lds_bytes"] == 2 * (4 * 256 + 2 * 1024) * 16 + 8 * 64, plan
+            else:
+                assert plan["form"] == L.FORM_TILE, (name, plan)
+            out = ops.bbb_linear_fwd(xin, d(wm), d(wr), d(bm), d(br), y_dtype=y_dtype, **kw, **extra)
+            if y_dtype == torch.float32:
+                y = out["y"].cpu().numpy()
+                assert out["y_lo"] is None
+            else:
+                y = (out["y"].float() + out["y_lo"].float()).cpu().numpy()
+                hi = torch.from_numpy(want3).to(torch.bfloat16)
+                # the hi plane is the RNE rounding of the fp32 output (ulp flips where the device's sum rounds the other way)
+                assert float((out["y"].float().cpu() - hi.float()).abs().max()) <= 2.0 ** -7 * scale, name
+            assert np.abs(y - want3).max() <= (X3_POINTS_RTOL if y_dtype == torch.float32 else 2e-5 + 2.0 ** -16) * scale, (name, y_dtype, np.abs(y - want3).max() / scale)
+            assert np.abs(y - want32).max() <= 6e-5 * scale, (name, y_dtype)
+            close(out["log_prior"], lp, rtol=2e-5)
+            close(out["log_q"], lq, rtol=2e-5)
+
+
+X3_SHAPES = [(1, 1, None), (1, 8, None), (4, 2, None), (20, 1, None), (256, 1, (0, 1, 17, 63, 64, 127, 128, 200, 254, 255))]
+
+
+@pytest.mark.parametrize("G,S,pairs", X3_SHAPES)
+def test_split_bf16_timed_path_meets_the_fp32_tolerance_at_every_beta(dev, G, S, pairs):
+    """The path bench.py times (engine.GraphedElbo, captured, on-chip Philox, G stacked minibatches x S samples per launch
+    group) in split-bf16 math against the FP32 oracle (O.network_forward = the reference's arithmetic) on the same epsilon,
+    per (minibatch, sample) pair: NLL rtol 1e-4, hence the ELBO rtol 1e-4 at beta = 0.5, 2^-10 and 0 (class_task.py:70) --
+    what plain bf16 math meets only for the first ~6 minibatches of an epoch; statistics rtol 1e-5; and against the CPU
+    restatement with the mode's rounding points 2e-5."""
+    from bnn_hip import engine
+    B, dims, seed, first, E = 128, (784, 1200, 10), 434343, 9000, 2
+    bnn_hip.set_math("bf16x3")
+    net, sd = build_net(dev, False, dims, "classification")
+    p = O.NetParams.from_state_dict(sd, "classification", dims[0], False, O.Prior.from_init([1.0], False))
+    xs, ys = zip(*[synth.synth_batch("classification", B, dims[0], dims[2], seed=100 + m) for m in range(G)])
+    xd = torch.from_numpy(np.stack(xs)).to(dev)
+    yd = torch.from_numpy(np.stack(ys)).to(dev)
+    bnn_hip.manual_seed(seed, counter=first)
+    ev = engine.GraphedElbo(net, xd if G > 1 else xd[0], yd if G > 1 else yd[0], S, stacked=G > 1, evals_per_replay=E)
+    assert ev.x3 and all((b is not None) == (i < 2) for i, b in enumerate(ev.bufs_lo))
+    sums = ev.replay().clone().view(G, 4).double().cpu().numpy()
+    torch.cuda.synchronize()
+    total = G * S
+    assert int(ev.counter.item()) == first + total * (1 + E)
+    base = first + total * E
+    idx = np.arange(total) if pairs is None else np.asarray(pairs)
+    want, want_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx)
+    w3, w3_logits = [], []
+    torch.set_num_threads(8)
+    for f in idx:
+        m, j = divmod(int(f), S)
+        out, a, b = O.network_forward_bf16x3(p, t(xs[m]), O.philox_eps_for_network(p, B, seed, base + m * S + j))
+        w3.append(float(O.nll(out, t(ys[m]), p.mode)))
+        w3_logits.append(out.numpy())
+    torch.set_num_threads(1)
+    w3, w3_logits = np.asarray(w3), np.stack(w3_logits)
+    for c, k in enumerate(("log_prior", "log_q")):
+        close(ev.out[k].double().cpu().numpy()[idx], want[:, c], rtol=1e-5)
+    got_nll = ev.out["nll"].double().cpu().numpy()[idx]
+    lg = ev.logits.double().cpu().numpy().reshape(total, B, dims[2])[idx]
+    nll_err = np.abs(got_nll - want[:, 2]) / np.abs(want[:, 2])
+    lg_err = np.abs(lg - want_logits).max() / np.abs(want_logits).max()
+    nll3_err = np.abs(got_nll - w3) / np.abs(w3)
+    lg3_err = np.abs(lg - w3_logits).max() / np.abs(w3_logits).max()
+    print(f"\n[bf16x3 at C2] G={G} S={S}: vs fp32 oracle nll {nll_err.max():.2e} logits {lg_err:.2e} of scale; "
+          f"vs rounding-point restatement nll {nll3_err.max():.2e} logits {lg3_err:.2e}")
+    assert nll_err.max() <= X3_NLL_RTOL and lg_err <= 1e-4
+    assert nll3_err.max() <= 2e-5 and lg3_err <= 3e-5
+    assert (sums[:, 3] == S).all()
+    full_eval = [m for m in range(G) if all((m * S + j) in set(idx.tolist()) for j in range(S))]
+    pos = {int(f): i for i, f in enumerate(idx.tolist())}
+    assert full_eval
+    for m in full_eval:
+        e32 = want[[pos[m * S + j] for j in range(S)]].sum(0)
+        close(sums[m, 0], e32[0], rtol=1e-5)
+        close(sums[m, 1], e32[1], rtol=1e-5)
+        close(sums[m, 2], e32[2], rtol=X3_NLL_RTOL)
+        for beta in BETAS:
+            close(_elbo(sums[m, :3], S, beta, False), _elbo(e32, S, beta, False), rtol=1e-4)      # EVERY beta, against fp32
+
+
+def test_split_bf16_math_through_the_drop_in_module(dev):
+    """set_math('bf16x3') through the nn.Module surface: sample_elbo (4-tuple, injected epsilon, differentiable) equals the
+    exact-fp32 mode to the mode's tolerance, gradients included (the backward kernels run the exact-fp32 matrix core), and a
+    local-reparameterisation network runs the mode as exact fp32 (same results as set_math('f32'))."""
+    B, dims, S = 64, (40, 72, 5), 2
+    outs = {}
+    for lr in (False, True):
+        for mode in ("f32", "bf16x3"):
+            bnn_hip.set_math(mode)
+            net, sd = build_net(dev, lr, dims, "classification", B=B)
+            install_eps(net, B, S, lr)
+            x, y = synth.synth_batch("classification", B, dims[0], dims[2], seed=3)
+            res = (net.sample_elbo_lr if lr else net.sample_elbo)(t(x).to(dev), t(y).to(dev), 0.25, S)
+            res[0].backward()
+            outs[(lr, mode)] = ([r.detach().double().cpu().numpy() for r in res],
+                                [p.grad.detach().double().cpu().numpy() for p in net.parameters()])
+    for lr in (False, True):
+        (r32, g32), (r3, g3) = outs[(lr, "f32")], outs[(lr, "bf16x3")]
+        for a, b in zip(r3, r32):
+            close(a, b, rtol=0.0 if lr else 1e-4)
+        for a, b in zip(g3, g32):
+            assert np.abs(a - b).max() <= (0.0 if lr else 2e-4) * (np.abs(b).max() + 1e-12)

@@ -319,10 +319,12 @@ def test_launch_plans_are_a_function_of_the_shape():
     lib = L.load()
     P = 0x10000                                             # any 16-byte aligned non-null address: plans never dereference
 
-    def bbb(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, scratch=False):
+    def bbb(S, B, K, N, math=L.MATH_BF16, xdt=L.BF16, form=0, scratch=False, sigma=False, ydt=L.F32):
+        x3 = math == L.MATH_BF16X3
         a = _plan_args(L.BbbFwdArgs, n_samples=S, batch=B, in_features=K, out_features=N, x=P, x_dtype=xdt, w_mu=P, w_rho=P,
-                       b_mu=P, b_rho=P, math=math, y=P, form=form, split_scratch=P if scratch else None,
-                       split_scratch_bytes=lib.bnn_bbb_split_scratch_bytes(S, B, N) if scratch else 0)
+                       b_mu=P, b_rho=P, math=math, y=P, y_dtype=ydt, form=form, split_scratch=P if scratch else None,
+                       split_scratch_bytes=lib.bnn_bbb_split_scratch_bytes(S, B, N) if scratch else 0,
+                       w_sigma=P if sigma else None, x_lo=P if (x3 and xdt == L.BF16) else None, y_lo=P if (x3 and ydt == L.BF16) else None)
         a.prior.sigma_p = 1.0
         pl = L.Plan()
         assert lib.bnn_bbb_plan(C.byref(a), C.byref(pl)) == 0
@@ -358,6 +360,22 @@ def test_launch_plans_are_a_function_of_the_shape():
     pl = bbb(256, 128, 1200, 1200)
     assert (pl.form, pl.waves, pl.blocks, pl.features_per_block) == (L.FORM_GEMM, 4, 19 * 256, 64)
     assert bbb(256, 128, 1200, 1200, math=L.MATH_F32, xdt=L.F32).form == L.FORM_TILE      # fp32 math has no GEMM form
+    # the headline launch: hoisted sigma -> K1b2, two pairs per 8-wave block, 64.5 KiB of LDS (two blocks per CU)
+    pl = bbb(256, 128, 1200, 1200, sigma=True)
+    assert (pl.form, pl.waves, pl.blocks, pl.lds_bytes) == (L.FORM_GEMM, 8, 19 * 128, 2 * (4 * 256 + 2 * 512) * 16 + 512)
+    # split-bf16 math: the same form over (hi, lo) plane pairs, 48 KiB per staging buffer; no K-sliced form, and without the
+    # hoisted sigma (or on fp32 x: split in registers) the tile form
+    pl = bbb(256, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, ydt=L.BF16)
+    assert (pl.form, pl.waves, pl.blocks, pl.lds_bytes) == (L.FORM_GEMM, 8, 19 * 128, 2 * (4 * 256 + 2 * 1024) * 16 + 512)
+    assert bbb(256, 128, 1200, 1200, math=L.MATH_BF16X3).form == L.FORM_TILE
+    assert bbb(256, 128, 784, 1200, math=L.MATH_BF16X3, sigma=True, xdt=L.F32).form == L.FORM_TILE
+    assert bbb(8, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, scratch=True).form == L.FORM_TILE
+    assert bbb(4, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, form=L.FORM_GEMM).form == L.FORM_GEMM
+    assert bbb(3, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, form=L.FORM_GEMM).form == L.FORM_TILE     # fewer than two blocks' worth of pairs
+    a = _plan_args(L.BbbFwdArgs, n_samples=8, batch=128, in_features=1200, out_features=1200, x=P, x_dtype=L.BF16, w_mu=P, w_rho=P, b_mu=P,
+                   b_rho=P, math=L.MATH_BF16X3, y=P)
+    a.prior.sigma_p = 1.0
+    assert lib.bnn_bbb_plan(C.byref(a), C.byref(L.Plan())) == -1           # BNN_ERR_NULL: bf16 x in this mode is a plane PAIR
     # C5's per-GPU share: K-sliced GEMM for the 16.8 M-weight layer when a scratch is there, the tile form without
     pl = bbb(4, 128, 4096, 4096, scratch=True)
     assert pl.form == L.FORM_GEMM_KSLICE and pl.k_slices >= 2 and pl.blocks == 64 * 4 * pl.k_slices
@@ -407,7 +425,8 @@ def test_launch_plans_are_a_function_of_the_shape():
         for B in (1, 16, 100, 128, 300):
             for K in (1, 8, 50, 784, 1200, 4096):
                 for N in (1, 10, 50, 1200, 4096):
-                    for pl in (bbb(S, B, K, N), lr(S, B, K, N), bbb(S, B, K, N, math=L.MATH_F32, xdt=L.F32)):
+                    for pl in (bbb(S, B, K, N), lr(S, B, K, N), bbb(S, B, K, N, math=L.MATH_F32, xdt=L.F32),
+                               bbb(S, B, K, N, math=L.MATH_BF16X3, sigma=True, ydt=L.BF16)):
                         assert 1 <= pl.waves <= 16 and pl.lds_bytes <= 160 * 1024 and pl.blocks >= 1
                         assert pl.form in (L.FORM_TILE, L.FORM_GEMM, L.FORM_GEMM_KSLICE)
                         assert pl.k_classes in (1, 2, 4) and pl.batch_rows in (32, 128)

@@ -26,7 +26,8 @@ from isa_loop_mix import classify                       # noqa: E402
 
 CSRC = os.path.join(REPO, "bayesian-neural-network_amd", "csrc")
 KERNELS = {   # key -> (source file, mangled-name substring, family of bench.KERNEL_SOURCES)
-    "bbb_fwd_gemm2_kernel<4,2,philox>": ("bbb_linear.hip", "bbb_fwd_gemm2_kernelILi4ELi2ELi0", "bbb"),
+    "bbb_fwd_gemm2_kernel<4,2,philox>": ("bbb_linear.hip", "bbb_fwd_gemm2_kernelILi4ELi2ELi0ELi2ELb0E", "bbb"),
+    "bbb_fwd_gemm2_kernel<4,2,philox,x3>": ("bbb_linear.hip", "bbb_fwd_gemm2_kernelILi4ELi2ELi0ELi2ELb1E", "bbb"),
     "bbb_fwd_gemm_kernel<4,true,philox>": ("bbb_linear.hip", "bbb_fwd_gemm_kernelILi4ELb1ELi0", "bbb"),
     "bbb_fwd_gemm_kernel<4,false,philox>": ("bbb_linear.hip", "bbb_fwd_gemm_kernelILi4ELb0ELi0", "bbb"),
     "lr_fwd_gemm_kernel<16,true,2>": ("lr_linear.hip", "lr_fwd_gemm_kernelILi16ELb1ELi2", "lr"),
