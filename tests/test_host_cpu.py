@@ -474,17 +474,44 @@ def test_bench_roofline_bookkeeping_without_a_device(tmp_path, monkeypatch):
         assert got["traffic"] == want and ("traffic_note" in got) == (want is None)
 
 
-def test_kernels_with_hand_issued_loads_do_not_spill(tmp_path):
+def test_kernels_with_hand_issued_loads_keep_their_registers(tmp_path):
     """The block-GEMM / K-sliced kernels issue some of their loads in inline assembly and wait for them by hand (the
-    compiler's own wait-count bookkeeping drains the prefetch: DESIGN 4).  A register whose hand-issued load is still in
-    flight must never be spilled and handed to another value -- an address, in the case that faulted -- so these kernels
-    must compile without scratch.  Compiles the two sources to gfx950 assembly (no GPU needed) and reads the metadata."""
+    compiler's own wait-count bookkeeping drains the prefetch: DESIGN 4).  The compiler does not know that the destination
+    of such a load is busy until the wait: it may spill it (the round-3 memory fault: an address register overwritten by a
+    late-landing load) or hand it to another value on a path that does not run through the wait statement.  Two checks
+    over the gfx950 assembly of both sources (compiled here, no GPU needed):
+      (1) tools/lint_hand_loads.py -- the invariant itself: between a hand-issued load with VGPR destinations and the
+          s_waitcnt that retires it, no instruction reads or writes those registers (scratch traffic included), in EVERY
+          kernel, K3b's 16-wave form (which carries 16 bytes of scratch for values of its epilogue) included;
+      (2) the kernels whose hand-issued loads stay in flight across whole loop iterations compile without scratch."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import lint_hand_loads as lint
+    # the lint detects what it is for: a touch of an in-flight destination, a spill of one, a counted wait that does not
+    # reach the load yet -- and accepts the same code with the wait in place
+    bad = tmp_path / "bad.s"
+    bad.write_text("""_ZN3bnn4testEv:
+\t;;#ASMSTART
+\tds_read_b128 v[4:7], v1
+\tds_read_b128 v[8:11], v1 offset:1024
+\t;;#ASMEND
+\tv_add_f32_e32 v20, v21, v22
+\ts_waitcnt lgkmcnt(1)
+\tv_mov_b32_e32 v30, v5
+\tv_mov_b32_e32 v31, v9
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[12:15], v[2:3], off sc1
+\t;;#ASMEND
+\tscratch_store_dword off, v13, s0
+\ts_waitcnt vmcnt(0) lgkmcnt(0)
+\tv_mov_b32_e32 v32, v12
+\ts_endpgm
+""")
+    v, seen = lint.check(str(bad))
+    assert [(x[1], x[5]) for x in v] == [(9, ["v9"]), (13, ["v13"])] and seen == {"_ZN3bnn4testEv": 3}, v
     csrc = os.path.join(REPO, "bayesian-neural-network_amd", "csrc")
-    # (K3b, lr_fwd_gemm_kernel, is not in the list: what it reads by hand are LDS fragments waited for inside the same
-    # straight-line group of MFMAs; its 16-wave form has carried 16 bytes of scratch since round 2)
     watched = ("bbb_fwd_gemm_kernel", "bbb_fwd_gemm2_kernel", "bbb_fwd_gemm_rider_kernel", "bbb_block_gemm_kernel",
                "lr_fwd_kslice_kernel")
     seen = set()
@@ -494,8 +521,12 @@ def test_kernels_with_hand_issued_loads_do_not_spill(tmp_path):
         procs.append((out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-S",
                                              "--offload-device-only", os.path.join(csrc, src), "-o", str(out)],
                                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    hand_kernels = {}
     for out, pr in procs:
         assert pr.wait() == 0
+        violations, hand = lint.check(str(out))
+        assert not violations, violations[:5]
+        hand_kernels.update(hand)
         name = None
         for line in open(out):
             m = re.match(r"^(_ZN3bnn\S+):", line)
@@ -509,3 +540,7 @@ def test_kernels_with_hand_issued_loads_do_not_spill(tmp_path):
                     assert int(m.group(1)) == 0, (name, int(m.group(1)))
                 name = None
     assert seen == set(watched), seen
+    # the lint saw the kernels it is meant for (their hand-issued loads carry register destinations)
+    # (K1g's hand-issued loads are all LDS-DMA -- no register destination --, its LDS reads are the compiler's)
+    for w in ("bbb_fwd_gemm_kernel", "bbb_fwd_gemm2_kernel", "bbb_fwd_gemm_rider_kernel", "lr_fwd_kslice_kernel", "lr_fwd_gemm_kernel"):
+        assert any(re.search(r"\d+" + w + r"I", k) for k in hand_kernels), w
