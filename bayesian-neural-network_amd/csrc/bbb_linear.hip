@@ -1325,9 +1325,14 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 // X3 (BNN_MATH_BF16X3): split-bf16 operands.  x arrives as two planes (hi, lo): a pair's tile of a k-step is 16 KiB
 // ([hi | lo][8 batch tiles][64 lanes] x 16 B), the sampled weight fragment is split in registers (wa = bf16(w), wl =
 // bf16(w - wa)), and every (batch tile, k-step) takes three MFMAs: wa . xh + wl . xh + wa . xl.  The staging buffers then
-// hold 48 KiB each (96 KiB per block: one 8-wave block per CU, two waves per SIMD, up to 256 VGPRs).
+// would hold 48 KiB each -- 96 KiB per block, one 8-wave block per CU, two waves per SIMD: measured 636 us per 256-pair
+// launch of the 1200 x 1200 layer against the bf16 form's 322 (both forms' steps take ~4000 cycles per WAVE: what a launch
+// delivers is waves per SIMD over that latency).  So the X3 form keeps its PARAMETERS IN ONE BUFFER (PS): a step reads its
+// (mu, sigma) fragments into registers first, the block meets (a second, cheap barrier right behind the step's start), and
+// only then are the next step's parameter pieces requested into the same 16 KiB; x stays double-buffered, the bias goes
+// through lane shuffles instead of LDS: 16 + 2 x 32 KiB = 80 KiB, two blocks per CU, four waves per SIMD like the bf16 form.
 template <int NF, int SB, int EPS, int NB = 2, bool X3 = false>
-__global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
+__global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
   constexpr int NW = NF * SB;
   static_assert(NB == 2 || NB == 3, "staging buffers (NB - 1 k-steps of DMA run-ahead)");
   constexpr int WPW = 4 / SB;                 // parameter pieces (of a tile's four) each of the SB waves of a tile brings
@@ -1335,11 +1340,16 @@ __global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel
   constexpr int XT = X3 ? 1024 : 512;         // float4s of one pair's x tile (X3: the hi plane's 8 pieces, then the lo plane's)
   static_assert(SB == 1 || SB == 2 || SB == 4, "pairs per block");
   static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
-  static_assert(!X3 || NB == 2, "split-bf16 form: two staging buffers");
+  static_assert(!X3 || NB == 2, "split-bf16 form: two x buffers");
+  constexpr bool PS = X3;                     // parameters single-buffered (see above)
+  constexpr int BUF = NF * 256 + SB * XT;     // float4s of one staging buffer of the double-buffered-everything layout
+  // LDS image, in float4s.  !PS: [buffer][NF tiles' parameter pieces | SB pairs' x tiles], then the bias table.
+  //                          PS: [parameter pieces][x buffer 0][x buffer 1].
+  auto p_idx = [](int buf) { return PS ? 0 : buf * BUF; };
+  auto x_idx = [](int buf) { return PS ? NF * 256 + buf * (SB * XT) : buf * BUF + NF * 256; };
   // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
-  __shared__ __attribute__((aligned(16))) float4 sm_all[NB * (NF * 256 + SB * XT) + NW * 4];
-  float4 (*sm)[NF * 256 + SB * XT] = reinterpret_cast<float4 (*)[NF * 256 + SB * XT]>(sm_all);
-  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + NB * (NF * 256 + SB * XT));
+  __shared__ __attribute__((aligned(16))) float4 sm_all[PS ? NF * 256 + 2 * SB * XT : NB * BUF + NW * 4];
+  float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + (PS ? 0 : NB * BUF));          // (!PS only)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the staging bases below live in SGPRs)
   const int fw = wave % NF, sb = wave / NF;
   const int r = lane & 15, q = lane >> 4;
@@ -1385,62 +1395,72 @@ __global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel
   uint32_t voff_x[XPW];
 #pragma unroll
   for (int i = 0; i < XPW; ++i) voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[0][0];
-  constexpr uint32_t kBufBytes = (NF * 256 + SB * XT) * 16;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm_all[0];
   // (the plan takes this form only where the tensors' byte spans fit 32 bits)
-  auto stage_fast = [&](int t, int buf) __attribute__((always_inline)) {
+  // WP / WX (compile-time): stage the parameter pieces / the x pieces of step t (the PS form requests them at different points
+  // of a step, into different buffer indices)
+  auto stage_fast = [&](int t, int pbuf, int xbuf, auto wp_, auto wx_) __attribute__((always_inline)) {
+    if (decltype(wp_)::value) {
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-      const int j = sb * WPW + i;                               // wave-uniform
-      const char* base = reinterpret_cast<const char*>((j & 2) ? p.w_sigma : p.w_mu) + (size_t)t * 128 + (j & 1) * 16;
-      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((fw * 4 + j) * 64 * 16);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_w), "s"(base), "s"(m0v) : "memory", "m0");
+      for (int i = 0; i < WPW; ++i) {
+        const int j = sb * WPW + i;                               // wave-uniform
+        const char* base = reinterpret_cast<const char*>((j & 2) ? p.w_sigma : p.w_mu) + (size_t)t * 128 + (j & 1) * 16;
+        const uint32_t m0v = lds0 + (uint32_t)((p_idx(pbuf) + (fw * 4 + j) * 64) * 16);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_w), "s"(base), "s"(m0v) : "memory", "m0");
+      }
     }
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-      const char* base = reinterpret_cast<const char*>(xs) + (size_t)t * 64;
-      const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + sb * XT + (fw + i * NF) * 64) * 16);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
-    }
-    if (X3) {
+    if (decltype(wx_)::value) {
 #pragma unroll
       for (int i = 0; i < XPW; ++i) {
-        const char* base = reinterpret_cast<const char*>(xs_lo) + (size_t)t * 64;
-        const uint32_t m0v = lds0 + (uint32_t)buf * kBufBytes + (uint32_t)((NF * 256 + sb * XT + 512 + (fw + i * NF) * 64) * 16);
+        const char* base = reinterpret_cast<const char*>(xs) + (size_t)t * 64;
+        const uint32_t m0v = lds0 + (uint32_t)((x_idx(xbuf) + sb * XT + (fw + i * NF) * 64) * 16);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
       }
-    }
-  };
-  auto stage_slow = [&](int t, int buf) __attribute__((always_inline)) {
-    const int kk = min(t * 32 + q * 8, K - 8);
+      if (X3) {
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-#ifdef BNN_TUNE
-      const int j = ((p.tune & 64) ? (SB - 1 - sb) : sb) * WPW + i;
-#else
-      const int j = sb * WPW + i;                               // wave-uniform
-#endif
-      const float* src = ((j & 2) ? p.w_sigma : p.w_mu) + wrow + kk + (j & 1) * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)&sm[buf][(fw * 4 + j) * 64], 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
-                                       (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + sb * XT + (fw + i * NF) * 64], 16, 0, 0);
-    }
-    if (X3) {
-#pragma unroll
-      for (int i = 0; i < XPW; ++i) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_lo + xrow[i] + kk),
-                                         (__attribute__((address_space(3))) void*)&sm[buf][NF * 256 + sb * XT + 512 + (fw + i * NF) * 64], 16, 0, 0);
+        for (int i = 0; i < XPW; ++i) {
+          const char* base = reinterpret_cast<const char*>(xs_lo) + (size_t)t * 64;
+          const uint32_t m0v = lds0 + (uint32_t)((x_idx(xbuf) + sb * XT + 512 + (fw + i * NF) * 64) * 16);
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
+        }
       }
     }
   };
-  auto stage = [&](int t, int buf) __attribute__((always_inline)) {
-    if ((t + 1) * 32 <= K) stage_fast(t, buf);                   // block-uniform
-    else stage_slow(t, buf);                                      // the K tail inside a k-step: clamped per-lane addresses
+  auto stage_slow = [&](int t, int pbuf, int xbuf, auto wp_, auto wx_) __attribute__((always_inline)) {
+    const int kk = min(t * 32 + q * 8, K - 8);
+    if (decltype(wp_)::value) {
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+#ifdef BNN_TUNE
+        const int j = ((p.tune & 64) ? (SB - 1 - sb) : sb) * WPW + i;
+#else
+        const int j = sb * WPW + i;                               // wave-uniform
+#endif
+        const float* src = ((j & 2) ? p.w_sigma : p.w_mu) + wrow + kk + (j & 1) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)&sm_all[p_idx(pbuf) + (fw * 4 + j) * 64], 16, 0, 0);
+      }
+    }
+    if (decltype(wx_)::value) {
+#pragma unroll
+      for (int i = 0; i < XPW; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
+                                         (__attribute__((address_space(3))) void*)&sm_all[x_idx(xbuf) + sb * XT + (fw + i * NF) * 64], 16, 0, 0);
+      }
+      if (X3) {
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_lo + xrow[i] + kk),
+                                           (__attribute__((address_space(3))) void*)&sm_all[x_idx(xbuf) + sb * XT + 512 + (fw + i * NF) * 64], 16, 0, 0);
+        }
+      }
+    }
   };
+  auto stage_sel = [&](int t, int pbuf, int xbuf, auto wp_, auto wx_) __attribute__((always_inline)) {
+    if ((t + 1) * 32 <= K) stage_fast(t, pbuf, xbuf, wp_, wx_);   // block-uniform
+    else stage_slow(t, pbuf, xbuf, wp_, wx_);                      // the K tail inside a k-step: clamped per-lane addresses
+  };
+  auto stage = [&](int t, int buf) __attribute__((always_inline)) { stage_sel(t, buf, buf, std::true_type{}, std::true_type{}); };
 
   // bias of this wave's tile: eps now, applied in the epilogue
   float bmu_pre = 0.f, brho_pre = 0.f, beps_pre = 0.f;
@@ -1480,20 +1500,35 @@ __global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel
 #ifdef BNN_TUNE
     // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 0 = no barrier, 1 = no waits, 3 = no DMA (the LDS
     // reads of the parameters stay: stale bytes, the same vector work), 4 = no x reads, 5 = no MFMAs
-    if (staged && !(p.tune & 8)) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+    if (staged && !(p.tune & 8)) {
+      if (PS) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});
+      else stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+    }
 #else
-    if (staged) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+    if (staged) {
+      if (PS) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});      // x of step t + 1 now, its parameters below
+      else stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+    }
 #endif
     // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
     // flight that may alias it -- s_waitcnt vmcnt(0) right behind the prefetch this step has just issued -- although
     // buffer t & 1 was complete at the last barrier.  The "+v" operands of the wait tie the consumers to it; the outputs
     // are early-clobber: a result register must not be the address register of a later read of the same statement.
-    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm[cur][0];
-    const uint32_t pa = lbase + (uint32_t)((fw * 256 + lane) * 16);
+    const uint32_t pa = lds0 + (uint32_t)((p_idx(cur) + fw * 256 + lane) * 16);
     f32x4 m_lo, m_hi, g_lo, g_hi;
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
                  : "=&v"(m_lo), "=&v"(m_hi), "=&v"(g_lo), "=&v"(g_hi) : "v"(pa));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m_lo), "+v"(m_hi), "+v"(g_lo), "+v"(g_hi));
+    if (PS) {
+      // every wave of the block holds its (mu, sigma) fragments in registers: the one parameter buffer is free for step t + 1
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef BNN_TUNE
+      if (staged && !(p.tune & 8)) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+#else
+      if (staged) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+#endif
+    }
     const f32x2 mu2[4] = {{m_lo[0], m_lo[1]}, {m_lo[2], m_lo[3]}, {m_hi[0], m_hi[1]}, {m_hi[2], m_hi[3]}};
     const f32x2 sg2[4] = {{g_lo[0], g_lo[1]}, {g_lo[2], g_lo[3]}, {g_hi[0], g_hi[1]}, {g_hi[2], g_hi[3]}};
     float e[8];
@@ -1542,16 +1577,29 @@ __global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel
       s_ls += lane_ok ? ls : 0.f;
     }
     bf16x8 wa, wl;
+    if (X3) {
+      // the split pair, two weights per instruction where the ISA has one: hi = cvt_pk(w0, w1); its two floats by a shift and
+      // a mask of the packed word; the exact differences; lo = cvt_pk(d0, d1): 6 vector instructions per two weights
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      uint32_t hw[4], lw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wa[2 * j] = lane_ok ? (__bf16)w2[j][0] : (__bf16)0.f;
-      wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
-      if (X3) {                                   // the low part of the split pair: bf16(w - bf16(w)), exact difference
-        wl[2 * j] = lane_ok ? (__bf16)(w2[j][0] - (float)wa[2 * j]) : (__bf16)0.f;
-        wl[2 * j + 1] = lane_ok ? (__bf16)(w2[j][1] - (float)wa[2 * j + 1]) : (__bf16)0.f;
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 wv = lane_ok ? w2[j] : f32x2{0.f, 0.f};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(wv, bf16x2));
+        const f32x2 hf = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+        hw[j] = hb;
+        lw[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(wv - hf, bf16x2));
+      }
+      wa = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+      wl = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wa[2 * j] = lane_ok ? (__bf16)w2[j][0] : (__bf16)0.f;
+        wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
       }
     }
-    const uint32_t xa = lbase + (uint32_t)((NF * 256 + sb * XT + q * 16 + r) * 16);
+    const uint32_t xa = lds0 + (uint32_t)((x_idx(cur) + sb * XT + q * 16 + r) * 16);
 #ifdef BNN_TUNE
     const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
 #else
@@ -1632,22 +1680,29 @@ __global__ __launch_bounds__(NF * SB * 64, X3 ? 2 : 4) void bbb_fwd_gemm2_kernel
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
+  float b_own = 0.f;                                           // lanes 0 .. 15 (q == 0): the sampled bias of feature r
   if (q == 0) {
-    float b = 0.f;
-    if (n_ok) b = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
-    bias_s[wave][r] = b;
+    if (n_ok) b_own = sample_bias(p, bmu_pre, brho_pre, beps_pre, do_stats, do_ls, s_e2, s_a, s_ls);
+    if (!PS) bias_s[wave][r] = b_own;
   }
   if (do_stats) {
     const float a = wave_sum(s_e2), b = wave_sum(s_a), cc = wave_sum(s_ls);
     if (lane == 0 && tile < T) p.ws[1 + (size_t)s * T + tile] = make_float4(a, b, cc, 0.f);
   }
-  __syncthreads();
+  float bq[4];
+  if (PS) {                                                    // the PS form has no LDS left for a bias table: lane shuffles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = __shfl(b_own, q * 4 + i, 64);
+  } else {
+    __syncthreads();
+  }
   if (!active) return;
   const int nb = tile * 16 + q * 4;
   const bool vec_ok = (N & 3) == 0;
-  float bq[4];
+  if (!PS) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+    for (int i = 0; i < 4; ++i) bq[i] = bias_s[wave][q * 4 + i];
+  }
   if (nb < N) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -1956,7 +2011,8 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
     pl.pairs = pairs;
     pl.nw = 4 * pairs;
     pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + pairs - 1) / pairs);
-    pl.lds = (x3 ? 2 : kGemmRing) * (4 * 256 + pairs * (x3 ? 1024 : 512)) * 16 + pl.nw * 16 * sizeof(float);
+    // (split-bf16 form: one parameter buffer + two x buffers of a (hi, lo) plane pair per unit, no bias table)
+    pl.lds = x3 ? (4 * 256 + 2 * pairs * 1024) * 16 : kGemmRing * (4 * 256 + pairs * 512) * 16 + pl.nw * 16 * sizeof(float);
   }
   if (x3 && pl.pairs == 1) {                 // (the plain block-GEMM kernel has no split-bf16 variant)
     tile_plan(S, B, K, N, al, 8, pl);

@@ -366,7 +366,7 @@ def test_launch_plans_are_a_function_of_the_shape():
     # split-bf16 math: the same form over (hi, lo) plane pairs, 48 KiB per staging buffer; no K-sliced form, and without the
     # hoisted sigma (or on fp32 x: split in registers) the tile form
     pl = bbb(256, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, ydt=L.BF16)
-    assert (pl.form, pl.waves, pl.blocks, pl.lds_bytes) == (L.FORM_GEMM, 8, 19 * 128, 2 * (4 * 256 + 2 * 1024) * 16 + 512)
+    assert (pl.form, pl.waves, pl.blocks, pl.lds_bytes) == (L.FORM_GEMM, 8, 19 * 128, (4 * 256 + 2 * 2 * 1024) * 16)
     assert bbb(256, 128, 1200, 1200, math=L.MATH_BF16X3).form == L.FORM_TILE
     assert bbb(256, 128, 784, 1200, math=L.MATH_BF16X3, sigma=True, xdt=L.F32).form == L.FORM_TILE
     assert bbb(8, 128, 1200, 1200, math=L.MATH_BF16X3, sigma=True, scratch=True).form == L.FORM_TILE
