@@ -139,6 +139,19 @@ def bbb_linear(x: torch.Tensor, w_mu: torch.Tensor, w_rho: torch.Tensor, b_mu: t
     return y, lp, lq
 
 
+def bbb_linear_bf16(x: torch.Tensor, w_mu: torch.Tensor, w_rho: torch.Tensor, b_mu: torch.Tensor,
+                    b_rho: torch.Tensor, eps_w: torch.Tensor, eps_b: torch.Tensor, prior: Prior):
+    """bbb_linear with the device's bf16 rounding points and nothing else changed: the matmul operands (x, the sampled w)
+    rounded to bf16 (RNE), fp32 accumulation, fp32 bias, the statistics from the un-rounded fp32 weights -- what the bf16
+    kernels of a layer are pinned against (their own fp32 summation order is all that differs)."""
+    w = sample_gaussian(w_mu, w_rho, eps_w)
+    b = sample_gaussian(b_mu, b_rho, eps_b)
+    lp = prior.log_prob(w).sum() + prior.log_prob(b).sum()
+    lq = log_q(w, w_mu, w_rho).sum() + log_q(b, b_mu, b_rho).sum()
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    return torch.nn.functional.linear(rnd(x), rnd(w), b), lp, lq
+
+
 # --------------------------------------------------------------------------------------
 # a7: BayesianLinearLR.forward + compute_kl_cost (networks.py:109-138)
 # --------------------------------------------------------------------------------------
