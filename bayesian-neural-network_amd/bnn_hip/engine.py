@@ -61,6 +61,7 @@ def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
 # >= 512 batch rows): 2 * batch flops per sampled weight make the matrix cores the bound, and the fused kernels would
 # redo the sampling for every 128-row batch block
 BLOCK_GEMM_MIN_BATCH = 512
+SAMPLE_BESIDE_MATMUL = True     # GraphedElbo: those layers' sampling launches on a side stream, beside the earlier layers' matmuls
 
 
 def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:
@@ -593,6 +594,10 @@ class GraphedElbo:
                 self.w_pre[i] = torch.empty((S, n_i, k_i), dtype=torch.bfloat16, device=dev)
                 self.b_pre[i] = torch.empty((S, n_i), dtype=torch.float32, device=dev)
                 self.ws[i] = ops.sample_workspace(S, k_i, n_i, dev)
+        # large-batch layers (K1s + K1g): the sampling launches depend on no activation -- they run on a SIDE stream beside the
+        # matmuls of the layers before them (vector / memory work next to matrix-core work on the same CUs: layer l's K1g
+        # waits for layer l's K1s only), forked and joined inside the evaluation so that a captured graph keeps the edges
+        self.side = torch.cuda.Stream(device=dev) if (SAMPLE_BESIDE_MATMUL and sum(self.lib) >= 1 and not self.lr) else None
         self.graph = None
         if capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
@@ -622,6 +627,16 @@ class GraphedElbo:
                 h, h_sq, h_lo = self.x16, self.x16_sq, self.x16_lo
         last = len(self.specs) - 1
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
+        sampled = {}                                     # layer -> event: its K1s launch (side stream) has been enqueued
+        if self.side is not None:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)                  # fork: behind everything this stream has enqueued (the last finalize)
+            with torch.cuda.stream(self.side):
+                for i, sp in enumerate(self.specs):
+                    if self.lib[i]:
+                        self._sample_layer(i, grp)
+                        sampled[i] = torch.cuda.Event()
+                        sampled[i].record(self.side)
         fin_kw = dict(layer_in=[sp.in_out[0] for sp in self.specs], layer_out=[sp.in_out[1] for sp in self.specs],
                       local_reparam=self.lr, prior=self.specs[0].m._prior_spec, n_samples=self.n_local,
                       target=self.target, mode=self.net.mode, nll_sigma=self.sigma, sample_counter=self.counter,
@@ -629,6 +644,9 @@ class GraphedElbo:
                       ticket=self.ticket, scratch=self.scratch, group_samples=self.group)
         for i, sp in enumerate(self.specs):
             p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+            if i == last and self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)      # join: ahead of the launch that finalizes (it advances
+                                                                        # the sample counter the sampling launches read)
             common = dict(n_samples=self.n_local, math_mode=math_mode, relu=sp.relu, y_dtype=self.bufs[i].dtype,
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i], form=state.form, **grp)
@@ -646,9 +664,10 @@ class GraphedElbo:
                                   rider=self.lr_rider if i == last - 1 else None, **common)
                 h_sq = self.bufs_sq[i]
             elif self.lib[i]:
-                ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,
-                                             workspace=self.ws[i], w_out=self.lib_w[i], b_out=self.lib_b[i])],
-                                       n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
+                if i in sampled:
+                    torch.cuda.current_stream().wait_event(sampled[i])
+                else:
+                    self._sample_layer(i, grp)
                 ops.bbb_sampled_matmul(h, self.lib_w[i], self.lib_b[i], n_samples=self.n_local, relu=sp.relu,
                                        y_dtype=self.bufs[i].dtype, out=self.bufs[i])
                 if i == last:
@@ -680,6 +699,14 @@ class GraphedElbo:
             h, h_lo = self.bufs[i], self.bufs_lo[i]
         if self.lr:
             ops.elbo_finalize(workspaces=self.ws, logits=h, **fin_kw)
+
+    def _sample_layer(self, i, grp):
+        """K1s of layer i into its static buffers (on the current stream)."""
+        sp = self.specs[i]
+        p = tuple(t.detach() for t in (sp.m.weight_mu, sp.m.weight_rho, sp.m.bias_mu, sp.m.bias_rho))
+        ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,
+                                     workspace=self.ws[i], w_out=self.lib_w[i], b_out=self.lib_b[i])],
+                               n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
 
     def _eager(self):
         for _ in range(self.per_replay):

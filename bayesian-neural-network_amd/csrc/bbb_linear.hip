@@ -501,8 +501,7 @@ __device__ __forceinline__ bool bbb_fwd_body(const BbbK& p, const FinPack* fp) {
       }
     } else if (p.eps_mode == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-      philox_normal4(g, gs, wid, p.k0, p.k1, e);
-      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+      philox_normal8(g, gs, wid, p.k0, p.k1, e);
     } else if (p.eps_mode == BNN_EPS_MEMORY) {
       load8<ALIGNED>(p.eps_w + ((size_t)s * N + n) * K + k, valid, e);
     } else {
@@ -1104,8 +1103,7 @@ __device__ __forceinline__ void bbb_gemm_body(const BbbK& p, float4 (*xt)[8 * 64
     float e[8], w[8];
     if (EPS == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-      philox_normal4(g, gs, wid, p.k0, p.k1, e);
-      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+      philox_normal8(g, gs, wid, p.k0, p.k1, e);
     } else if (EPS == BNN_EPS_MEMORY) {
       load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
     } else {
@@ -1331,8 +1329,14 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 // (mu, sigma) fragments into registers first, the block meets (a second, cheap barrier right behind the step's start), and
 // only then are the next step's parameter pieces requested into the same 16 KiB; x stays double-buffered, the bias goes
 // through lane shuffles instead of LDS: 16 + 2 x 32 KiB = 80 KiB, two blocks per CU, four waves per SIMD like the bf16 form.
+#ifndef BNN_K1B2_PS
+#define BNN_K1B2_PS 0       // build knob: the bf16 form with single-buffered parameters too (48 KiB: three blocks per CU)
+#endif
+#ifndef BNN_K1B2_WPS
+#define BNN_K1B2_WPS 4      // build knob: waves per SIMD the register allocation aims at
+#endif
 template <int NF, int SB, int EPS, int NB = 2, bool X3 = false>
-__global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const BbbK p) {
+__global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd_gemm2_kernel(const BbbK p) {
   constexpr int NW = NF * SB;
   static_assert(NB == 2 || NB == 3, "staging buffers (NB - 1 k-steps of DMA run-ahead)");
   constexpr int WPW = 4 / SB;                 // parameter pieces (of a tile's four) each of the SB waves of a tile brings
@@ -1341,7 +1345,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
   static_assert(SB == 1 || SB == 2 || SB == 4, "pairs per block");
   static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
   static_assert(!X3 || NB == 2, "split-bf16 form: two x buffers");
-  constexpr bool PS = X3;                     // parameters single-buffered (see above)
+  constexpr bool PS = X3 || (BNN_K1B2_PS && NB == 2);   // parameters single-buffered (see above)
   constexpr int BUF = NF * 256 + SB * XT;     // float4s of one staging buffer of the double-buffered-everything layout
   // LDS image, in float4s.  !PS: [buffer][NF tiles' parameter pieces | SB pairs' x tiles], then the bias table.
   //                          PS: [parameter pieces][x buffer 0][x buffer 1].
@@ -1534,8 +1538,7 @@ __global__ __launch_bounds__(NF * SB * 64, 4) void bbb_fwd_gemm2_kernel(const Bb
     float e[8];
     if (EPS == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-      philox_normal4(g, gs, wid, p.k0, p.k1, e);
-      philox_normal4(g + 1u, gs, wid, p.k0, p.k1, e + 4);
+      philox_normal8(g, gs, wid, p.k0, p.k1, e);
     } else if (EPS == BNN_EPS_MEMORY) {
       load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
     } else {

@@ -57,6 +57,44 @@ __device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample,
   box_muller(r.z, r.w, out[2], out[3]);
 }
 
+// Two consecutive epsilon groups (`group`, `group + 1`: the 8 weights a lane of the block forms holds per k-step) with
+// the two Philox calls in LOCK-STEP.  A call is a chain of ROUNDS dependent (multiply -> xor -> xor -> multiply ...) rounds
+// with two independent multiplies each; written one call after the other the compiler keeps them apart (the k-step's
+// critical path is then 2 x ROUNDS rounds deep, and three or four waves per SIMD do not cover it: the counters show the
+// waves issue-stalled a third of the time).  Interleaved round by round the chain is ROUNDS deep with four independent
+// multiplies per level.  Same arithmetic, same bits.
+template <int ROUNDS = BNN_PHILOX_ROUNDS>
+__device__ __forceinline__ void philox_normal8(uint32_t group, uint32_t gsample, uint32_t tensor_id, uint32_t k0, uint32_t k1,
+                                               float out[8]) {
+#ifdef BNN_PHILOX_SEQ       // A/B build knob (tools/): the two calls one after the other, as rounds 1-3 wrote them
+  philox_normal4(group, gsample, tensor_id, k0, k1, out);
+  philox_normal4(group + 1u, gsample, tensor_id, k0, k1, out + 4);
+  return;
+#endif
+  uint4 a = make_uint4(group, gsample, tensor_id, 0u), b = make_uint4(group + 1u, gsample, tensor_id, 0u);
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const uint64_t pa0 = (uint64_t)a.x * 0xD2511F53u, pb0 = (uint64_t)b.x * 0xD2511F53u;
+    const uint64_t pa1 = (uint64_t)a.z * 0xCD9E8D57u, pb1 = (uint64_t)b.z * 0xCD9E8D57u;
+    a = make_uint4((uint32_t)(pa1 >> 32) ^ a.y ^ k0, (uint32_t)pa1, (uint32_t)(pa0 >> 32) ^ a.w ^ k1, (uint32_t)pa0);
+    b = make_uint4((uint32_t)(pb1 >> 32) ^ b.y ^ k0, (uint32_t)pb1, (uint32_t)(pb0 >> 32) ^ b.w ^ k1, (uint32_t)pb0);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  // four Box-Muller pairs, level by level: the uniforms, the four logarithms, the four square roots, the sines / cosines
+  const float u[8] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z), u01(b.w)};
+  float rad[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rad[j] = -2.0f * kLn2 * __builtin_amdgcn_logf(u[2 * j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rad[j] = __builtin_amdgcn_sqrtf(rad[j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = rad[j] * __builtin_amdgcn_cosf(u[2 * j + 1]);
+    out[2 * j + 1] = rad[j] * __builtin_amdgcn_sinf(u[2 * j + 1]);
+  }
+}
+
 // ---------------------------------------------------------------------------- math
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }

@@ -1501,6 +1501,22 @@ def test_large_batch_layers_take_the_block_gemm(dev, monkeypatch):
             close(tup[1] * S, float(sums[0]), rtol=1e-6)
             close(tup[2] * S, float(sums[1]), rtol=1e-6)
             close(tup[3] * S, float(sums[2]), rtol=1e-5)
+    # the sampling launches run on a side stream beside the matmuls (forked and joined inside the captured evaluation): the
+    # same evaluation with everything on one stream gives the same bits, replay after replay
+    monkeypatch.setattr(bnn_hip.runtime.state, "form", L.FORM_AUTO)
+    monkeypatch.setattr(engine, "SAMPLE_BESIDE_MATMUL", False)
+    bnn_hip.manual_seed(4, counter=10)
+    ev1 = engine.GraphedElbo(net, xd, yd, S)
+    assert ev1.side is None and all(ev1.lib)
+    monkeypatch.setattr(engine, "SAMPLE_BESIDE_MATMUL", True)
+    bnn_hip.manual_seed(4, counter=10)
+    ev2 = engine.GraphedElbo(net, xd, yd, S, evals_per_replay=2)
+    assert ev2.side is not None
+    for rep_ in range(3):
+        a = ev1.replay().clone(); ev1.replay()                   # two evaluations per step on either side
+        b = ev2.replay().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ev1.logits, ev2.logits) and torch.equal(ev1.sums, ev2.sums), rep_
     (s1, o1, lg1), (s2, o2, lg2) = res
     close(o1["log_prior"], o2["log_prior"].cpu().numpy(), rtol=2e-6)
     close(o1["log_q"], o2["log_q"].cpu().numpy(), rtol=2e-6)
