@@ -18,7 +18,7 @@ NLL_REGRESSION, NLL_CLASSIFICATION = 0, 1
 FORM_AUTO, FORM_TILE, FORM_GEMM, FORM_GEMM_KSLICE, FORM_BLOCK256 = 0, 1, 2, 3, 4
 
 EXPORTS = (
-    "bnn_version", "bnn_status_string",
+    "bnn_version", "bnn_philox_rounds", "bnn_status_string",
     "bnn_bbb_linear_fwd_workspace_bytes", "bnn_bbb_split_scratch_bytes", "bnn_bbb_split_scratch_zero_bytes", "bnn_bbb_linear_fwd",
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
@@ -220,6 +220,7 @@ def load():
     if missing:
         raise BnnHipError(f"libbnn_hip.so lacks symbols declared in include/bnn_hip.h: {missing}")
     lib.bnn_version.restype = C.c_int
+    lib.bnn_philox_rounds.restype = C.c_int
     lib.bnn_status_string.restype = C.c_char_p
     lib.bnn_status_string.argtypes = [C.c_int]
     lib.bnn_bbb_linear_fwd_workspace_bytes.restype = C.c_size_t

@@ -61,7 +61,12 @@ def final_rows_ok(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
 # >= 512 batch rows): 2 * batch flops per sampled weight make the matrix cores the bound, and the fused kernels would
 # redo the sampling for every 128-row batch block
 BLOCK_GEMM_MIN_BATCH = 512
-SAMPLE_BESIDE_MATMUL = True     # GraphedElbo: those layers' sampling launches on a side stream, beside the earlier layers' matmuls
+# GraphedElbo: those layers' sampling launches on a side stream, beside the earlier layers' matmuls.  Measured and left OFF
+# (tools/side_stream_ab.py, profiles/r04_side_stream_ab.log: 580 against 573 us per 4-sample evaluation at batch 1024, 1640
+# against 1617 at batch 4096): a K1g block takes 2 x 216 of a SIMD's 512 registers and 128 KiB of LDS, so a sampling block
+# only ever runs where a matmul block has not started yet -- the launches take turns on a CU instead of sharing it, and the
+# cross-stream edges cost more than the little that overlaps.  The bits are the same either way (tests).
+SAMPLE_BESIDE_MATMUL = False
 
 
 def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:

@@ -861,8 +861,10 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
       const uint32_t tk = __hip_atomic_fetch_add(p.ks_ticket + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last_s = ((tk & 0xffffu) == (uint32_t)KSL - 1u) ? 1u : 0u;
       if (spread) {
-        // arrivals in the low half of the word, departures in the high half; the poll is bounded (a launch that could not
-        // make progress ends with wrong numbers, not with a hung device)
+        // arrivals in the low half of the word, departures in the high half; the poll is bounded: a launch whose unit's
+        // blocks are not all resident (CUs held by another stream's kernels) must not hang the device -- it ends, and the
+        // block that gave up POISONS its share of the outputs (NaN: the evaluation's NLL and ELBO show it) instead of
+        // building them from incomplete partial tiles
         uint32_t seen = tk + 1u;
         for (int it = 0; (seen & 0xffffu) < (uint32_t)KSL && it < (1 << 22); ++it) {
           __builtin_amdgcn_s_sleep(4);
@@ -871,8 +873,8 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
         const uint32_t dp = __hip_atomic_fetch_add(p.ks_ticket + unit, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((dp >> 16) == (uint32_t)KSL - 1u)                  // the last to leave puts the word back to zero
           __hip_atomic_store(p.ks_ticket + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = 1u;                                           // every block of the unit runs its share of the epilogues
-      }
+        last_s = ((seen & 0xffffu) < (uint32_t)KSL) ? 2u : 1u;   // every block of the unit runs its share of the epilogues
+      }                                                        // (2: the poll timed out)
     }
     __syncthreads();
     LR_STAMP(5);
@@ -902,6 +904,11 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) sum[m] += part[sl][m];
       }
+    if (last_s == 2u) {                                        // block-uniform: a slice never arrived
+      const float nan = __builtin_nanf("");
+#pragma unroll
+      for (int m = 0; m < 4; ++m) sum[m] = f32x4{nan, nan, nan, nan};
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m >> 1][m & 1] = sum[m];
   } else if (p.eps_mode == BNN_EPS_PHILOX) {

@@ -711,6 +711,7 @@ extern "C" int bnn_eval_prepare(const bnn_prepare_args* a, void* stream_) {
 }
 
 extern "C" int bnn_version(void) { return BNN_HIP_ABI_VERSION; }
+extern "C" int bnn_philox_rounds(void) { return BNN_PHILOX_ROUNDS; }
 
 extern "C" const char* bnn_status_string(int status) {
   switch (status) {

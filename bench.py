@@ -649,6 +649,15 @@ def main():
             out["single_evaluation_us"] = us                        # (flat copies: the driver's parser keeps scalars)
             out["single_evaluation_samples_per_s"] = rate
             del e1
+            # the same chain with 8 evaluations per hipGraph replay: every evaluation still waits for the previous one (one
+            # stream, dependent launches), the ~8 us between two replays of a graph is paid once per eight
+            e1b = make_evaluator(engine, net, x, y, 1, 1, per_replay=8)
+            g_, full_, _, warm_ = plan_groups(100, 10, 1)
+            dt8 = run_groups(e1b, full_, warm_, None)
+            out["single_evaluation_in_flight"]["eight_per_replay"] = {"us_per_evaluation": dt8 * 1e6 / (full_ * 8), "samples_per_s": full_ * 8 / dt8,
+                                                                      "note": "8 dependent evaluations per graph replay (fresh epsilon each): the replay gap amortised"}
+            out["single_evaluation_us_8_per_replay"] = dt8 * 1e6 / (full_ * 8)
+            del e1b
             # MC-batched evaluations of ONE minibatch (C4's per-GPU share is 8 samples; 64 = C4 on one GPU)
             mc = []
             for (S, steps) in ((8, 200), (64, 60), (256, 24)):
@@ -673,8 +682,30 @@ def main():
                                 "minibatches_per_launch_group": G, "roofline": rm}
                 out[f"{mname}_math_samples_per_s"] = rate            # (flat copies: the driver's parser keeps scalars)
                 del em
+            # ... and the local-reparameterisation network in exact-fp32 math (what set_math('bf16x3') runs an LR network as)
+            bnn_hip.set_math("f32")
+            net_lr32, _, _ = build_net(dims, True, args.batch, dev, mode, n_minibatches=1)
+            em, rate, us = timed_config(engine, net_lr32, x, y, 1, G, 4 * G)
+            modes["lr_f32"] = {"samples_per_s": rate, "us_per_minibatch": us, "minibatches_per_launch_group": G,
+                               "roofline": layer2_roofline(em, net_lr32, dims, args.batch, True, "f32")}
+            del em, net_lr32
             bnn_hip.set_math(args.math)
             extras["math_modes"] = modes
+            # the headline with rocRAND's generator (Philox4x32-10, epsilon map version 1): a second library built with
+            # PHILOX_ROUNDS=10 (csrc/Makefile: make rounds10), run in a child process through BNN_HIP_LIB
+            r10 = os.path.join(REPO, "bayesian-neural-network_amd", "bnn_hip", "libbnn_hip_r10.so")
+            if os.path.exists(r10) and not os.environ.get("BNN_HIP_LIB"):
+                try:
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(args.steps),
+                                         "--warmup", str(args.warmup), "--group", str(G), "--batch", str(args.batch)],
+                                        env=dict(os.environ, BNN_HIP_LIB=r10), capture_output=True, text=True, timeout=300)
+                    d10 = json.loads(cp.stdout.strip().splitlines()[-1])
+                    extras["philox_10_rounds"] = {"samples_per_s": d10["value"], "vs_headline": d10["value"] / value, "ms_per_step": d10["ms_per_step"],
+                                                  "layer2_us_per_launch": d10["roofline"]["avg_launch_us"],
+                                                  "note": "the same workload on libbnn_hip_r10.so (BNN_PHILOX_ROUNDS = 10: rocRAND's PHILOX4_32_10)"}
+                    out["philox_10_rounds_samples_per_s"] = d10["value"]
+                except Exception as e:      # a diagnostic figure: never fails the bench
+                    extras["philox_10_rounds"] = {"error": repr(e)[:200]}
             # C3: the local-reparameterisation variant, same workload as the headline and one evaluation at a time
             net_lr, _, _ = build_net(dims, True, args.batch, dev, mode, n_minibatches=1)
             e3, rate, us = timed_config(engine, net_lr, x, y, 1, G, max(4 * G, 1024))
@@ -720,6 +751,14 @@ def main():
                        "us_per_evaluation": us,
                        "collective": "one RCCL all-reduce of the 4-vector per evaluation, awaited before the next" if world > 1 else "none (1 GPU)"})
             del e6
+            if world > 1:
+                # the same with the collective OVERLAPPED -- evaluation i + 1 is launched while the all-reduce
+                # of evaluation i is in flight (two slab slots; nobody waits for an ELBO before starting the next evaluation)
+                e6, rate, us = timed_config(engine, net, x, y, S_tot, 1, 200 if S_tot == 64 else 40, dist, every_eval=False)
+                c4.append({"mc_samples_per_evaluation": S_tot, "mc_samples_per_gpu": S_tot // world, "samples_per_s": rate,
+                           "us_per_evaluation": us, "collective": "one RCCL all-reduce of the 4-vector per evaluation, asynchronous: "
+                                                                  "the next evaluation is launched behind it (pipelined)"})
+                del e6
         extras["c4"] = c4
         if rank == 0:
             out["extras"] = extras

@@ -52,7 +52,9 @@ extern "C" {
 
 #define BNN_HIP_ABI_VERSION 6
 #define BNN_EPS_MAP_VERSION 2     /* 1: Philox4x32-10 (rounds 1-2); 2: Philox4x32-7 */
-#define BNN_PHILOX_ROUNDS 7
+#ifndef BNN_PHILOX_ROUNDS          /* build-time choice (csrc/Makefile: make PHILOX_ROUNDS=10): 7 = map version 2 (the product), */
+#define BNN_PHILOX_ROUNDS 7        /* 10 = rocRAND's PHILOX4_32_10 / map version 1.  bnn_philox_rounds() tells what a library runs */
+#endif
 
 enum bnn_status {
   BNN_OK = 0,
@@ -766,6 +768,7 @@ typedef struct bnn_prepare_args {
 int bnn_eval_prepare(const bnn_prepare_args* args, void* stream);
 
 int bnn_version(void);                    /* BNN_HIP_ABI_VERSION the library was built with */
+int bnn_philox_rounds(void);              /* BNN_PHILOX_ROUNDS the library was built with (7, or 10 for rocRAND's generator) */
 const char* bnn_status_string(int status); /* static string for a negative status */
 
 #ifdef __cplusplus

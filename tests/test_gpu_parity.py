@@ -1490,6 +1490,7 @@ def test_large_batch_layers_take_the_block_gemm(dev, monkeypatch):
     for form in (L.FORM_AUTO, L.FORM_TILE):
         monkeypatch.setattr(bnn_hip.runtime.state, "form", form)
         bnn_hip.manual_seed(4, counter=10)
+        monkeypatch.setattr(engine, "SAMPLE_BESIDE_MATMUL", True)   # (the side-stream form of the sampling launches: checked below)
         ev = engine.GraphedElbo(net, xd, yd, S)
         assert all(ev.lib) == (form == L.FORM_AUTO)
         sums = ev.replay().clone()

@@ -241,7 +241,8 @@ BENCH_WORKER = textwrap.dedent(r'''
             return self.sums
 
     for (steps, warmup, group, every) in ((120, 24, 16, False), (46, 10, 8, False), (9, 3, 4, False), (20, 5, 256, False),
-                                          (12, 4, 1, True)):
+                                          (12, 4, 1, True), (12, 4, 1, False)):     # the last: C4 pipelined (one minibatch per
+                                                                                    # evaluation, its all-reduce behind the next launch)
         G, full, rem, warm = bench.plan_groups(steps, warmup, group)
         main, tail = FakeEvaluator(G), (FakeEvaluator(rem) if rem else None)
         dt = bench.run_groups(main, full, warm, tail, dist, every)

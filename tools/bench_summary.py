@@ -4,7 +4,7 @@ d = json.load(open(sys.argv[1]))
 r = d["roofline"]
 print("value %.0f samples/s  %.2f us/step | roof %s %.1f us frac %s" % (d["value"], d["ms_per_step"] * 1e3, r["kernel"], r["avg_launch_us"], r["frac"]))
 for k, m in d.get("extras", {}).get("math_modes", {}).items():
-    print("  math %s: %.0f samples/s (%.2f of the headline), layer2 %.1f us [%s] frac %s" % (k, m["samples_per_s"], m["vs_headline"], m["roofline"]["avg_launch_us"], m["roofline"]["bound"], m["roofline"]["frac"]))
+    print("  math %s: %.0f samples/s (%.2f of the headline), layer2 %.1f us [%s] frac %s" % (k, m["samples_per_s"], m.get("vs_headline", float("nan")), m["roofline"]["avg_launch_us"], m["roofline"]["bound"], m["roofline"]["frac"]))
 if "single_evaluation_in_flight" in d:
     s = d["single_evaluation_in_flight"]; print("single eval %.1f us, layer2 %.1f us" % (s["us_per_evaluation"], s["layer2"]["avg_launch_us"]))
 e = d.get("extras", {})
