@@ -23,7 +23,7 @@ EXPORTS = (
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_stage_inputs_cast", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_split_scratch_bytes", "bnn_lr_split_scratch_zero_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_split_scratch_bytes", "bnn_lr_split_scratch_zero_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare", "bnn_lr_prepare_x3_bytes", "bnn_lr_prepare_x3",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
@@ -104,6 +104,7 @@ class LrFwdArgs(C.Structure):
         ("x_sq", C.c_void_p), ("y_sq", C.c_void_p), ("w_frag", C.c_void_p), ("v_out", C.c_void_p),
         ("hfac_out", C.c_void_p), ("y_bf16_copy", C.c_void_p),
         ("rider", C.POINTER(LrRider)), ("split_scratch", C.c_void_p), ("split_scratch_bytes", C.c_size_t),
+        ("x_lo", C.c_void_p), ("y_lo", C.c_void_p),
     ]
 
 
@@ -275,9 +276,11 @@ def load():
     lib.bnn_lr_linear_fwd.argtypes = [C.POINTER(LrFwdArgs), C.c_void_p]
     lib.bnn_lr_prepare_bytes.restype = C.c_size_t
     lib.bnn_lr_prepare_bytes.argtypes = [C.c_int32, C.c_int32]
-    lib.bnn_lr_prepare.restype = C.c_int
-    lib.bnn_lr_prepare.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                                     C.c_void_p]
+    lib.bnn_lr_prepare_x3_bytes.restype = C.c_size_t
+    lib.bnn_lr_prepare_x3_bytes.argtypes = [C.c_int32, C.c_int32]
+    for fn in (lib.bnn_lr_prepare, lib.bnn_lr_prepare_x3):
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.bnn_gauss_kl_workspace_bytes.restype = C.c_size_t
     lib.bnn_gauss_kl_workspace_bytes.argtypes = [C.c_int64]
     lib.bnn_gauss_kl.restype = C.c_int

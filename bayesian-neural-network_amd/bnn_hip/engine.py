@@ -520,16 +520,24 @@ class GraphedElbo:
         self.counter = torch.tensor([first], dtype=torch.int32, device=dev)
         S = self.n_local
         B = self.x.shape[-2]
-        math_mode = self.math = effective_math(self.lr)
+        # split-bf16 math on a local-reparameterisation network: a stream of stacked minibatches whose hidden layers all take the
+        # block form over prepared fragments (K3b<X3>) runs them in that mode -- the layer below the output layer hands it fp32
+        # activations and the narrow output layer runs exact fp32; any other LR evaluation runs exact fp32 throughout
+        self.lr_x3 = (self.lr and state.math == L.MATH_BF16X3 and self.G > 1 and len(self.specs) >= 2 and S >= LR_SQUARES_MIN_SAMPLES and
+                      self.x.dtype == torch.float32 and
+                      all(sp.in_out[0] % 8 == 0 and lr_use_prepare(sp.in_out[1], S, B) for sp in self.specs[:-1]))
+        math_mode = self.math = L.MATH_BF16X3 if self.lr_x3 else effective_math(self.lr)
         self.x3 = math_mode == L.MATH_BF16X3
         hid = torch.float32 if math_mode == L.MATH_F32 else torch.bfloat16
         self.bufs, self.ws, self.bufs_lo = [], [], []
+        nl_ = len(self.specs)
         for i, sp in enumerate(self.specs):
             fin, fout = sp.in_out
-            last = i == len(self.specs) - 1
-            self.bufs.append(torch.empty((S, B, fout), dtype=torch.float32 if last else hid, device=dev))
+            last = i == nl_ - 1
+            f32_out = last or (self.lr_x3 and i == nl_ - 2)
+            self.bufs.append(torch.empty((S, B, fout), dtype=torch.float32 if f32_out else hid, device=dev))
             # split-bf16 math: the low plane of every bf16 activation
-            self.bufs_lo.append(torch.empty((S, B, fout), dtype=torch.bfloat16, device=dev) if (self.x3 and not last) else None)
+            self.bufs_lo.append(torch.empty((S, B, fout), dtype=torch.bfloat16, device=dev) if (self.x3 and not f32_out) else None)
             self.ws.append(ops.lr_workspace(fout, dev) if self.lr else ops.bbb_workspace(S, fout, dev))
         keys = ("kl",) if self.lr else ("log_prior", "log_q")
         self.out = {k: torch.zeros(S, dtype=torch.float32, device=dev) for k in keys + ("nll",)}
@@ -559,8 +567,8 @@ class GraphedElbo:
         self.x16_lo = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if (self.x3 and self.x16 is not None) else None
         self.lr_sq = self.lr and (self.x16 is not None or (k3s_first and hid == torch.bfloat16)) and S >= LR_SQUARES_MIN_SAMPLES
         self.x16_sq = torch.empty(self.x.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and self.x16 is not None) else None
-        self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev) if (self.lr_sq and i < len(self.bufs) - 1)
-                        else None for i, b in enumerate(self.bufs)]
+        self.bufs_sq = [torch.empty(b.shape, dtype=torch.bfloat16, device=dev)
+                        if (self.lr_sq and i < len(self.bufs) - 1 and b.dtype == torch.bfloat16) else None for i, b in enumerate(self.bufs)]
         self.split = [ops.split_scratch(S, B, sp.in_out[1], dev)
                       if (not self.lr and hid == torch.bfloat16 and not self.lib[i] and
                           use_split(sp.in_out[0], sp.in_out[1], S, B)) else None
@@ -576,8 +584,9 @@ class GraphedElbo:
                       for sp, lb in zip(self.specs, self.lib)]
         self.wfrag = [None] * len(self.specs)
         if self.lr_sq:
-            self.wfrag = [torch.empty(L.load().bnn_lr_prepare_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
-                          if (lr_use_prepare(sp.in_out[1], S, B) and not (shared0 and i == 0)) else None
+            frag_bytes = L.load().bnn_lr_prepare_x3_bytes if self.lr_x3 else L.load().bnn_lr_prepare_bytes
+            self.wfrag = [torch.empty(frag_bytes(*sp.in_out) // 4, dtype=torch.float32, device=dev)
+                          if (lr_use_prepare(sp.in_out[1], S, B) and not (shared0 and i == 0) and not (self.lr_x3 and i == nl_ - 1)) else None
                           for i, sp in enumerate(self.specs)]
         # LR, few samples: the narrow output layer's operands are prepared by a rider of the previous layer's launch
         # (bnn_lr_rider), so that the row-split final launch (K3r) parks nothing
@@ -656,8 +665,10 @@ class GraphedElbo:
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i], form=state.form, **grp)
             if self.lr:
+                if self.lr_x3 and i == last:
+                    common["math_mode"] = L.MATH_F32          # the narrow output layer: exact fp32 on the fp32 activations
                 if self.wfrag[i] is not None:
-                    ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i])
+                    ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i], x3=self.lr_x3)
                 if i == last and self.scratch is not None and not wide_nll(self.specs, self.x.shape[-2]):
                     # output layer + finalize in one launch when the library's row-split form applies (else it issues both)
                     ops.lr_final_fwd((h,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
@@ -666,7 +677,8 @@ class GraphedElbo:
                     return
                 ops.lr_linear_fwd(h, *p, sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,
                                   out_sq=self.bufs_sq[i], w_frag=self.wfrag[i], split_scratch=self.lr_split[i],
-                                  rider=self.lr_rider if i == last - 1 else None, **common)
+                                  rider=self.lr_rider if i == last - 1 else None,
+                                  x_lo=h_lo if self.lr_x3 else None, out_lo=self.bufs_lo[i] if self.lr_x3 else None, **common)
                 h_sq = self.bufs_sq[i]
             elif self.lib[i]:
                 if i in sampled:

@@ -371,11 +371,14 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
                   dump_eps: bool = False, workspace=None, sample_counter=None, out=None, x_sq=None,
                   out_sq=None, w_frag=None, want_v: bool = False, want_y16: bool = False, want_hfac: bool = False, form: int = 0,
                   sample_group: int = 0,
-                  sample_group_stride: int = 0, split_scratch=None, rider=None):
+                  sample_group_stride: int = 0, split_scratch=None, rider=None, x_lo=None, out_lo=None):
     """Argument block of K3 + the result dict + the tensors it points at.  `rider`: dict(w_mu, w_rho, b_mu, b_rho, w_frag,
-    workspace) of a narrow LR layer whose operands this launch prepares on the side (bnn_lr_rider)."""
+    workspace) of a narrow LR layer whose operands this launch prepares on the side (bnn_lr_rider).
+    math_mode MATH_BF16X3 (the block form over lr_prepare(x3=True) fragments, bf16 x with `x_lo` and `x_sq`): taken as asked when
+    those operands are there, else the launch runs exact fp32 (the mode's promise is the reference's arithmetic)."""
     require_device(x, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b)
-    math_mode = _exact_unless_bf16(math_mode)
+    if math_mode == L.MATH_BF16X3 and (x_lo is None or x_sq is None or w_frag is None or x.dtype != torch.bfloat16):
+        math_mode = L.MATH_F32
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     K, N = w_mu.shape
@@ -438,6 +441,17 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
     if split_scratch is not None:
         a.split_scratch = split_scratch.data_ptr()
         a.split_scratch_bytes = split_scratch.numel() * split_scratch.element_size()
+    y_lo = None
+    if math_mode == L.MATH_BF16X3:
+        if x_lo.dtype != torch.bfloat16 or tuple(x_lo.shape) != tuple(xs.shape) or not x_lo.is_contiguous():
+            raise BnnHipError("x_lo must be a contiguous bfloat16 tensor shaped like x")
+        require_device(x_lo)
+        a.x_lo = x_lo.data_ptr()
+        if y.dtype == torch.bfloat16:
+            y_lo = out_lo if out_lo is not None else torch.empty(tuple(y.shape), dtype=torch.bfloat16, device=dev)
+            if y_lo.dtype != torch.bfloat16 or y_lo.numel() != y.numel() or not y_lo.is_contiguous():
+                raise BnnHipError("out_lo must be a contiguous bf16 tensor shaped like y")
+            a.y_lo = y_lo.data_ptr()
     rd = None
     if rider is not None:
         rw = [_f32c(rider[k], k) for k in ("w_mu", "w_rho", "b_mu", "b_rho")]
@@ -451,8 +465,8 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
         rd.kl_workspace_bytes = rider["workspace"].numel() * rider["workspace"].element_size()
         a.rider = C.pointer(rd)
         rd = (rd, rw, rider["w_frag"], rider["workspace"])
-    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac)
-    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch, rd)
+    res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac, y_lo=y_lo)
+    keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch, rd, x_lo, y_lo)
     return a, res, keep
 
 
@@ -629,21 +643,22 @@ def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, out_sq: Optio
     return (out, out_sq) if (want_sq or out_sq is not None) else out
 
 
-def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None):
-    """bnn_lr_prepare: bf16 (M, sigma^2) in MFMA fragment order + the KL sums into `workspace`.
-    Returns (w_frag, workspace)."""
+def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None, x3: bool = False):
+    """bnn_lr_prepare: bf16 (M, sigma^2) in MFMA fragment order + the KL sums into `workspace` (`x3`: bnn_lr_prepare_x3 --
+    the fragments of the split-bf16 math mode, with the low part of M as a third plane).  Returns (w_frag, workspace)."""
     lib = L.load()
     require_device(w_mu, w_rho, b_mu, b_rho)
     w_mu, w_rho = _f32c(w_mu, "weight_mu"), _f32c(w_rho, "weight_rho")
     b_mu, b_rho = _f32c(b_mu, "bias_mu"), _f32c(b_rho, "bias_rho")
     K, N = w_mu.shape
-    nbytes = lib.bnn_lr_prepare_bytes(K, N)
+    nbytes = (lib.bnn_lr_prepare_x3_bytes if x3 else lib.bnn_lr_prepare_bytes)(K, N)
     if out is None:
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_mu.device)
     if workspace is None:
         workspace = lr_workspace(N, w_mu.device)
-    L.check(lib.bnn_lr_prepare(w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr(), K, N,
-                               out.data_ptr(), out.numel() * 4, workspace.data_ptr(), workspace.numel() * 4, _stream()),
+    fn = lib.bnn_lr_prepare_x3 if x3 else lib.bnn_lr_prepare
+    L.check(fn(w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr(), K, N,
+               out.data_ptr(), out.numel() * 4, workspace.data_ptr(), workspace.numel() * 4, _stream()),
             "bnn_lr_prepare")
     return out, workspace
 

@@ -4,8 +4,10 @@ arguments (networks.py:50, :92, :142), so build-side settings live here and in e
   BNN_HIP_MATH   bf16 (default; bf16 MFMA operands, fp32 accumulate, fp32 statistics)
                  f32  (exact fp32 MFMA; the parity mode)
                  bf16x3 (split-bf16 operands, three bf16 MFMAs per product: the reference's fp32 F.linear to ~1e-5 of
-                         the output scale at 3/16 of the exact mode's matrix-core time; BBB forward paths, the
-                         local-reparameterisation layers and every backward run it as f32)
+                         the output scale at 3/16 of the exact mode's matrix-core time; the BBB forward paths and the
+                         stacked-minibatch path of a local-reparameterisation network (its mean product; the variance
+                         product stays on bf16 operands) -- every other launch of a job in this mode, the backward kernels
+                         included, runs exact fp32)
   BNN_HIP_SEED   64-bit Philox key (default 2026)
   BNN_HIP_EPS    device (default; on-chip Philox)  |  host (draw eps with torch's CPU
                  generator in the reference's order, networks.py:42, then copy H2D)

@@ -41,7 +41,9 @@ struct LrK {
   float* eps_b_dump;
   void* y;
   const void* x_sq; // optional bf16 x*x (same shape as x)
-  const float4* w_frag;  // optional prepared weights (lr_prepare_kernel): [T][ksteps][2][64] x 16 B
+  const void* x_lo; // BNN_MATH_BF16X3: the low plane of x
+  void* y_lo;       // BNN_MATH_BF16X3, bf16 y: the low plane of y
+  const float4* w_frag;  // optional prepared weights (lr_prepare_kernel): [T][ksteps][2][64] x 16 B (X3: [3][64], see bnn_lr_prepare_x3)
   Xcd2D xc;              // K3b: work order (feature group x (sample, batch block)), see bnn_device.h
 #ifdef BNN_TUNE
   int tune;              // tuning build only: 1 = no MFMAs, 2 = no LDS reads, 4 = no loads in the k loop
@@ -955,12 +957,17 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
 // 512-byte segments (16 bytes per thread), forms bf16 M and sigma^2 and the KL terms, parks the two 32 x 128 bf16
 // tiles in LDS and writes them out in MFMA-fragment order, 16 bytes per lane, 1 KiB per wave.  One KL entry per block
 // (the finalize only needs the layer's totals); the biases go with the blocks of the first k range.
+// X3 (split-bf16 math): a third plane per (tile, k-step) -- the low part bf16(M - bf16(M)) of the mean operand; the fragment
+// block is then [mean hi | variance | mean lo][64 lanes] x 16 B.
+template <bool X3>
 __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
                                                                const float* __restrict__ b_mu, const float* __restrict__ b_rho,
                                                                int K, int N, int kb, float4* __restrict__ frag,
                                                                float4* __restrict__ ws) {
   constexpr int LD = 130;                                   // bf16 elements per LDS row (128 + 2: the four 8-row groups a
+  constexpr int FB = X3 ? 192 : 128;                        // float4s per fragment block
   __shared__ __bf16 m_s[32 * LD], v_s[32 * LD];             // fragment read touches fall on different banks)
+  __shared__ __bf16 l_s[X3 ? 32 * LD : 1];
   __shared__ float red[4 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1002,8 +1009,10 @@ __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __re
           s_s2 += ok[j] ? sig * sig : 0.f;
           s_m2 += ok[j] ? mu[j] * mu[j] : 0.f;
         }
-        m_s[kr * LD + c4 + j] = ok[j] ? (__bf16)mu[j] : (__bf16)0.f;
+        const __bf16 mh = ok[j] ? (__bf16)mu[j] : (__bf16)0.f;
+        m_s[kr * LD + c4 + j] = mh;
         v_s[kr * LD + c4 + j] = ok[j] ? (__bf16)(sig * sig) : (__bf16)0.f;
+        if (X3) l_s[kr * LD + c4 + j] = ok[j] ? split_lo(mu[j], mh) : (__bf16)0.f;
       }
     }
     __syncthreads();
@@ -1012,15 +1021,17 @@ __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __re
     for (int h = 0; h < 2; ++h) {
       const int tl = wave + 4 * h, tile = grp * 8 + tl;
       if (tile < T) {                                        // wave-uniform
-        bf16x8 ma, sa;
+        bf16x8 ma, sa, la;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           ma[j] = m_s[(q * 8 + j) * LD + tl * 16 + r];
           sa[j] = v_s[(q * 8 + j) * LD + tl * 16 + r];
+          if (X3) la[j] = l_s[(q * 8 + j) * LD + tl * 16 + r];
         }
-        float4* dst = frag + ((size_t)tile * ksteps + t) * 128;
+        float4* dst = frag + ((size_t)tile * ksteps + t) * FB;
         dst[lane] = __builtin_bit_cast(float4, ma);
         dst[64 + lane] = __builtin_bit_cast(float4, sa);
+        if (X3) dst[128 + lane] = __builtin_bit_cast(float4, la);
       }
     }
     __syncthreads();
@@ -1058,10 +1069,18 @@ __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __re
 // in a ring of DEPTH + 1 LDS buffers.  With one step of prefetch every block-step lasted a whole L2 round trip on top
 // of its own work: with the fabric traffic out of the way (2-D work order) the counters showed MFMA, LDS, L2 and VALU
 // each ~26 % busy and the waves parked two thirds of the time.
-template <int NW, bool PREP, int DEPTH>
+// X3 (BNN_MATH_BF16X3, prepared fragments only): the MEAN product in split-bf16 -- M_hi x_hi + M_lo x_hi + M_hi x_lo over the
+// plane pair (x, x_lo) and the fragment pair (M_hi, M_lo): the reference's fp32 x . M (networks.py:120) to ~1e-5 of the output
+// scale --, the VARIANCE product as in bf16 math (one MFMA over bf16(x^2), bf16(sigma^2): the activation noise sqrt(v) eps is a
+// few per cent of the output, a 2^-9 relative error of it is below the mean product's 2^-15; measured on the CPU: NLL 1e-6
+// against the fp32 arithmetic either way, tests/test_oracle_golden.py).  Four MFMAs per batch tile and k-step instead of two,
+// three tile planes (24 KiB per step) and three fragments per wave-step.
+template <int NW, bool PREP, int DEPTH, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(const LrK p) {
   static_assert(DEPTH == 1 || (PREP && DEPTH == 2), "two steps of prefetch: prepared fragments only");
-  typedef float4 XtB[2][8 * 64];                                    // [x | x^2][tile]: 16 KiB
+  static_assert(!X3 || PREP, "split-bf16 form: over prepared fragments");
+  constexpr int NP = X3 ? 3 : 2;
+  typedef float4 XtB[NP][8 * 64];                                   // [x | x^2 (| x lo)][tile]: 16 (24) KiB
   __shared__ __attribute__((aligned(16))) XtB xt[DEPTH + 1];        // ring: step t reads xt[t % (DEPTH + 1)]
   __shared__ float bias_s[NW][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1084,13 +1103,16 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
   const bool do_kl = !PREP && p.want_kl && mb == 0 && s == 0;   // PREP: the prepare pass owns the KL sums
   const __bf16* xs = reinterpret_cast<const __bf16*>(p.x) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
   const __bf16* xq = reinterpret_cast<const __bf16*>(p.x_sq) + (size_t)(s / p.xg) * (size_t)p.x_sstride;
+  const __bf16* xl = X3 ? reinterpret_cast<const __bf16*>(p.x_lo) + (size_t)(s / p.xg) * (size_t)p.x_sstride : nullptr;
   const int T = (N + 15) >> 4;
   if (do_kl && item == 0 && threadIdx.x == 0) p.ws[0] = make_float4(__int_as_float(T), 0.f, 0.f, 0.f);
 
   // staging: 16 tile pieces per k-step (8 batch tiles of x, 8 of x^2); NW <= 8: wave w brings batch tiles w, w + NW, ...
   // of both; NW == 16: waves 0..7 bring the x tiles, waves 8..15 the x^2 tiles
   constexpr int NX = NW >= 8 ? 1 : 8 / NW;
-  constexpr int OPS = (NW == 16 ? 1 : 2 * NX) + 2;          // vector-memory operations a wave issues per step (PREP)
+  // vector-memory operations a wave issues per step (PREP): its DMA pieces + its fragment loads.  X3 with 16 waves: waves 0-7
+  // bring a piece of x AND of x lo, waves 8-15 a piece of x^2 -- OPS for the first half, OPS - 1 for the second
+  constexpr int OPS = (NW == 16 ? (X3 ? 2 : 1) : NP * NX) + NP;
   size_t xrow[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) xrow[i] = (size_t)min(m0 + ((wave & 7) + i * NW) * 16 + r, B - 1) * K;
@@ -1100,6 +1122,9 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
       const __bf16* src = (wave < 8 ? xs : xq) + xrow[0] + kk;          // wave-uniform select
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)&xb_[wave >> 3][(wave & 7) * 64], 16, 0, 0);
+      if (X3 && wave < 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xl + xrow[0] + kk),
+                                         (__attribute__((address_space(3))) void*)&xb_[NP - 1][(wave & 7) * 64], 16, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
@@ -1107,16 +1132,30 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
                                          (__attribute__((address_space(3))) void*)&xb_[0][(wave + i * NW) * 64], 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xq + xrow[i] + kk),
                                          (__attribute__((address_space(3))) void*)&xb_[1][(wave + i * NW) * 64], 16, 0, 0);
+        if (X3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xl + xrow[i] + kk),
+                                           (__attribute__((address_space(3))) void*)&xb_[NP - 1][(wave + i * NW) * 64], 16, 0, 0);
       }
+    }
+  };
+  // counted wait "all but this wave's operations of the youngest step have landed"
+  auto wait_ring = [&]() __attribute__((always_inline)) {
+    if (X3 && NW == 16) {
+      if (wave < 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");        // wave-uniform
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS - 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
     }
   };
   float mu_n[8], rho_n[8];
   float4 ma_a, sa_a, ma_b, sa_b;                       // PREP: prepared bf16 fragments of the steps in flight
+  float4 la_a = make_float4(0.f, 0.f, 0.f, 0.f), la_b = la_a;   // X3: the low part of the mean fragment
   const int tclamp = min(tile, T - 1);
-  auto load_frag = [&](int t, float4& ma_r, float4& sa_r) {
-    const float4* src = p.w_frag + ((size_t)tclamp * ksteps + t) * 128;
+  auto load_frag = [&](int t, float4& ma_r, float4& sa_r, float4& la_r) {
+    const float4* src = p.w_frag + ((size_t)tclamp * ksteps + t) * (X3 ? 192 : 128);
     ma_r = src[lane];
     sa_r = src[64 + lane];
+    if (X3) la_r = src[128 + lane];
   };
   auto load_raw = [&](int t) {
     const int k = t * 32 + q * 8;
@@ -1141,12 +1180,12 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
     if (p.eps_b_dump && mb == 0) p.eps_b_dump[(size_t)s * N + n] = beps_pre;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the bias loads are not part of the ring's count
-  if (PREP) load_frag(0, ma_a, sa_a); else load_raw(0);
+  if (PREP) load_frag(0, ma_a, sa_a, la_a); else load_raw(0);
   stage_dma(0, xt[0]);
   if (DEPTH == 2 && ksteps > 1) {
-    load_frag(1, ma_b, sa_b);
+    load_frag(1, ma_b, sa_b, la_b);
     stage_dma(1, xt[1]);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    wait_ring();
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1167,12 +1206,13 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
   float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
   // one k-step: consume the fragments of step t (held in ma_r / sa_r), refill them for step t + DEPTH, 16 MFMAs on
   // ring buffer `buf`, then wait for step t + 1's loads and meet the block
-  auto step = [&](int t, XtB& cur, XtB& nxt, float4& ma_r, float4& sa_r, bool steady) __attribute__((always_inline)) {
-    bf16x8 ma, sa;
+  auto step = [&](int t, XtB& cur, XtB& nxt, float4& ma_r, float4& sa_r, float4& la_r, bool steady) __attribute__((always_inline)) {
+    bf16x8 ma, sa, ml;
     float mu[8], s2[8];
     if (PREP) {
       ma = __builtin_bit_cast(bf16x8, ma_r);             // a wave past the last tile computes on the last tile's
       sa = __builtin_bit_cast(bf16x8, sa_r);             // fragments (finite) and stores nothing
+      if (X3) ml = __builtin_bit_cast(bf16x8, la_r);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1188,7 +1228,7 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
 #endif
     if (more && !tune_noload) {
       stage_dma(t + DEPTH, nxt);
-      if (PREP) load_frag(t + DEPTH, ma_r, sa_r); else load_raw(t + DEPTH);
+      if (PREP) load_frag(t + DEPTH, ma_r, sa_r, la_r); else load_raw(t + DEPTH);
     }
     if (!PREP) {
       const int k = t * 32 + q * 8;
@@ -1243,12 +1283,48 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
   BNN_MF(av[M], sa, g0); BNN_MF(av[M + 1], sa, g1);                                               \
   __builtin_amdgcn_sched_barrier(0);                                                              \
   if (!(LAST) && BNN_RD) BNN_LDS2(g0, g1, 8192 + (M + 2) * 1024);
-      BNN_LDS2(f0, f1, 0);                               // x,   batch tiles 0, 1
-      BNN_LDS2(g0, g1, 8192);                            // x^2, batch tiles 0, 1
-      BNN_PAIR(0, false)
-      BNN_PAIR(2, false)
-      BNN_PAIR(4, false)
-      BNN_PAIR(6, true)
+      // X3: three single fragments in rotation (x, x^2, x lo of batch tile M; single tiles, not pairs: the 16-wave block has 128
+      // registers per lane and must not spill -- scratch traffic would enter the counted vmcnt waits of the ring): the x fragment
+      // feeds two MFMAs (hi and lo part of the mean operand), x^2 and x lo one each; a fragment is requested one tile ahead
+#define BNN_LDS1(a, O) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(a) : "v"(la), "n"((O)))
+#define BNN_LGKM1(N, a) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a))
+#define BNN_TRIO(M, LAST)                                                                         \
+  BNN_LGKM1(2, f0);                                                                               \
+  BNN_MF(am[M], ma, f0); BNN_MF(am[M], ml, f0);                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (!(LAST) && BNN_RD) BNN_LDS1(f0, (M + 1) * 1024);                                            \
+  if (LAST) { BNN_LGKM1(1, g0); } else { BNN_LGKM1(2, g0); }                                      \
+  BNN_MF(av[M], sa, g0);                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (!(LAST) && BNN_RD) BNN_LDS1(g0, 8192 + (M + 1) * 1024);                                     \
+  if (LAST) { BNN_LGKM1(0, h0); } else { BNN_LGKM1(2, h0); }                                      \
+  BNN_MF(am[M], ma, h0);                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if (!(LAST) && BNN_RD) BNN_LDS1(h0, 16384 + (M + 1) * 1024);
+      if (X3) {
+        f32x4 h0;
+        BNN_LDS1(f0, 0);                                 // x, x^2, x lo of batch tile 0
+        BNN_LDS1(g0, 8192);
+        BNN_LDS1(h0, 16384);
+        BNN_TRIO(0, false)
+        BNN_TRIO(1, false)
+        BNN_TRIO(2, false)
+        BNN_TRIO(3, false)
+        BNN_TRIO(4, false)
+        BNN_TRIO(5, false)
+        BNN_TRIO(6, false)
+        BNN_TRIO(7, true)
+      } else {
+        BNN_LDS2(f0, f1, 0);                             // x,   batch tiles 0, 1
+        BNN_LDS2(g0, g1, 8192);                          // x^2, batch tiles 0, 1
+        BNN_PAIR(0, false)
+        BNN_PAIR(2, false)
+        BNN_PAIR(4, false)
+        BNN_PAIR(6, true)
+      }
+#undef BNN_TRIO
+#undef BNN_LDS1
+#undef BNN_LGKM1
 #undef BNN_PAIR
 #undef BNN_RD
 #undef BNN_LDS2
@@ -1269,7 +1345,7 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
     // workgroup fence would drain every LDS-DMA in flight (vmcnt(0)) and with it the second step of prefetch.  What the
     // barrier must order is stated by hand: this wave's LDS reads of `buf` are complete (the MFMAs consumed them), its
     // DMA pieces of step t + 1 have landed (the vmcnt wait).
-    if (DEPTH == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    if (DEPTH == 2 && more) wait_ring();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (PREP) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1281,7 +1357,7 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
   };
   if (DEPTH == 1) {
 #pragma nounroll
-    for (int t = 0; t < ksteps; ++t) step(t, xt[t & 1], xt[(t + 1) & 1], ma_a, sa_a, false);
+    for (int t = 0; t < ksteps; ++t) step(t, xt[t & 1], xt[(t + 1) & 1], ma_a, sa_a, la_a, false);
   } else {
     // step t reads ring buffer t % 3 and fills buffer (t + 2) % 3 for step t + 2; the fragments alternate between two
     // register sets.  Steady state: both steps of a pair refill (no branch in the body), so the compiler's own
@@ -1291,18 +1367,18 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
     // body holds six steps: one full drain per six)
 #pragma nounroll
     for (; t + 7 < ksteps; t += 6) {
-      step(t, xt[0], xt[2], ma_a, sa_a, true);
-      step(t + 1, xt[1], xt[0], ma_b, sa_b, true);        // step t + 3 reuses the buffer of step t
-      step(t + 2, xt[2], xt[1], ma_a, sa_a, true);
-      step(t + 3, xt[0], xt[2], ma_b, sa_b, true);
-      step(t + 4, xt[1], xt[0], ma_a, sa_a, true);
-      step(t + 5, xt[2], xt[1], ma_b, sa_b, true);
+      step(t, xt[0], xt[2], ma_a, sa_a, la_a, true);
+      step(t + 1, xt[1], xt[0], ma_b, sa_b, la_b, true);        // step t + 3 reuses the buffer of step t
+      step(t + 2, xt[2], xt[1], ma_a, sa_a, la_a, true);
+      step(t + 3, xt[0], xt[2], ma_b, sa_b, la_b, true);
+      step(t + 4, xt[1], xt[0], ma_a, sa_a, la_a, true);
+      step(t + 5, xt[2], xt[1], ma_b, sa_b, la_b, true);
     }
 #pragma nounroll
     for (; t < ksteps; t += 2) {
       const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-      step(t, xt[b0], xt[b2], ma_a, sa_a, false);
-      if (t + 1 < ksteps) step(t + 1, xt[b1], xt[b0], ma_b, sa_b, false);
+      step(t, xt[b0], xt[b2], ma_a, sa_a, la_a, false);
+      if (t + 1 < ksteps) step(t + 1, xt[b1], xt[b0], ma_b, sa_b, la_b, false);
       b0 = b2;
     }
   }
@@ -1380,15 +1456,28 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
         }
         if (p.y_bf16) {
           __bf16* yp = reinterpret_cast<__bf16*>(p.y) + yoff;
-          if (vec_ok) {
-            bf16x4 o;
+          bf16x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          if (vec_ok) {
             *reinterpret_cast<bf16x4*>(yp) = o;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (nb + i < N) yp[i] = (__bf16)v[i];
+              if (nb + i < N) yp[i] = o[i];
+          }
+          if (X3) {                                  // the low plane of the output's split pair
+            __bf16* lp = reinterpret_cast<__bf16*>(p.y_lo) + yoff;
+            bf16x4 l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = split_lo(v[i], o[i]);
+            if (vec_ok) {
+              *reinterpret_cast<bf16x4*>(lp) = l;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (nb + i < N) lp[i] = l[i];
+            }
           }
         } else {
           float* yp = reinterpret_cast<float*>(p.y) + yoff;
@@ -1806,12 +1895,16 @@ extern "C" size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features
   return (size_t)((out_features + 15) / 16) * (size_t)((in_features + 31) / 32) * 128 * 16;
 }
 
-extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
-                              int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
-                              void* kl_workspace, size_t kl_workspace_bytes, void* stream_) {
+extern "C" size_t bnn_lr_prepare_x3_bytes(int32_t in_features, int32_t out_features) {
+  return bnn_lr_prepare_bytes(in_features, out_features) / 2 * 3;
+}
+
+static int lr_prepare_impl(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                           int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                           void* kl_workspace, size_t kl_workspace_bytes, void* stream_, bool x3) {
   if (!w_mu || !w_rho || !b_mu || !b_rho || !w_frag) return BNN_ERR_NULL;
   if (in_features <= 0 || out_features <= 0) return BNN_ERR_SHAPE;
-  if (w_frag_bytes < bnn_lr_prepare_bytes(in_features, out_features)) return BNN_ERR_WORKSPACE;
+  if (w_frag_bytes < (x3 ? bnn_lr_prepare_x3_bytes(in_features, out_features) : bnn_lr_prepare_bytes(in_features, out_features))) return BNN_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(w_frag) & 15) return BNN_ERR_ALIGN;
   if (kl_workspace) {
     if (kl_workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(out_features)) return BNN_ERR_WORKSPACE;
@@ -1822,12 +1915,38 @@ extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float
   const int max_entries = (out_features + 3) / 4 > kPrepEntries ? (out_features + 3) / 4 : kPrepEntries;
   int kb = 1;
   while ((long)((ksteps + kb - 1) / kb) * groups > max_entries) ++kb;
-  hipLaunchKernelGGL(lr_prepare_tiled_kernel, dim3((unsigned)((ksteps + kb - 1) / kb), (unsigned)groups), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu, b_rho, in_features, out_features, kb,
-                     reinterpret_cast<float4*>(w_frag), reinterpret_cast<float4*>(kl_workspace));
+  if (x3)
+    hipLaunchKernelGGL(lr_prepare_tiled_kernel<true>, dim3((unsigned)((ksteps + kb - 1) / kb), (unsigned)groups), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu, b_rho, in_features, out_features, kb,
+                       reinterpret_cast<float4*>(w_frag), reinterpret_cast<float4*>(kl_workspace));
+  else
+    hipLaunchKernelGGL(lr_prepare_tiled_kernel<false>, dim3((unsigned)((ksteps + kb - 1) / kb), (unsigned)groups), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), w_mu, w_rho, b_mu, b_rho, in_features, out_features, kb,
+                       reinterpret_cast<float4*>(w_frag), reinterpret_cast<float4*>(kl_workspace));
   hipError_t err = hipGetLastError();
   return err == hipSuccess ? BNN_OK : (int)err;
 }
+
+extern "C" int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                              int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                              void* kl_workspace, size_t kl_workspace_bytes, void* stream_) {
+  return lr_prepare_impl(w_mu, w_rho, b_mu, b_rho, in_features, out_features, w_frag, w_frag_bytes, kl_workspace, kl_workspace_bytes, stream_, false);
+}
+
+extern "C" int bnn_lr_prepare_x3(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                                 int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                                 void* kl_workspace, size_t kl_workspace_bytes, void* stream_) {
+  return lr_prepare_impl(w_mu, w_rho, b_mu, b_rho, in_features, out_features, w_frag, w_frag_bytes, kl_workspace, kl_workspace_bytes, stream_, true);
+}
+
+// K3b in split-bf16 math: k-steps of prefetch.  One: the block-wide kernels have 128 registers per lane, and with a second
+// set of three prefetched fragments in flight the compiler spills INSIDE the k loop -- scratch loads and stores count in vmcnt
+// like every vector-memory operation, so the ring's counted waits ("all but this step's operations have landed") would no
+// longer say what they mean.  With one step of prefetch every wait in the loop is vmcnt(0).
+#ifndef BNN_LR_X3_DEPTH
+#define BNN_LR_X3_DEPTH 1
+#endif
+static constexpr int kLrX3Depth = BNN_LR_X3_DEPTH;
 
 // validate the arguments and fill the kernel parameter block
 static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
@@ -1836,8 +1955,21 @@ static int lr_fill(const bnn_lr_fwd_args* a, LrK& k) {
   if (a->n_samples <= 0 || a->batch <= 0 || a->in_features <= 0 || a->out_features <= 0) return BNN_ERR_SHAPE;
   if ((double)a->n_samples * ((a->batch + 127) / 128) * ((a->out_features + 3) / 4) > 2.0e9) return BNN_ERR_SHAPE;
   if (!a->x || !a->w_mu || !a->w_rho || !a->b_mu || !a->b_rho || !a->y) return BNN_ERR_NULL;
-  if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 1u || (unsigned)a->eps_mode > 2u)
+  if ((unsigned)a->x_dtype > 1u || (unsigned)a->y_dtype > 1u || (unsigned)a->math > 2u || (unsigned)a->eps_mode > 2u)
     return BNN_ERR_ENUM;
+  k.x_lo = nullptr; k.y_lo = nullptr;
+  if (a->math == BNN_MATH_BF16X3) {
+    // split-bf16 math: the block-GEMM form over bnn_lr_prepare_x3's fragments and the (x, x_lo, x_sq) planes -- nothing else
+    if (!a->x_lo || !a->x_sq || !a->w_frag) return BNN_ERR_NULL;
+    if (a->x_dtype != BNN_BF16 || a->v_out || a->hfac_out || a->y_bf16_copy || a->rider || (a->in_features % 8)) return BNN_ERR_ENUM;
+    if ((reinterpret_cast<uintptr_t>(a->x_lo) | reinterpret_cast<uintptr_t>(a->x_sq) | reinterpret_cast<uintptr_t>(a->w_frag)) & 15) return BNN_ERR_ALIGN;
+    k.x_lo = a->x_lo;
+    if (a->y_dtype == BNN_BF16) {
+      if (!a->y_lo) return BNN_ERR_NULL;
+      if ((a->out_features % 4 == 0) && (reinterpret_cast<uintptr_t>(a->y_lo) & 7)) return BNN_ERR_ALIGN;
+      k.y_lo = a->y_lo;
+    }
+  }
   if (a->eps_mode == BNN_EPS_MEMORY && (!a->eps_act || !a->eps_b)) return BNN_ERR_NULL;
   if (a->want_kl) {
     if (!a->workspace || a->workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(a->out_features))
@@ -1926,14 +2058,16 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   pl.es = 1;
   // all samples on one input: the K-sliced form makes the products once -- ahead of the block-GEMM form, which would
   // make them per sample
-  if (lr_shared_input(a) && a->form == BNN_FORM_AUTO && lr_kslice_plan(a, pl) == BNN_OK) return BNN_OK;
+  if (a->math != BNN_MATH_BF16X3 && lr_shared_input(a) && a->form == BNN_FORM_AUTO && lr_kslice_plan(a, pl) == BNN_OK) return BNN_OK;
   // K3b needs bf16 x AND x^2 streams; the saved variance (v_out) is a K3a epilogue
-  const bool can = !a->v_out && !a->y_bf16_copy && !a->hfac_out && a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
+  const bool x3 = a->math == BNN_MATH_BF16X3;             // (lr_fill has checked what that mode needs)
+  const bool can = !a->v_out && !a->y_bf16_copy && !a->hfac_out && (a->math == BNN_MATH_BF16 || x3) && a->x_dtype == BNN_BF16 && a->x_sq && (K % 8 == 0) && K >= 8 &&
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
+  if (x3 && !(can && a->form != BNN_FORM_TILE && a->form != BNN_FORM_GEMM_KSLICE)) return BNN_ERR_ENUM;
   // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
   // (over prepared fragments the block form pays from 8 samples on: 1200 x 1200, 10 samples 29 us + a 6 us prepare launch against
   // K3a's 49; 16 samples 33 against 80 -- tools/lr_mid_sweep.py, profiles/r03_lr_mid_sweep.log)
-  if (can && (a->form == BNN_FORM_GEMM ||
+  if (can && (a->form == BNN_FORM_GEMM || x3 ||
               (a->form == BNN_FORM_AUTO && (gemm_blocks >= 300 || (a->w_frag && a->n_samples >= 8 && gemm_blocks >= 150))))) {
     pl.form = BNN_FORM_GEMM;
     pl.R = 1; pl.MT = 8;
@@ -1950,7 +2084,7 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
     if (const char* v = getenv("BNN_TUNE_LRNW")) { const int f = atoi(v); if (a->w_frag && (f == 4 || f == 8 || f == 16)) pl.nw = f; }
 #endif
     pl.total = (long)((N + 16 * pl.nw - 1) / (16 * pl.nw)) * a->n_samples * mbs;
-    pl.lds = (size_t)(a->w_frag ? 3 : 2) * 2 * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);   // static: the ring of x / x^2 tile pairs + biases
+    pl.lds = (size_t)(x3 ? kLrX3Depth + 1 : a->w_frag ? 3 : 2) * (x3 ? 3 : 2) * 8 * 64 * 16 + (size_t)pl.nw * 16 * sizeof(float);   // static: the ring of x / x^2 (/ x lo) tiles + biases
     return BNN_OK;
   }
   // K3s: few samples on a wide layer -- 32-feature groups x K slices, so that ~150-300 blocks exist and each pulls
@@ -2095,11 +2229,15 @@ extern "C" int bnn_lr_linear_fwd(const bnn_lr_fwd_args* a, void* stream_) {
 #endif
       const int feats = 16 * pl.nw;
       k.xc = xcd2d_make((N + feats - 1) / feats, a->n_samples * ((a->batch + 127) / 128), 1,
-                        (size_t)feats * K * (a->w_frag ? 4 : 8), l2_budget);
+                        (size_t)feats * K * (a->math == BNN_MATH_BF16X3 ? 6 : a->w_frag ? 4 : 8), l2_budget);
     }
     if (a->w_frag) {
       if (reinterpret_cast<uintptr_t>(a->w_frag) & 15) return BNN_ERR_ALIGN;
-      if (pl.nw == 16) hipLaunchKernelGGL((lr_fwd_gemm_kernel<16, true, 2>), grid, block, 0, stream, k);
+      if (a->math == BNN_MATH_BF16X3) {
+        if (pl.nw == 16) hipLaunchKernelGGL((lr_fwd_gemm_kernel<16, true, kLrX3Depth, true>), grid, block, 0, stream, k);
+        else if (pl.nw == 8) hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true, kLrX3Depth, true>), grid, block, 0, stream, k);
+        else hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true, kLrX3Depth, true>), grid, block, 0, stream, k);
+      } else if (pl.nw == 16) hipLaunchKernelGGL((lr_fwd_gemm_kernel<16, true, 2>), grid, block, 0, stream, k);
       else if (pl.nw == 8) hipLaunchKernelGGL((lr_fwd_gemm_kernel<8, true, 2>), grid, block, 0, stream, k);
       else hipLaunchKernelGGL((lr_fwd_gemm_kernel<4, true, 2>), grid, block, 0, stream, k);
     } else {

@@ -285,6 +285,10 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
     if lr:
         kw = dict(sigma_p=1.0, want_kl=True, x_sq=ev.bufs_sq[0], out_sq=ev.bufs_sq[1], w_frag=ev.wfrag[1],
                   split_scratch=getattr(ev, "lr_split", [None] * 3)[1], **common)
+        if getattr(ev, "lr_x3", False):                # split-bf16 math: the plane pair in, fp32 out (the layer below the output layer)
+            kw.update(x_lo=ev.bufs_lo[0], out_lo=ev.bufs_lo[1])
+        else:
+            kw["math_mode"] = ev.math
         plan = ops.lr_plan(xin, *pd, **kw)
         launch = lambda: ops.lr_linear_fwd(xin, *pd, **kw)
     else:
@@ -308,7 +312,8 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
              ("bbb", "gemm"): ("K1b2 bbb_fwd_gemm2_kernel<X3> (split-bf16 operands: three bf16 MFMAs per product; parameters and the x plane pair through LDS, 2 pairs per block)"
                                if math_name == "bf16x3" else "K1b2 bbb_fwd_gemm2_kernel (parameters and x through LDS, 2 pairs per block)") if plan["waves"] == 8 else "K1b bbb_fwd_gemm_kernel",
              ("bbb", "gemm_kslice"): "K1b bbb_fwd_gemm_kernel, K-sliced with the fused last-arriver reduce",
-             ("lr", "tile"): "K3a lr_fwd_kernel", ("lr", "gemm"): "K3b lr_fwd_gemm_kernel",
+             ("lr", "tile"): "K3a lr_fwd_kernel",
+             ("lr", "gemm"): "K3b lr_fwd_gemm_kernel<X3> (mean product in split-bf16: three MFMAs; variance product one)" if math_name == "bf16x3" else "K3b lr_fwd_gemm_kernel",
              ("lr", "gemm_kslice"): "K3s lr_fwd_kslice_kernel (32-feature groups x K slices, whole parameter lines, slices meet through a scratch)"}[("lr" if lr else "bbb", form)]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "traffic_key": f"{'lr' if lr else 'bbb'}_{dims[1]}_n{n}_b{batch}_{math_name}",
@@ -324,11 +329,12 @@ def layer2_roofline(ev, net, dims, batch, lr, math_name):
         roof["hbm_algorithmic"] = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
         roof.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS})
     elif math_name == "bf16x3":
-        roof["mfma_flops_issued_per_launch"] = 3 * flops            # three bf16 MFMAs per product
-        roof["mfma_issued_frac_of_bf16_peak"] = 3 * flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        issued = (2 if lr else 3) * flops                           # BBB: three bf16 MFMAs per product; LR: 3 (mean) + 1 (variance) of 2
+        roof["mfma_flops_issued_per_launch"] = issued
+        roof["mfma_issued_frac_of_bf16_peak"] = issued / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS
     if not lr and form in ("gemm", "gemm_kslice") and math_name in ("bf16", "bf16x3"):
         roof = valu_bound(roof, dims[1], dims[1], n, batch, us, ev.wsigma[1] is not None)
-    elif lr and form == "gemm" and math_name == "bf16":
+    elif lr and form == "gemm" and math_name in ("bf16", "bf16x3"):
         # K3b: two bf16 GEMMs (mean, variance) over parameters the launch's pairs share -- the matrix cores are its busiest
         # unit (profiles/pmc.json: MFMA 0.36, VALU 0.28 busy), not memory: price it against the bf16 MFMA figure, with the
         # SURVEY 8(d) HBM figure beside it
@@ -688,6 +694,12 @@ def main():
             em, rate, us = timed_config(engine, net_lr32, x, y, 1, G, 4 * G)
             modes["lr_f32"] = {"samples_per_s": rate, "us_per_minibatch": us, "minibatches_per_launch_group": G,
                                "roofline": layer2_roofline(em, net_lr32, dims, args.batch, True, "f32")}
+            del em
+            bnn_hip.set_math("bf16x3")                 # ... and in split-bf16 math (hidden layers K3b<X3>, output layer exact fp32)
+            em, rate, us = timed_config(engine, net_lr32, x, y, 1, G, 8 * G)
+            modes["lr_bf16x3"] = {"samples_per_s": rate, "us_per_minibatch": us, "minibatches_per_launch_group": G,
+                                  "roofline": layer2_roofline(em, net_lr32, dims, args.batch, True, "bf16x3")}
+            out["lr_bf16x3_math_samples_per_s"] = rate
             del em, net_lr32
             bnn_hip.set_math(args.math)
             extras["math_modes"] = modes

@@ -377,6 +377,12 @@ typedef struct bnn_lr_fwd_args {
                                only the bias, the activation noise and the stores run per sample; the scratch then only
                                needs the sizes of n_samples = 1. */
   size_t split_scratch_bytes;
+  const void* x_lo;         /* BNN_MATH_BF16X3: the low plane of x (as in bnn_bbb_fwd_args).  In that mode the layer runs the
+                               block-GEMM form only: bf16 x with x_lo AND x_sq (bf16 of the fp32 squares), w_frag from
+                               bnn_lr_prepare_x3; the mean product x . M (networks.py:120) in split-bf16 (three MFMAs), the
+                               variance product x^2 . sigma^2 (:121) on bf16 operands as in BNN_MATH_BF16 -- the activation
+                               noise is a few per cent of the output, its 2^-9 error below the mean's 2^-15 */
+  void* y_lo;               /* BNN_MATH_BF16X3 with y_dtype == BNN_BF16: the low plane of y */
 } bnn_lr_fwd_args;
 
 size_t bnn_lr_linear_fwd_workspace_bytes(int32_t out_features);
@@ -394,6 +400,12 @@ size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features);
 int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
                    int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
                    void* kl_workspace, size_t kl_workspace_bytes, void* stream);
+/* The same for BNN_MATH_BF16X3: the fragments additionally carry the low part bf16(M - bf16(M)) of the mean operand
+ * ([mean hi | variance | mean lo] per feature tile and k-step: 1.5 x the bytes). */
+size_t bnn_lr_prepare_x3_bytes(int32_t in_features, int32_t out_features);
+int bnn_lr_prepare_x3(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                      int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                      void* kl_workspace, size_t kl_workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K2  bnn_gauss_kl — one streaming pass over (mu, rho)[n]: the eps-independent sums of

@@ -330,12 +330,29 @@ def linear_bf16x3(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Te
 
 
 def network_forward_bf16x3(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tensor]):
-    """(logits, log_prior, log_q) like network_forward for a BBB network, with the rounding points of the device's
-    split-bf16 math mode and nothing else changed (statistics from the un-rounded fp32 weights)."""
-    assert not p.local_reparam, "the split-bf16 mode is a BBB forward mode (LR layers run exact fp32)"
+    """(logits, log_prior | kl, log_q | None) like network_forward, with the rounding points of the device's split-bf16 math
+    mode and nothing else changed (statistics from the un-rounded fp32 parameters).  Local reparameterisation (the stacked-
+    minibatch path of engine.GraphedElbo): hidden layers take the MEAN product x . M in split-bf16 and the VARIANCE product on
+    bf16 operands -- bf16 of the fp32 squares of the layer's fp32 input, bf16(sigma^2) --; the output layer is exact fp32."""
     if p.mode == "classification":
         x = x.view(-1, p.input_shape)
     a, b = 0, 0
+    if p.local_reparam:
+        last = len(p.layers) - 1
+        for i, (wm, wr, bm, br) in enumerate(p.layers):
+            ew, eb = eps[2 * i], eps[2 * i + 1]
+            w_sigma, b_sigma = softplus_naive(wr), softplus_naive(br)
+            if i < last:
+                act_mu = linear_bf16x3(x, wm.t(), torch.zeros(wm.shape[1]))
+                act_sigma = torch.sqrt(torch.mm(_bf16(x * x), _bf16(w_sigma * w_sigma)))
+            else:
+                act_mu = torch.mm(x, wm)
+                act_sigma = torch.sqrt(torch.mm(x * x, w_sigma * w_sigma))
+            x = act_mu + act_sigma * ew + (bm + b_sigma * eb).unsqueeze(0)
+            a = a + (kl_closed_form(wm, w_sigma, 0.0, p.prior.sigma_p) + kl_closed_form(bm, b_sigma, 0.0, p.prior.sigma_p))
+            if i < last:
+                x = torch.relu(x)
+        return x, a, None
     for i, (wm, wr, bm, br) in enumerate(p.layers):
         w = sample_gaussian(wm, wr, eps[2 * i])
         bb = sample_gaussian(bm, br, eps[2 * i + 1])

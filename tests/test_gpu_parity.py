@@ -1732,6 +1732,64 @@ def test_split_bf16_layer_forms_against_the_rounding_point_oracle(dev, shape):
 X3_SHAPES = [(1, 1, None), (1, 8, None), (4, 2, None), (20, 1, None), (256, 1, (0, 1, 17, 63, 64, 127, 128, 200, 254, 255))]
 
 
+@pytest.mark.parametrize("G,S,pairs", [(1, 8, None), (4, 2, None), (20, 1, None), (256, 1, (0, 1, 17, 63, 64, 127, 128, 200, 254, 255))])
+def test_split_bf16_lr_timed_path_meets_the_fp32_tolerance_at_every_beta(dev, G, S, pairs):
+    """The local-reparameterisation network under set_math('bf16x3') through engine.GraphedElbo (captured, on-chip Philox): a
+    stream of stacked minibatches runs its hidden layers as K3b<X3> (split-bf16 mean product, bf16 variance product over
+    bnn_lr_prepare_x3's fragments, plane pairs between the layers) and its output layer in exact fp32; one minibatch runs exact
+    fp32 throughout.  Either way, against the FP32 oracle (= the reference's arithmetic, networks.py:116-138, :211-225) on the
+    same epsilon: KL rtol 1e-5, NLL rtol 1e-4, hence the ELBO rtol 1e-4 at every beta; and against the CPU restatement with
+    the mode's rounding points (O.network_forward_bf16x3) 2e-5."""
+    from bnn_hip import engine
+    B, dims, seed, first, E = 128, (784, 1200, 10), 454545, 11000, 2
+    bnn_hip.set_math("bf16x3")
+    net, sd = build_net(dev, True, dims, "classification")
+    p = O.NetParams.from_state_dict(sd, "classification", dims[0], True, O.Prior.from_init([1.0], False))
+    xs, ys = zip(*[synth.synth_batch("classification", B, dims[0], dims[2], seed=100 + m) for m in range(G)])
+    xd = torch.from_numpy(np.stack(xs)).to(dev)
+    yd = torch.from_numpy(np.stack(ys)).to(dev)
+    bnn_hip.manual_seed(seed, counter=first)
+    ev = engine.GraphedElbo(net, xd if G > 1 else xd[0], yd if G > 1 else yd[0], S, stacked=G > 1, evals_per_replay=E)
+    assert ev.lr_x3 == (G > 1) and ev.math == (L.MATH_BF16X3 if G > 1 else L.MATH_F32)
+    sums = ev.replay().clone().view(G, 4).double().cpu().numpy()
+    torch.cuda.synchronize()
+    total = G * S
+    base = first + total * E
+    idx = np.arange(total) if pairs is None else np.asarray(pairs)
+    want, want_logits = _oracle_pairs(p, xs, ys, seed, base, S, pairs=idx)
+    close(ev.out["kl"].double().cpu().numpy()[idx], want[:, 0], rtol=1e-5)
+    got_nll = ev.out["nll"].double().cpu().numpy()[idx]
+    lg = ev.logits.double().cpu().numpy().reshape(total, B, dims[2])[idx]
+    nll_err = np.abs(got_nll - want[:, 2]) / np.abs(want[:, 2])
+    lg_err = np.abs(lg - want_logits).max() / np.abs(want_logits).max()
+    msg = f"\n[bf16x3 LR at C3] G={G} S={S}: vs fp32 oracle nll {nll_err.max():.2e} logits {lg_err:.2e} of scale"
+    if G > 1:
+        w3, w3_logits = [], []
+        torch.set_num_threads(8)
+        for f in idx:
+            m, j = divmod(int(f), S)
+            out, a, _ = O.network_forward_bf16x3(p, t(xs[m]), O.philox_eps_for_network(p, B, seed, base + m * S + j))
+            w3.append(float(O.nll(out, t(ys[m]), p.mode)))
+            w3_logits.append(out.numpy())
+        torch.set_num_threads(1)
+        nll3_err = np.abs(got_nll - np.asarray(w3)) / np.abs(np.asarray(w3))
+        lg3_err = np.abs(lg - np.stack(w3_logits)).max() / np.abs(np.stack(w3_logits)).max()
+        msg += f"; vs rounding-point restatement nll {nll3_err.max():.2e} logits {lg3_err:.2e}"
+        assert nll3_err.max() <= 2e-5 and lg3_err <= 5e-5
+    print(msg)
+    assert nll_err.max() <= X3_NLL_RTOL and lg_err <= 1e-4
+    assert (sums[:, 3] == S).all()
+    full_eval = [m for m in range(G) if all((m * S + j) in set(idx.tolist()) for j in range(S))]
+    pos = {int(f): i for i, f in enumerate(idx.tolist())}
+    assert full_eval
+    for m in full_eval:
+        e32 = want[[pos[m * S + j] for j in range(S)]].sum(0)
+        close(sums[m, 0], e32[0], rtol=1e-5)
+        close(sums[m, 2], e32[2], rtol=X3_NLL_RTOL)
+        for beta in BETAS:
+            close(_elbo(sums[m, :3], S, beta, True), _elbo(e32, S, beta, True), rtol=1e-4)
+
+
 @pytest.mark.parametrize("G,S,pairs", X3_SHAPES)
 def test_split_bf16_timed_path_meets_the_fp32_tolerance_at_every_beta(dev, G, S, pairs):
     """The path bench.py times (engine.GraphedElbo, captured, on-chip Philox, G stacked minibatches x S samples per launch
