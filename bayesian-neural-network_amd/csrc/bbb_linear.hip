@@ -1346,13 +1346,17 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
   static_assert(NF == 2 || NF == 4 || NF == 8, "feature waves per block");
   static_assert(!X3 || NB == 2, "split-bf16 form: two x buffers");
   constexpr bool PS = X3 || (BNN_K1B2_PS && NB == 2);   // parameters single-buffered (see above)
+  // x buffers of the PS form: two, or (build knob BNN_K1B2_PS = 2, bf16 form) a ring of three -- the x pieces of step t + 2 are
+  // requested during step t, behind the parameters of step t + 1, and stay in flight over the step's closing wait
+  constexpr int XB = (PS && !X3 && BNN_K1B2_PS == 2) ? 3 : 2;
+  constexpr int RB = PS ? XB : NB;            // buffers the step index cycles through
   constexpr int BUF = NF * 256 + SB * XT;     // float4s of one staging buffer of the double-buffered-everything layout
   // LDS image, in float4s.  !PS: [buffer][NF tiles' parameter pieces | SB pairs' x tiles], then the bias table.
   //                          PS: [parameter pieces][x buffer 0][x buffer 1].
   auto p_idx = [](int buf) { return PS ? 0 : buf * BUF; };
   auto x_idx = [](int buf) { return PS ? NF * 256 + buf * (SB * XT) : buf * BUF + NF * 256; };
   // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
-  __shared__ __attribute__((aligned(16))) float4 sm_all[PS ? NF * 256 + 2 * SB * XT : NB * BUF + NW * 4];
+  __shared__ __attribute__((aligned(16))) float4 sm_all[PS ? NF * 256 + XB * SB * XT : NB * BUF + NW * 4];
   float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + (PS ? 0 : NB * BUF));          // (!PS only)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the staging bases below live in SGPRs)
   const int fw = wave % NF, sb = wave / NF;
@@ -1474,7 +1478,10 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     beps_pre = bias_eps(p, n, s, gs, do_dump);
   }
   stage(0, 0);
-  if (NB == 3) {
+  if (PS && XB == 3) {
+    stage_sel(ksteps > 1 ? 1 : 0, 0, 1, std::false_type{}, std::true_type{});      // x of step 1 (a one-step layer: a clamped re-read)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (NB == 3) {
     // two k-steps of run-ahead (build knob BNN_GEMM_RING=3, tools/build_k1b2_variants.sh): step 1 is in flight while step
     // 0's pieces are waited for (a one-step layer issues a clamped re-read of step 0 into the idle buffer 1 so that the
     // counted wait holds on every path)
@@ -1505,15 +1512,16 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     // tuning build only (wrong results; tools/k1b_ablate.py): BNN_TUNE_K1B bit 0 = no barrier, 1 = no waits, 3 = no DMA (the LDS
     // reads of the parameters stay: stale bytes, the same vector work), 4 = no x reads, 5 = no MFMAs
     if (staged && !(p.tune & 8)) {
-      if (PS) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});
-      else stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+      if (PS && XB == 2) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});
+      else if (!PS) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     }
 #else
     if (staged) {
-      if (PS) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});      // x of step t + 1 now, its parameters below
-      else stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+      if (PS && XB == 2) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});      // x of step t + 1 now, its parameters below
+      else if (!PS) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     }
 #endif
+    const bool x_ahead = PS && XB == 3 && t + 2 < ksteps;        // block-uniform: this step requests the x pieces of step t + 2
     // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
     // flight that may alias it -- s_waitcnt vmcnt(0) right behind the prefetch this step has just issued -- although
     // buffer t & 1 was complete at the last barrier.  The "+v" operands of the wait tie the consumers to it; the outputs
@@ -1528,9 +1536,11 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #ifdef BNN_TUNE
-      if (staged && !(p.tune & 8)) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+      if (t + 1 < ksteps && !(p.tune & 8)) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+      if (x_ahead && !(p.tune & 8)) stage_sel(t + 2, 0, cur == 0 ? 2 : cur - 1, std::false_type{}, std::true_type{});
 #else
-      if (staged) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+      if (t + 1 < ksteps) stage_sel(t + 1, 0, 0, std::true_type{}, std::false_type{});
+      if (x_ahead) stage_sel(t + 2, 0, cur == 0 ? 2 : cur - 1, std::false_type{}, std::true_type{});   // slot (cur + 2) % 3, behind the parameters
 #endif
     }
     const f32x2 mu2[4] = {{m_lo[0], m_lo[1]}, {m_lo[2], m_lo[3]}, {m_hi[0], m_hi[1]}, {m_hi[2], m_hi[3]}};
@@ -1661,12 +1671,14 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     // WPW + XPW of them are younger than step t + 1's pieces whenever this step staged anything.
 #ifdef BNN_TUNE
     if (!(p.tune & 2)) {
-      if (NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
+      if (x_ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XPW) : "memory");
+      else if (!PS && NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     if (!(p.tune & 1)) __builtin_amdgcn_s_barrier();
 #else
-    if (NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
+    if (x_ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XPW) : "memory");     // the x pieces of step t + 2 stay in flight
+    else if (!PS && NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
@@ -1677,9 +1689,9 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     const int full_steps = tiles_full ? (K >> 5) : 0;           // steps whose 32 k are all inside K
     int t = 0, cur = 0;
 #pragma nounroll
-    for (; t < full_steps; ++t, cur = (cur + 1 == NB ? 0 : cur + 1)) step(t, cur, std::true_type{});
+    for (; t < full_steps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1)) step(t, cur, std::true_type{});
 #pragma nounroll
-    for (; t < ksteps; ++t, cur = (cur + 1 == NB ? 0 : cur + 1)) step(t, cur, std::false_type{});
+    for (; t < ksteps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1)) step(t, cur, std::false_type{});
   }
 
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
