@@ -336,6 +336,59 @@ __global__ __launch_bounds__(kBgThreads, 2) void bbb_block_gemm_kernel(const Blo
   // m0 + 128 mh + 64 wr + 16 mi + r, features n0 + 128 nh + 32 wc + 16 ni + 4 q + {0..3}
   const bool vec = (N & 3) == 0;
   const float* bs = p.bias ? p.bias + (size_t)s * N : nullptr;
+#ifndef BG_NO_WIDE_STORES
+  if (p.y_bf16 && (N & 7) == 0 && !(reinterpret_cast<uintptr_t>(p.y) & 15) && !(BG_ABL & 8)) {
+    // bf16 output, 16-byte stores (the store tail of this kernel is issue-bound: every block reaches its epilogue at once,
+    // 32 eight-byte stores per lane).  Lanes (r, q) and (r, q ^ 1) hold neighbouring 4-feature groups of the SAME batch row in
+    // each of the two feature tiles ni = 0, 1 of a W half; one v_permlane16_swap per packed dword hands the even row of 16 lanes
+    // its partner's group of tile 0 and the odd row its partner's group of tile 1: every lane then owns 8 consecutive
+    // features -- [own | partner's] of tile 0 in the even rows, [partner's | own] of tile 1 in the odd rows -- and stores
+    // them with one instruction: 16 stores per lane instead of 32, the same bytes at the same addresses.
+    const int qe = q & ~1;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      float bv[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + nh * 128 + wc * 32 + ni * 16 + q * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[ni][j] = 0.f;
+        if (bs && n < N) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bs + n);
+          bv[ni][0] = b4.x; bv[ni][1] = b4.y; bv[ni][2] = b4.z; bv[ni][3] = b4.w;
+        }
+      }
+      const int n8 = n0 + nh * 128 + wc * 32 + (q & 1) * 16 + qe * 4;     // first of this lane's 8 features after the exchange
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          uint32_t pk[2][2];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = acc[mh][mi][nh][ni][j] + bv[ni][j];
+              if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+            pk[ni][0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t));
+            pk[ni][1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t));
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          const int m = m0 + mh * 128 + wr * 64 + mi * 16 + r;
+          if (m < M && n8 < N) {
+            const size_t o = ((size_t)s * M + m) * (size_t)N + n8;
+            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.y) + o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        }
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
 #pragma unroll

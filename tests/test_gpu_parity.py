@@ -1871,3 +1871,24 @@ def test_split_bf16_math_through_the_drop_in_module(dev):
             close(a, b, rtol=0.0 if lr else 1e-4)
         for a, b in zip(g3, g32):
             assert np.abs(a - b).max() <= (0.0 if lr else 2e-4) * (np.abs(b).max() + 1e-12)
+    # the forward-only product paths on on-chip epsilon (engine.run_layers: the input cast to a plane pair from 4 samples on,
+    # plane pairs between the layers, the tile / block forms as the plans choose): sample_elbo under no_grad, predict_mc and
+    # forward_mc in split-bf16 math against exact-fp32 math on the same Philox indices, C2-sized layers
+    dims, B = (784, 1200, 10), 128
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        bnn_hip.set_math(mode)
+        net, sd = build_net(dev, False, dims, "classification", B=B)
+        x, y = synth.synth_batch("classification", B, dims[0], dims[2], seed=5)
+        xd, yd = t(x).to(dev), t(y).to(dev)
+        bnn_hip.manual_seed(77, counter=0)
+        with torch.no_grad():
+            e1 = net.sample_elbo(xd, yd, 2.0 ** -10, 1)
+            e8 = net.sample_elbo(xd, yd, 2.0 ** -10, 8)
+            lg = net.forward_mc(xd, 10)
+            preds, probs = net.predict_mc(xd, 10)
+        res[mode] = ([v.double().cpu().numpy() for v in e1 + e8], lg.double().cpu().numpy(), probs.double().cpu().numpy())
+    for a, b in zip(res["bf16x3"][0], res["f32"][0]):
+        close(a, b, rtol=1e-4)
+    assert np.abs(res["bf16x3"][1] - res["f32"][1]).max() <= 1e-4 * np.abs(res["f32"][1]).max()
+    assert np.abs(res["bf16x3"][2] - res["f32"][2]).max() <= 1e-4
