@@ -1335,6 +1335,9 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 #ifndef BNN_K1B2_WPS
 #define BNN_K1B2_WPS 4      // build knob: waves per SIMD the register allocation aims at
 #endif
+#ifndef BNN_K1B2_SPREAD
+#define BNN_K1B2_SPREAD 0   // build knob: the four staging pieces of a step spread over the previous step (K2_STAGE_PIECE) instead of all at its top.  Measured (profiles/r04_k1b2_spread.log): eps = 0 launches 304 -> 294 us, launches with the generator 348 -> 353: off
+#endif
 template <int NF, int SB, int EPS, int NB = 2, bool X3 = false>
 __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd_gemm2_kernel(const BbbK p) {
   constexpr int NW = NF * SB;
@@ -1434,6 +1437,26 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       }
     }
   };
+  // ONE piece of step t's staging (full steps only), pinned in the instruction stream by `tie`: a value computed just before and
+  // consumed just after.  All four pieces of a wave issued back to back at the top of a step queue behind the other fifteen
+  // waves' pieces in the CU's one vector-memory pipe (64 B per clock: the 64 KiB the CU's two blocks request per step take it
+  // ~1000 cycles) and the wave cannot issue anything else meanwhile -- in-kernel stamps: 1370 of a wave-step's ~2800 cycles
+  // between the top of a step and its parameter fragments (tools/stamps_k1b2.py, profiles/r04_k1b2_stamps.log).  Spread over
+  // the step -- top, behind the parameter reads, behind the generator, behind the packing of w -- a piece meets a drained pipe.
+  // (a macro, not a generic lambda: `tie` is a float, a uint32_t or a 4-register vector; IDX is a literal)
+#define K2_STAGE_PIECE(T, BUF, IDX, TIE)                                                                                                   \
+  do {                                                                                                                                     \
+    if ((IDX) < WPW) {                                                                                                                     \
+      const int j_ = sb * WPW + (IDX);                                                                                                     \
+      const char* base_ = reinterpret_cast<const char*>((j_ & 2) ? p.w_sigma : p.w_mu) + (size_t)(T) * 128 + (j_ & 1) * 16;               \
+      const uint32_t m0v_ = lds0 + (uint32_t)((p_idx(BUF) + (fw * 4 + j_) * 64) * 16);                                                     \
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : "+v"(TIE) : "v"(voff_w), "s"(base_), "s"(m0v_) : "memory", "m0"); \
+    } else {                                                                                                                               \
+      const char* base_ = reinterpret_cast<const char*>(xs) + (size_t)(T) * 64;                                                            \
+      const uint32_t m0v_ = lds0 + (uint32_t)((x_idx(BUF) + sb * XT + (fw + ((IDX) - WPW) * NF) * 64) * 16);                               \
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : "+v"(TIE) : "v"(voff_x[((IDX) - WPW) % XPW]), "s"(base_), "s"(m0v_) : "memory", "m0"); \
+    }                                                                                                                                      \
+  } while (0)
   auto stage_slow = [&](int t, int pbuf, int xbuf, auto wp_, auto wx_) __attribute__((always_inline)) {
     const int kk = min(t * 32 + q * 8, K - 8);
     if (decltype(wp_)::value) {
@@ -1502,10 +1525,20 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
   // compiled out; the statistics and w run two lanes-worth per instruction (v_pk_fma_f32).  The kernel is bound by its
   // vector instruction stream once the parameters come through LDS (tools/k1b_ablate.py), so every one of them counts.
   typedef __attribute__((ext_vector_type(2))) float f32x2;
+#ifdef BNN_STAMPS
+  // diagnostic build: shader-clock time of every wave's step phases, summed over the steps (tools/stamps_k1b2.py):
+  // [0] staging issue + parameter reads, [1] generator / w / statistics, [2] x reads + MFMAs, [3] the closing vmcnt / lgkmcnt
+  // wait, [4] the barrier
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#define K2_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define K2_T(v)
+#endif
   auto step = [&](int t, int cur, auto full_) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_)::value;
     const int k = t * 32 + q * 8;
     const bool lane_ok = FULL || (n_ok && k < K);
+    K2_T(st0);
     // the buffer staged here was last read in step t - 1 (barrier since)
     const bool staged = t + NB - 1 < ksteps;                     // block-uniform
 #ifdef BNN_TUNE
@@ -1516,10 +1549,15 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       else if (!PS) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     }
 #else
-    if (staged) {
+    // (spread: the four pieces of step t + 1 at four points of this step instead of here -- see stage_piece)
+    const bool spread = BNN_K1B2_SPREAD && !PS && NB == 2 && WPW + XPW == 4 && staged && (t + 2) * 32 <= K;     // block-uniform
+    if (staged && !spread) {
       if (PS && XB == 2) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});      // x of step t + 1 now, its parameters below
       else if (!PS) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     }
+    uint32_t tie0 = voff_w;
+    if (spread) K2_STAGE_PIECE(t + 1, cur ^ 1, 2, tie0);            // an x piece first: the pieces longest in flight are the ones the
+                                                                 // next step reads last
 #endif
     const bool x_ahead = PS && XB == 3 && t + 2 < ksteps;        // block-uniform: this step requests the x pieces of step t + 2
     // LDS reads by hand (ds_read_b128 in asm): a compiler-visible read of `sm` would be ordered behind EVERY LDS-DMA in
@@ -1543,12 +1581,21 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       if (x_ahead) stage_sel(t + 2, 0, cur == 0 ? 2 : cur - 1, std::false_type{}, std::true_type{});   // slot (cur + 2) % 3, behind the parameters
 #endif
     }
+    K2_T(st1);
+#ifndef BNN_TUNE
+    if (spread) K2_STAGE_PIECE(t + 1, cur ^ 1, 3, m_lo);
+#endif
     const f32x2 mu2[4] = {{m_lo[0], m_lo[1]}, {m_lo[2], m_lo[3]}, {m_hi[0], m_hi[1]}, {m_hi[2], m_hi[3]}};
     const f32x2 sg2[4] = {{g_lo[0], g_lo[1]}, {g_lo[2], g_lo[3]}, {g_hi[0], g_hi[1]}, {g_hi[2], g_hi[3]}};
     float e[8];
     if (EPS == BNN_EPS_PHILOX) {
       const uint32_t g = (uint32_t)n * (uint32_t)gpr + (uint32_t)(k >> 2);
-      philox_normal8(g, gs, wid, p.k0, p.k1, e);
+      uint4 pa_, pb_;
+      philox_pair<>(g, gs, wid, p.k0, p.k1, pa_, pb_);
+#ifndef BNN_TUNE
+      if (spread) K2_STAGE_PIECE(t + 1, cur ^ 1, 0, pa_.x);          // between the integer and the transcendental half
+#endif
+      box_muller8(pa_, pb_, e);
     } else if (EPS == BNN_EPS_MEMORY) {
       load8<true>(p.eps_w + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
     } else {
@@ -1556,6 +1603,10 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       for (int j = 0; j < 8; ++j) e[j] = 0.f;
     }
     if (p.eps_w_dump && do_dump) store8<true>(p.eps_w_dump + ((size_t)s * N + n) * K + k, lane_ok ? 8 : 0, e);
+#ifndef BNN_TUNE
+    if (spread) K2_STAGE_PIECE(t + 1, cur ^ 1, 1, e[0]);             // behind the generator (EPS != PHILOX: the third and fourth piece
+    if (spread && EPS != BNN_EPS_PHILOX) K2_STAGE_PIECE(t + 1, cur ^ 1, 0, e[1]);   // both here)
+#endif
     f32x2 w2[4], e2v = {0.f, 0.f}, av = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1612,6 +1663,10 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
         wa[2 * j + 1] = lane_ok ? (__bf16)w2[j][1] : (__bf16)0.f;
       }
     }
+#ifdef BNN_STAMPS
+    asm volatile("" :: "v"(wa));
+#endif
+    K2_T(st2);
     const uint32_t xa = lds0 + (uint32_t)((x_idx(cur) + sb * XT + q * 16 + r) * 16);
 #ifdef BNN_TUNE
     const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
@@ -1677,12 +1732,21 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     }
     if (!(p.tune & 1)) __builtin_amdgcn_s_barrier();
 #else
+#ifdef BNN_STAMPS
+    asm volatile("" :: "v"(acc[0]), "v"(acc[7]));
+    K2_T(st3);
+#endif
     if (x_ahead) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XPW) : "memory");     // the x pieces of step t + 2 stay in flight
     else if (!PS && NB == 3 && staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WPW + XPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    K2_T(st4);
     __builtin_amdgcn_s_barrier();
 #endif
     asm volatile("" ::: "memory");
+#ifdef BNN_STAMPS
+    K2_T(st5);
+    ph[0] += st1 - st0; ph[1] += st2 - st1; ph[2] += st3 - st2; ph[3] += st4 - st3; ph[4] += st5 - st4;
+#endif
   };
   {
     const bool tiles_full = (tb * NF + NF) * 16 <= N;           // block-uniform
@@ -1694,6 +1758,14 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     for (; t < ksteps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1)) step(t, cur, std::false_type{});
   }
 
+#ifdef BNN_STAMPS
+  if (p.dbg && lane == 0 && blockIdx.x < 1024) {               // per wave: the five phase sums + the step count
+    unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+    d[0] = ph[0]; d[1] = ph[1]; d[2] = ph[2]; d[3] = ph[3]; d[4] = ph[4]; d[5] = (unsigned long long)ksteps;
+  }
+#endif
+#undef K2_T
+#undef K2_STAGE_PIECE
   // ---- epilogue: bias, stats, store (no cross-wave reduction)
   float b_own = 0.f;                                           // lanes 0 .. 15 (q == 0): the sampled bias of feature r
   if (q == 0) {

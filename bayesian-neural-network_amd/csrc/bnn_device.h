@@ -63,15 +63,11 @@ __device__ __forceinline__ void philox_normal4(uint32_t group, uint32_t gsample,
 // critical path is then 2 x ROUNDS rounds deep, and three or four waves per SIMD do not cover it: the counters show the
 // waves issue-stalled a third of the time).  Interleaved round by round the chain is ROUNDS deep with four independent
 // multiplies per level.  Same arithmetic, same bits.
+// (in two halves, so that a kernel can place other work -- an LDS-DMA piece -- between the integer and the transcendental part)
 template <int ROUNDS = BNN_PHILOX_ROUNDS>
-__device__ __forceinline__ void philox_normal8(uint32_t group, uint32_t gsample, uint32_t tensor_id, uint32_t k0, uint32_t k1,
-                                               float out[8]) {
-#ifdef BNN_PHILOX_SEQ       // A/B build knob (tools/): the two calls one after the other, as rounds 1-3 wrote them
-  philox_normal4(group, gsample, tensor_id, k0, k1, out);
-  philox_normal4(group + 1u, gsample, tensor_id, k0, k1, out + 4);
-  return;
-#endif
-  uint4 a = make_uint4(group, gsample, tensor_id, 0u), b = make_uint4(group + 1u, gsample, tensor_id, 0u);
+__device__ __forceinline__ void philox_pair(uint32_t group, uint32_t gsample, uint32_t tensor_id, uint32_t k0, uint32_t k1, uint4& a, uint4& b) {
+  a = make_uint4(group, gsample, tensor_id, 0u);
+  b = make_uint4(group + 1u, gsample, tensor_id, 0u);
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
     const uint64_t pa0 = (uint64_t)a.x * 0xD2511F53u, pb0 = (uint64_t)b.x * 0xD2511F53u;
@@ -81,7 +77,9 @@ __device__ __forceinline__ void philox_normal8(uint32_t group, uint32_t gsample,
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  // four Box-Muller pairs, level by level: the uniforms, the four logarithms, the four square roots, the sines / cosines
+}
+// four Box-Muller pairs, level by level: the uniforms, the four logarithms, the four square roots, the sines / cosines
+__device__ __forceinline__ void box_muller8(const uint4& a, const uint4& b, float out[8]) {
   const float u[8] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z), u01(b.w)};
   float rad[4];
 #pragma unroll
@@ -93,6 +91,18 @@ __device__ __forceinline__ void philox_normal8(uint32_t group, uint32_t gsample,
     out[2 * j] = rad[j] * __builtin_amdgcn_cosf(u[2 * j + 1]);
     out[2 * j + 1] = rad[j] * __builtin_amdgcn_sinf(u[2 * j + 1]);
   }
+}
+template <int ROUNDS = BNN_PHILOX_ROUNDS>
+__device__ __forceinline__ void philox_normal8(uint32_t group, uint32_t gsample, uint32_t tensor_id, uint32_t k0, uint32_t k1,
+                                               float out[8]) {
+#ifdef BNN_PHILOX_SEQ       // A/B build knob (tools/): the two calls one after the other, as rounds 1-3 wrote them
+  philox_normal4(group, gsample, tensor_id, k0, k1, out);
+  philox_normal4(group + 1u, gsample, tensor_id, k0, k1, out + 4);
+  return;
+#endif
+  uint4 a, b;
+  philox_pair<ROUNDS>(group, gsample, tensor_id, k0, k1, a, b);
+  box_muller8(a, b, out);
 }
 
 // ---------------------------------------------------------------------------- math
