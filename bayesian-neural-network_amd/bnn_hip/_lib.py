@@ -216,6 +216,11 @@ def load():
         raise BnnHipError(
             f"{LIB_PATH} not found: build it with `make -C bayesian-neural-network_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the hot path.")
+    # torch FIRST: the wheel bundles its own libamdhip64 (soname libamdhip64.so.7, like /opt/rocm's, which libbnn_hip.so names).
+    # Loaded after torch, this library binds to the runtime torch has already mapped -- one HIP runtime in the process.  Loaded
+    # before it, the process ends up with two, the tensors' device belongs to the other one and the first launch returns
+    # hipErrorNoDevice (seen as `python __graft_entry__.py smoke`: build() loaded the library before anything imported torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     missing = [s for s in EXPORTS if not hasattr(lib, s)]
     if missing:

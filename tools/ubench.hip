@@ -2,6 +2,7 @@
 // building blocks on one SIMD, at 1..4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <algorithm>
 #include "../bayesian-neural-network_amd/csrc/bnn_device.h"
@@ -47,6 +48,52 @@ __device__ __forceinline__ void normal8_16bit(uint32_t g, uint32_t s, float out[
   bm16(r.y >> 16, r.y & 0xFFFFu, out[2], out[3]);
   bm16(r.z >> 16, r.z & 0xFFFFu, out[4], out[5]);
   bm16(r.w >> 16, r.w & 0xFFFFu, out[6], out[7]);
+}
+// epsilon-map v3 candidate (round-3 verdict, item 2): 40 bits per Box-Muller pair -- a 24-bit radius uniform (tail sqrt(2 ln 2^25) =
+// 5.89 sigma, what a 24-bit fp32 uniform gives) and a 16-bit angle (v_sin / v_cos take revolutions) -- so ONE Philox call yields
+// three pairs = 6 normals instead of 4.  Word w of (x, y, z) carries a pair's radius in its upper 24 bits and the high byte of its
+// angle in its low byte; the angle's low byte is byte w of the fourth word.
+__device__ __forceinline__ void bm_v3(uint32_t word, uint32_t lowbyte, float& n0, float& n1) {
+  const float u1 = __builtin_fmaf((float)(word >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);   // (r24 + 0.5) / 2^24
+  const float u2 = (float)(((word & 0xFFu) << 8) | lowbyte) * 1.52587890625e-05f;                              // a16 / 2^16 revolutions
+  const float rad = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
+}
+template <int R>
+__device__ __forceinline__ void normal6_v3(uint32_t g, uint32_t s, float out[6]) {
+  const uint4 r = philox_r<R, false>(make_uint4(g, s, 3u, 0u), 1u, 2u);
+  bm_v3(r.x, r.w & 0xFFu, out[0], out[1]);
+  bm_v3(r.y, (r.w >> 8) & 0xFFu, out[2], out[3]);
+  bm_v3(r.z, (r.w >> 16) & 0xFFu, out[4], out[5]);
+}
+// 24 weights (three k-steps of a lane) around a generator: GEN 0 = map v2 (6 Philox-7 calls, 4 normals each), 1 = map v3 candidate
+// (4 calls, 6 normals each); the same w / statistics / pack work either way
+template <int GEN>
+__device__ __forceinline__ float k1b_body24(uint32_t x, int i, float f) {
+  float e[24];
+  if (GEN == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) normal4_r<7, false>(x + c, i, e + 4 * c);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) normal6_v3<7>(x + c, i, e + 6 * c);
+  }
+  float e2 = 0.f, a = 0.f, acc = 0.f;
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    bf16x8 wa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = __builtin_fmaf(f + j, e[h * 8 + j], f * 0.5f);
+      e2 = __builtin_fmaf(e[h * 8 + j], e[h * 8 + j], e2);
+      a = __builtin_fmaf(w, w, a);
+      wa[j] = (__bf16)w;
+    }
+    const float4 pk = __builtin_bit_cast(float4, wa);
+    acc += pk.x + pk.y + pk.z + pk.w;
+  }
+  return e2 + a + acc;
 }
 // the per-8-weights body of K1b around a generator G: w = mu + sigma * eps, sum eps^2, sum w^2, bf16 pack
 template <int GEN>
@@ -111,6 +158,10 @@ __global__ void k(unsigned long long* out, float* sink, int iters) {
       acc += k1b_body<2>(x, i, f); x += 2;
     } else if (WHAT == 12) { // K1b body: one philox-7, 16-bit uniforms
       acc += k1b_body<3>(x, i, f); x += 2;
+    } else if (WHAT == 13) { // 24 weights, map v2: 6 philox-7 calls
+      acc += k1b_body24<0>(x, i, f); x += 6;
+    } else if (WHAT == 14) { // 24 weights, map v3 candidate: 4 philox-7 calls, 24-bit radius / 16-bit angle
+      acc += k1b_body24<1>(x, i, f); x += 4;
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -121,10 +172,11 @@ __global__ void k(unsigned long long* out, float* sink, int iters) {
 int main() {
   const char* names[] = {"philox4x32_10 (4 u32)", "philox_normal4 (4 normals)", "softplus x8", "16 mad_u64_u32 (+32 xor)", "16 fma (+16 add)", "box_muller x2 (4 normals)",
                          "normal4, philox-10 mul_hi+mul_lo", "normal4, philox-7", "normal8, 1 philox-10, 16-bit u", "K1b body/8w: 2 philox-10",
-                         "K1b body/8w: 2 philox-7", "K1b body/8w: 1 philox-10 16b", "K1b body/8w: 1 philox-7 16b"};
+                         "K1b body/8w: 2 philox-7", "K1b body/8w: 1 philox-10 16b", "K1b body/8w: 1 philox-7 16b",
+                         "body/24w: 6 philox-7 (map v2)", "body/24w: 4 philox-7 (v3: 24b/16b)"};
   unsigned long long* d; float* s; hipMalloc(&d, 1 << 20); hipMalloc(&s, 64 << 20);
   const int iters = 2000;
-  for (int what = 0; what < 13; ++what) {
+  for (int what = (getenv("UBENCH_FROM") ? atoi(getenv("UBENCH_FROM")) : 0); what < 15; ++what) {
     for (int wps = 1; wps <= 4; ++wps) {   // waves per SIMD: block = wps*4 waves, one block per CU
       dim3 grid(256), block(wps * 256);
       for (int rep = 0; rep < 3; ++rep) {
@@ -142,6 +194,8 @@ int main() {
           case 10: hipLaunchKernelGGL(k<10>, grid, block, 0, 0, d, s, iters); break;
           case 11: hipLaunchKernelGGL(k<11>, grid, block, 0, 0, d, s, iters); break;
           case 12: hipLaunchKernelGGL(k<12>, grid, block, 0, 0, d, s, iters); break;
+          case 13: hipLaunchKernelGGL(k<13>, grid, block, 0, 0, d, s, iters); break;
+          case 14: hipLaunchKernelGGL(k<14>, grid, block, 0, 0, d, s, iters); break;
         }
       }
       hipDeviceSynchronize();
