@@ -1335,6 +1335,9 @@ __global__ __launch_bounds__(NW * 64, 4) void bbb_fwd_gemm_kernel(const BbbK p) 
 #ifndef BNN_K1B2_WPS
 #define BNN_K1B2_WPS 4      // build knob: waves per SIMD the register allocation aims at
 #endif
+#ifndef BNN_K1B2_STAG
+#define BNN_K1B2_STAG 0     // the second pair's waves one MFMA phase behind the first pair's (see STAG in the kernel); 0: in lockstep
+#endif
 #ifndef BNN_K1B2_SPREAD
 #define BNN_K1B2_SPREAD 0   // build knob: the four staging pieces of a step spread over the previous step (K2_STAGE_PIECE) instead of all at its top.  Measured (profiles/r04_k1b2_spread.log): eps = 0 launches 304 -> 294 us, launches with the generator 348 -> 353: off
 #endif
@@ -1354,12 +1357,25 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
   constexpr int XB = (PS && !X3 && BNN_K1B2_PS == 2) ? 3 : 2;
   constexpr int RB = PS ? XB : NB;            // buffers the step index cycles through
   constexpr int BUF = NF * 256 + SB * XT;     // float4s of one staging buffer of the double-buffered-everything layout
+  // STAG (bf16 form, two pairs): the waves of the block's SECOND pair run their x reads + MFMAs of step t - 1 at the START of step
+  // t.  A CU's SIMD holds wave fw of the first pair and wave fw of the second: in lockstep both queue for the vector-memory pipe
+  // at the top of a step (half of a wave's step, tools/stamps_k1b2.py), both run their generator next, both their MFMAs last.
+  // One phase apart, the second pair's LDS reads and MFMAs run beside the first pair's staging burst, its staging beside the
+  // first pair's parameter reads, its generator beside the first pair's MFMAs.  The late pair keeps its weight fragment over the
+  // barrier (4 registers) and its x tile one step longer: a ring of THREE x slots for that pair (the two in the staging buffers
+  // + one more 8 KiB behind the bias table), since its waves request x of step t + 1 while others of them still read x of step
+  // t - 1.  Same arithmetic in the same order per accumulator: same bits.
+#if defined(BNN_TUNE) || defined(BNN_STAMPS)
+  constexpr bool STAG = false;
+#else
+  constexpr bool STAG = BNN_K1B2_STAG && !X3 && !(BNN_K1B2_PS && NB == 2) && NB == 2 && SB == 2;
+#endif
   // LDS image, in float4s.  !PS: [buffer][NF tiles' parameter pieces | SB pairs' x tiles], then the bias table.
   //                          PS: [parameter pieces][x buffer 0][x buffer 1].
   auto p_idx = [](int buf) { return PS ? 0 : buf * BUF; };
   auto x_idx = [](int buf) { return PS ? NF * 256 + buf * (SB * XT) : buf * BUF + NF * 256; };
   // ONE shared object (the guide's second-__shared__-object trap), the staging buffers first
-  __shared__ __attribute__((aligned(16))) float4 sm_all[PS ? NF * 256 + XB * SB * XT : NB * BUF + NW * 4];
+  __shared__ __attribute__((aligned(16))) float4 sm_all[PS ? NF * 256 + XB * SB * XT : NB * BUF + NW * 4 + (STAG ? XT : 0)];
   float (*bias_s)[16] = reinterpret_cast<float (*)[16]>(sm_all + (PS ? 0 : NB * BUF));          // (!PS only)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the staging bases below live in SGPRs)
   const int fw = wave % NF, sb = wave / NF;
@@ -1407,6 +1423,10 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
 #pragma unroll
   for (int i = 0; i < XPW; ++i) voff_x[i] = ((uint32_t)xrow[i] + (uint32_t)(q * 8)) * 2u;
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&sm_all[0];
+  // float4 index of this wave's pair's x tile `slot`: the pair's region of staging buffer `slot`, or (STAG, the late pair's
+  // third slot) the region behind the bias table
+  const bool late = STAG && sb == 1;                            // wave-uniform
+  auto x_slot = [&](int slot) { return (STAG && slot == 2) ? NB * BUF + NW * 4 : x_idx(slot) + sb * XT; };
   // (the plan takes this form only where the tensors' byte spans fit 32 bits)
   // WP / WX (compile-time): stage the parameter pieces / the x pieces of step t (the PS form requests them at different points
   // of a step, into different buffer indices)
@@ -1424,7 +1444,7 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
 #pragma unroll
       for (int i = 0; i < XPW; ++i) {
         const char* base = reinterpret_cast<const char*>(xs) + (size_t)t * 64;
-        const uint32_t m0v = lds0 + (uint32_t)((x_idx(xbuf) + sb * XT + (fw + i * NF) * 64) * 16);
+        const uint32_t m0v = lds0 + (uint32_t)((x_slot(xbuf) + (fw + i * NF) * 64) * 16);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_x[i]), "s"(base), "s"(m0v) : "memory", "m0");
       }
       if (X3) {
@@ -1476,7 +1496,7 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
 #pragma unroll
       for (int i = 0; i < XPW; ++i) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + xrow[i] + kk),
-                                         (__attribute__((address_space(3))) void*)&sm_all[x_idx(xbuf) + sb * XT + (fw + i * NF) * 64], 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)&sm_all[x_slot(xbuf) + (fw + i * NF) * 64], 16, 0, 0);
       }
       if (X3) {
 #pragma unroll
@@ -1534,11 +1554,72 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
 #else
 #define K2_T(v)
 #endif
-  auto step = [&](int t, int cur, auto full_) __attribute__((always_inline)) {
+  // x reads + MFMAs of one k-step: the weight fragment `wa` (and its low half `wl`, X3) against the pair's x tile at float4 index xi
+  auto mfma_phase = [&](const bf16x8& wa, const bf16x8& wl, int xi, const f32x4& m_lo) __attribute__((always_inline)) {
+    const uint32_t xa = lds0 + (uint32_t)((xi + q * 16 + r) * 16);
+#ifdef BNN_TUNE
+    const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
+#else
+    constexpr bool tune_nolds = false, tune_nomfma = false;
+#endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 x0, x1, x2, x3;
+      if (tune_nolds) {
+        x0 = x1 = x2 = x3 = m_lo;
+      } else if (h == 0)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
+      else
+        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
+      if (X3) {
+        // the lo plane's four fragments are requested behind the hi plane's: the hi products (two MFMAs per batch tile) run
+        // while they are in flight
+        f32x4 l0, l1, l2, l3;
+        if (h == 0)
+          asm volatile("ds_read_b128 %0, %4 offset:8192\n\tds_read_b128 %1, %4 offset:9216\n\tds_read_b128 %2, %4 offset:10240\n\tds_read_b128 %3, %4 offset:11264"
+                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
+        else
+          asm volatile("ds_read_b128 %0, %4 offset:12288\n\tds_read_b128 %1, %4 offset:13312\n\tds_read_b128 %2, %4 offset:14336\n\tds_read_b128 %3, %4 offset:15360"
+                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l3), acc[h * 4 + 3], 0, 0, 0);
+        continue;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      if (!tune_nomfma) {
+        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
+        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
+        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
+        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
+      } else {
+        asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(wa));
+      }
+    }
+  };
+  bf16x8 wa_prev = {};                                             // (STAG) the late pair's weight fragment of the step before
+  // cur: the staging buffer of step t (t % RB); c3 (STAG): t % 3, the late pair's x slot of step t
+  auto step = [&](int t, int cur, int c3, auto full_) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_)::value;
     const int k = t * 32 + q * 8;
     const bool lane_ok = FULL || (n_ok && k < K);
     K2_T(st0);
+    if (STAG) {
+      if (late && t > 0) mfma_phase(wa_prev, wa_prev, x_slot(c3 == 0 ? 2 : c3 - 1), f32x4{0.f, 0.f, 0.f, 0.f});   // wave-uniform branch
+    }
     // the buffer staged here was last read in step t - 1 (barrier since)
     const bool staged = t + NB - 1 < ksteps;                     // block-uniform
 #ifdef BNN_TUNE
@@ -1550,9 +1631,10 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     }
 #else
     // (spread: the four pieces of step t + 1 at four points of this step instead of here -- see stage_piece)
-    const bool spread = BNN_K1B2_SPREAD && !PS && NB == 2 && WPW + XPW == 4 && staged && (t + 2) * 32 <= K;     // block-uniform
+    const bool spread = BNN_K1B2_SPREAD && !STAG && !PS && NB == 2 && WPW + XPW == 4 && staged && (t + 2) * 32 <= K;     // block-uniform
     if (staged && !spread) {
       if (PS && XB == 2) stage_sel(t + 1, 0, cur ^ 1, std::false_type{}, std::true_type{});      // x of step t + 1 now, its parameters below
+      else if (STAG) stage_sel(t + 1, cur ^ 1, late ? (c3 == 2 ? 0 : c3 + 1) : (cur ^ 1), std::true_type{}, std::true_type{});
       else if (!PS) stage(t + NB - 1, NB == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     }
     uint32_t tie0 = voff_w;
@@ -1640,7 +1722,7 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
       s_a += lane_ok ? a : 0.f;
       s_ls += lane_ok ? ls : 0.f;
     }
-    bf16x8 wa, wl;
+    bf16x8 wa, wl = {};
     if (X3) {
       // the split pair, two weights per instruction where the ISA has one: hi = cvt_pk(w0, w1); its two floats by a shift and
       // a mask of the packed word; the exact differences; lo = cvt_pk(d0, d1): 6 vector instructions per two weights
@@ -1667,59 +1749,8 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
     asm volatile("" :: "v"(wa));
 #endif
     K2_T(st2);
-    const uint32_t xa = lds0 + (uint32_t)((x_idx(cur) + sb * XT + q * 16 + r) * 16);
-#ifdef BNN_TUNE
-    const bool tune_nolds = (p.tune & 16) != 0, tune_nomfma = (p.tune & 32) != 0;
-#else
-    constexpr bool tune_nolds = false, tune_nomfma = false;
-#endif
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x4 x0, x1, x2, x3;
-      if (tune_nolds) {
-        x0 = x1 = x2 = x3 = m_lo;
-      } else if (h == 0)
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
-      else
-        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\tds_read_b128 %3, %4 offset:7168"
-                     : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xa));
-      if (X3) {
-        // the lo plane's four fragments are requested behind the hi plane's: the hi products (two MFMAs per batch tile) run
-        // while they are in flight
-        f32x4 l0, l1, l2, l3;
-        if (h == 0)
-          asm volatile("ds_read_b128 %0, %4 offset:8192\n\tds_read_b128 %1, %4 offset:9216\n\tds_read_b128 %2, %4 offset:10240\n\tds_read_b128 %3, %4 offset:11264"
-                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
-        else
-          asm volatile("ds_read_b128 %0, %4 offset:12288\n\tds_read_b128 %1, %4 offset:13312\n\tds_read_b128 %2, %4 offset:14336\n\tds_read_b128 %3, %4 offset:15360"
-                       : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(xa));
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
-        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
-        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
-        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
-        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
-        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
-        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
-        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
-        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l0), acc[h * 4 + 0], 0, 0, 0);
-        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l1), acc[h * 4 + 1], 0, 0, 0);
-        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l2), acc[h * 4 + 2], 0, 0, 0);
-        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, l3), acc[h * 4 + 3], 0, 0, 0);
-        continue;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-      if (!tune_nomfma) {
-        acc[h * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x0), acc[h * 4 + 0], 0, 0, 0);
-        acc[h * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1), acc[h * 4 + 1], 0, 0, 0);
-        acc[h * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x2), acc[h * 4 + 2], 0, 0, 0);
-        acc[h * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x3), acc[h * 4 + 3], 0, 0, 0);
-      } else {
-        asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(wa));
-      }
-    }
+    if (STAG && late) wa_prev = wa;                                // its products at the top of the next step
+    else mfma_phase(wa, wl, x_idx(cur) + sb * XT, m_lo);
     // this wave's DMA pieces of step t + 1 have landed and its LDS reads of buffer `cur` are back; then the block meets
     // (a bare s_barrier: __syncthreads()'s fence would add the same vmcnt(0)).  With three buffers the pieces of step
     // t + 2, issued at the top of this step, stay in flight: vector-memory operations complete in issue order, and
@@ -1751,11 +1782,14 @@ __global__ __launch_bounds__(NF * SB * 64, (X3 ? 4 : BNN_K1B2_WPS)) void bbb_fwd
   {
     const bool tiles_full = (tb * NF + NF) * 16 <= N;           // block-uniform
     const int full_steps = tiles_full ? (K >> 5) : 0;           // steps whose 32 k are all inside K
-    int t = 0, cur = 0;
+    int t = 0, cur = 0, c3 = 0;
 #pragma nounroll
-    for (; t < full_steps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1)) step(t, cur, std::true_type{});
+    for (; t < full_steps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1), c3 = (c3 == 2 ? 0 : c3 + 1)) step(t, cur, c3, std::true_type{});
 #pragma nounroll
-    for (; t < ksteps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1)) step(t, cur, std::false_type{});
+    for (; t < ksteps; ++t, cur = (cur + 1 == RB ? 0 : cur + 1), c3 = (c3 == 2 ? 0 : c3 + 1)) step(t, cur, c3, std::false_type{});
+    if (STAG) {
+      if (late) mfma_phase(wa_prev, wa_prev, x_slot(c3 == 0 ? 2 : c3 - 1), f32x4{0.f, 0.f, 0.f, 0.f});   // the late pair's last step (ksteps >= 1)
+    }
   }
 
 #ifdef BNN_STAMPS
@@ -2099,7 +2133,8 @@ static int bbb_plan(const bnn_bbb_fwd_args* a, bool al, BbbPlan& pl, bool allow_
     pl.nw = 4 * pairs;
     pl.blocks = (long)((N + 63) / 64) * (((long)S * mbs + pairs - 1) / pairs);
     // (split-bf16 form: one parameter buffer + two x buffers of a (hi, lo) plane pair per unit, no bias table)
-    pl.lds = x3 ? (4 * 256 + 2 * pairs * 1024) * 16 : kGemmRing * (4 * 256 + pairs * 512) * 16 + pl.nw * 16 * sizeof(float);
+    pl.lds = x3 ? (4 * 256 + 2 * pairs * 1024) * 16 : kGemmRing * (4 * 256 + pairs * 512) * 16 + pl.nw * 16 * sizeof(float) +
+                      ((BNN_K1B2_STAG && !BNN_K1B2_PS && kGemmRing == 2 && pairs == 2) ? 512 * 16 : 0);   // (the late pair's third x slot)
   }
   if (x3 && pl.pairs == 1) {                 // (the plain block-GEMM kernel has no split-bf16 variant)
     tile_plan(S, B, K, N, al, 8, pl);

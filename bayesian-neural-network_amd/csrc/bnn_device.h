@@ -235,6 +235,14 @@ __device__ __forceinline__ __bf16 split_lo(float v, __bf16 hi) { return (__bf16)
 // fp32 -> bf16 (RNE) cast of the input batch, once per ELBO evaluation, so that every layer of
 // the throughput path reads 2-byte activations (the x tile is then LDS-DMA'd as is).  Thread `tid` of `nt`.
 // dsq (optional): the squares; dlo (optional): the low plane of the split-bf16 pair.
+// The x^2 operand of the LR variance product in bf16 math (include/bnn_hip.h, BNN_MATH_BF16): the square of the ROUNDED
+// activation, rounded -- bf16(bf16(x)^2) -- whoever forms it: a producer's epilogue / the input cast (the `x_sq` stream K3b
+// reads) or a consumer squaring the bf16 fragment it loaded (K3a, K3s, K3r).  One value per element, whatever the launch plans.
+__device__ __forceinline__ __bf16 sq_bf16(float v) {
+  const float r = (float)(__bf16)v;
+  return (__bf16)(r * r);
+}
+
 __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __bf16* __restrict__ dst,
                                                __bf16* __restrict__ dsq, long n, int vec_ok, long tid, long nt,
                                                __bf16* __restrict__ dlo = nullptr) {
@@ -248,7 +256,7 @@ __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __
       for (int j = 0; j < 8; ++j) {
         v[j] = (__bf16)f[j];
         l[j] = split_lo(f[j], v[j]);
-        q[j] = (__bf16)(f[j] * f[j]);
+        q[j] = dlo ? (__bf16)(f[j] * f[j]) : sq_bf16(f[j]);
       }
       reinterpret_cast<bf16x8*>(dst)[i] = v;
       if (dsq) reinterpret_cast<bf16x8*>(dsq)[i] = q;
@@ -257,14 +265,14 @@ __device__ __forceinline__ void cast_bf16_span(const float* __restrict__ src, __
     for (long i = (n8 << 3) + tid; i < n; i += nt) {
       const __bf16 h = (__bf16)src[i], l = split_lo(src[i], h);
       dst[i] = h;
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+      if (dsq) dsq[i] = dlo ? (__bf16)(src[i] * src[i]) : sq_bf16(src[i]);
       if (dlo) dlo[i] = l;
     }
   } else {
     for (long i = tid; i < n; i += nt) {
       const __bf16 h = (__bf16)src[i], l = split_lo(src[i], h);
       dst[i] = h;
-      if (dsq) dsq[i] = (__bf16)(src[i] * src[i]);
+      if (dsq) dsq[i] = dlo ? (__bf16)(src[i] * src[i]) : sq_bf16(src[i]);
       if (dlo) dlo[i] = l;
     }
   }

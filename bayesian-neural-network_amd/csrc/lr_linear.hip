@@ -134,12 +134,12 @@ __device__ __forceinline__ void lr_epilogue_item(const LrK& p, int s, uint32_t g
     if (vec_ok) {
       bf16x4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] * v[i]);
+      for (int i = 0; i < 4; ++i) o[i] = sq_bf16(v[i]);
       *reinterpret_cast<bf16x4*>(qp) = o;
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+        if (nb + i < N) qp[i] = sq_bf16(v[i]);
     }
   }
   if (p.v_out) {
@@ -1446,12 +1446,12 @@ __global__ __launch_bounds__(NW * 64, PREP ? 4 : 3) void lr_fwd_gemm_kernel(cons
           if (vec_ok) {
             bf16x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(v[i] * v[i]);
+            for (int i = 0; i < 4; ++i) o[i] = X3 ? (__bf16)(v[i] * v[i]) : sq_bf16(v[i]);
             *reinterpret_cast<bf16x4*>(qp) = o;
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (nb + i < N) qp[i] = (__bf16)(v[i] * v[i]);
+              if (nb + i < N) qp[i] = X3 ? (__bf16)(v[i] * v[i]) : sq_bf16(v[i]);
           }
         }
         if (p.y_bf16) {
@@ -2133,8 +2133,13 @@ static int lr_kslice_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
                   a->split_scratch && !(reinterpret_cast<uintptr_t>(a->split_scratch) & 15) &&
                   a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(shared ? 1 : a->n_samples, a->batch, N) &&
                   !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
-                  (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE) && units <= 160;
-  if (!ok) return BNN_ERR_ENUM;
+                  (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE);
+  long max_units = 160, max_blocks = 256;
+#if defined(BNN_TUNE)
+  if (const char* v = getenv("BNN_TUNE_LRS_MAXUNITS")) max_units = atol(v);
+  if (const char* v = getenv("BNN_TUNE_LRS_MAXBLOCKS")) max_blocks = atol(v);
+#endif
+  if (!ok || units > max_units) return BNN_ERR_ENUM;
   int ksl = (int)(160 / units);
   ksl = ksl < 1 ? 1 : ksl > kLrsMaxSlices ? kLrsMaxSlices : ksl;
 #if defined(BNN_TUNE) || defined(BNN_STAMPS)
@@ -2143,7 +2148,7 @@ static int lr_kslice_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
   while (ksl < kLrsMaxSlices && (ksteps + ksl - 1) / ksl > kLrsMaxSteps) ++ksl;
   const int nst = (ksteps + ksl - 1) / ksl;
   ksl = (ksteps + nst - 1) / nst;                          // no empty slices
-  if (nst > kLrsMaxSteps || units * ksl > 256) return BNN_ERR_ENUM;   // one round of blocks: slices that queue behind each other gain nothing
+  if (nst > kLrsMaxSteps || units * ksl > max_blocks) return BNN_ERR_ENUM;   // one round of blocks: slices that queue behind each other gain nothing
   pl.form = BNN_FORM_GEMM_KSLICE;
   pl.R = 1; pl.MT = 8; pl.nw = 8;
   pl.ksl = ksl; pl.nst = nst;

@@ -71,7 +71,10 @@ enum bnn_dtype { BNN_F32 = 0, BNN_BF16 = 1 };
 /* Arithmetic of the matmul.  BNN_MATH_F32: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, a
  * k-ordered fmaf chain) — the parity mode.  BNN_MATH_BF16: operands rounded to bf16 (RNE),
  * fp32 accumulate (v_mfma_f32_16x16x32_bf16) — the throughput mode.  Statistics (log-probs,
- * KL) are always formed in fp32 from the un-rounded fp32 weights. */
+ * KL) are always formed in fp32 from the un-rounded fp32 weights.  The x^2 operand of the LR variance product
+ * (networks.py:121) in BNN_MATH_BF16 is bf16(bf16(x)^2) — the square of the rounded activation, rounded — for every kernel
+ * form: the x_sq / y_sq / cast_dst_sq streams hold exactly what a kernel squaring the bf16 x it loaded computes, so which
+ * forms a launch plan picks never changes a result bit. */
 enum bnn_math { BNN_MATH_F32 = 0, BNN_MATH_BF16 = 1, BNN_MATH_BF16X3 = 2 };
 /* BNN_MATH_BF16X3 (BBB forward): split-bf16 operands on the bf16 matrix core.  Every matmul operand v is carried as the pair
  *     hi = bf16(v),   lo = bf16(v - hi)            (both round-to-nearest-even; v - hi is exact in fp32)
@@ -346,10 +349,10 @@ typedef struct bnn_lr_fwd_args {
   void* y;
   int32_t y_dtype;
   int32_t reserved2;
-  const void* x_sq;         /* optional bf16 [x_samples,batch,in]: x*x elementwise (what a previous
-                               layer's y_sq or bnn_cast_bf16 produced); lets the throughput kernel
+  const void* x_sq;         /* optional bf16 [x_samples,batch,in]: the squares of x as a previous layer's y_sq or
+                               bnn_cast_bf16 wrote them (BNN_MATH_BF16: bf16(bf16(x)^2), see bnn_math); lets the throughput kernel
                                stream both GEMM operands of networks.py:120-121 by LDS-DMA */
-  void* y_sq;               /* optional bf16 [n_samples,batch,out]: also write y*y (after ReLU) */
+  void* y_sq;               /* optional bf16 [n_samples,batch,out]: also write the squares of y (after ReLU) for the next layer's x_sq */
   const void* w_frag;       /* optional output of bnn_lr_prepare for these weights: the throughput
                                kernel then streams ready bf16 (M, sigma^2) fragments and the KL
                                workspace is the one bnn_lr_prepare filled (want_kl still set) */
@@ -378,7 +381,7 @@ typedef struct bnn_lr_fwd_args {
                                needs the sizes of n_samples = 1. */
   size_t split_scratch_bytes;
   const void* x_lo;         /* BNN_MATH_BF16X3: the low plane of x (as in bnn_bbb_fwd_args).  In that mode the layer runs the
-                               block-GEMM form only: bf16 x with x_lo AND x_sq (bf16 of the fp32 squares), w_frag from
+                               block-GEMM form only: bf16 x with x_lo AND x_sq (in this mode bf16 of the fp32 squares), w_frag from
                                bnn_lr_prepare_x3; the mean product x . M (networks.py:120) in split-bf16 (three MFMAs), the
                                variance product x^2 . sigma^2 (:121) on bf16 operands as in BNN_MATH_BF16 -- the activation
                                noise is a few per cent of the output, its 2^-9 error below the mean's 2^-15 */
@@ -755,7 +758,7 @@ int bnn_philox_normal(float* eps, uint64_t seed, uint32_t tensor_id, uint32_t sa
 /* sigma[i] = log1p(exp(rho[i])) (networks.py:39), n contiguous fp32 elements. */
 int bnn_softplus(const float* rho, float* sigma, int64_t n, void* stream);
 
-int bnn_cast_bf16(const float* src, void* dst_bf16, void* dst_sq_bf16 /* optional: x*x */, int64_t n, void* stream);
+int bnn_cast_bf16(const float* src, void* dst_bf16, void* dst_sq_bf16 /* optional: bf16(bf16(x)^2) */, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bnn_eval_prepare — the two passes above for a whole evaluation in ONE launch: everything that depends on no
@@ -773,7 +776,7 @@ typedef struct bnn_prepare_args {
   int64_t n[BNN_PREPARE_MAX];             /* elements of each tensor */
   const float* cast_src;                  /* optional (cast_n > 0) */
   void* cast_dst;                         /* bf16 */
-  void* cast_dst_sq;                      /* optional bf16: src * src */
+  void* cast_dst_sq;                      /* optional bf16 squares: bf16(bf16(src)^2); with cast_dst_lo (BNN_MATH_BF16X3) bf16(src^2) */
   int64_t cast_n;
   void* cast_dst_lo;                      /* optional bf16: the low plane bf16(src - cast_dst) of BNN_MATH_BF16X3 */
 } bnn_prepare_args;

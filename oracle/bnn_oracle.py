@@ -281,15 +281,14 @@ def network_forward(p: NetParams, x: torch.Tensor, eps: Optional[Sequence[torch.
 #   BBB: the matmul operands -- bf16(x) (the input batch and every hidden activation AFTER ReLU) and bf16(w) with
 #        w = mu + softplus(rho) * eps in fp32; products exact, fp32 accumulation, the fp32 bias sample added in fp32;
 #        log p / log q from the UN-rounded fp32 w.
-#   LR:  bf16(x) . bf16(M) and x2 . bf16(sigma^2) with x2 = bf16(x * x) formed from the fp32 x (`sq_carried`: the input
-#        cast and the producing layer's epilogue write it, evaluations of >= 8 pairs) or bf16(bf16(x)^2) (the consuming
-#        kernel squares the fragment it loaded, fewer pairs); sqrt, activation noise, bias and the KL in fp32.
+#   LR:  bf16(x) . bf16(M) and x2 . bf16(sigma^2) with x2 = bf16(bf16(x)^2), the square of the rounded activation, rounded
+#        (one definition for every kernel form, include/bnn_hip.h bnn_math); sqrt, activation noise, bias and the KL in fp32.
 # --------------------------------------------------------------------------------------
 def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def network_forward_bf16(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tensor], sq_carried: bool = True):
+def network_forward_bf16(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tensor]):
     """(logits, log_prior | kl, log_q | None) like network_forward, with the device's bf16 rounding points."""
     if p.mode == "classification":
         x = x.view(-1, p.input_shape)
@@ -299,7 +298,7 @@ def network_forward_bf16(p: NetParams, x: torch.Tensor, eps: Sequence[torch.Tens
         if p.local_reparam:
             w_sigma, b_sigma = softplus_naive(wr), softplus_naive(br)
             xr = _bf16(x)
-            x2 = _bf16(x * x) if sq_carried else _bf16(xr * xr)
+            x2 = _bf16(xr * xr)
             act_mu = torch.mm(xr, _bf16(wm))
             act_sigma = torch.sqrt(torch.mm(x2, _bf16(w_sigma * w_sigma)))
             x = act_mu + act_sigma * ew + (bm + b_sigma * eb).unsqueeze(0)

@@ -26,6 +26,15 @@ for S in [int(v) for v in os.environ.get("SWEEP_S", "4,8,10,16,24,32").split(","
     row = [f"S={S:3d}"]
     us = kernel_alone_us(lambda: ops.lr_linear_fwd(x, *dw, form=L.FORM_TILE, **kw), st, per_graph=8, reps=10)
     row.append(f"K3a {us:6.1f}")
+    if os.environ.get("SWEEP_K3S"):               # tune build: K3s (32-feature groups x K slices) past its one-round limit
+        os.environ["BNN_TUNE_LRS_MAXUNITS"], os.environ["BNN_TUNE_LRS_MAXBLOCKS"] = "400", "1200"
+        scratch = ops.lr_split_scratch(S, B, N, dev)
+        try:
+            pl = ops.lr_plan(x, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw)
+            us = kernel_alone_us(lambda: ops.lr_linear_fwd(x, *dw, form=L.FORM_GEMM_KSLICE, split_scratch=scratch, **kw), st, per_graph=8, reps=10)
+            row.append(f"K3s ksl{pl['k_slices']}[b{pl['blocks']}] {us:6.1f}")
+        except Exception as e:
+            row.append(f"K3s n/a ({type(e).__name__})")
     for nw in (4, 8, 16):
         os.environ["BNN_TUNE_LRNW"] = str(nw)
         pl = ops.lr_plan(x, *dw, form=L.FORM_GEMM, w_frag=frag, **kw)

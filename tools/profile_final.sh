@@ -10,18 +10,22 @@ P="bash tools/profile_round.sh $TAG"
 PMC="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 mkdir -p gpurun_out/profiles && echo '{}' > gpurun_out/profiles/pmc.json
 $P stats bbb_g256 &&
+$P stats bbb_g256_x3 --math bf16x3 &&
 $P stats lr_g256_l2 --variant lr &&
+$P stats lr_g256_l2_x3 --variant lr --math bf16x3 &&
 $P stats bbb_S8 --samples 8 --group 1 &&
 $P stats lr_S1 --variant lr --samples 1 --group 1 &&
 $P stats wide_B4096_S4 --net wide --batch 4096 --samples 4 --group 1 &&
 $P stats wide_B1024_S4 --net wide --batch 1024 --samples 4 --group 1 &&
 $P statspy train_step tools/train_step_bench.py 2 graph &&
 $P traffic bbb256 bbb_1200_n256_b128_bf16 bbb_fwd_gemm &&
+$P traffic bbb256x3 bbb_1200_n256_b128_bf16x3 bbb_fwd_gemm --math bf16x3 &&
 $P traffic lr256 lr_1200_n256_b128_bf16 lr_fwd_gemm_kernel --variant lr &&
 $P traffic bbbS8 bbb_1200_n8_b128_bf16 bbb_fwd_gemm --samples 8 --group 1 &&
 $P traffic lrS1 lr_1200_n1_b128_bf16 lr_fwd_kslice_kernel --variant lr --samples 1 --group 1 &&
 $P traffic wide4096 block_gemm_4096_n4_b4096_bf16 bbb_block_gemm_kernel --net wide --batch 4096 --samples 4 --group 1 &&
 $P pmc bbb256 bbb_g256 "$PMC" &&
+$P pmc bbb256x3 bbb_g256_x3 "$PMC" --math bf16x3 &&
 $P pmc lr256 lr_g256 "$PMC" --variant lr &&
 $P pmc wide4096 wide_B4096 "$PMC" --net wide --batch 4096 --samples 4 --group 1 &&
 $P statsfull steps20 --steps 20 --warmup 5 --no-extras --no-cpu-baseline    # last: its bench line carries the traffic / counters collected above
@@ -31,7 +35,8 @@ PROF=gpurun_out/profiles
 ( for pz in 1 0; do echo "== BNN_TUNE_PAIRS=$pz (1: K1b2, 0: K1b)"; BNN_TUNE_PAIRS=$pz BNN_HIP_LIB=$PWD/bayesian-neural-network_amd/bnn_hip/libbnn_hip_tune.so python3 tools/k1b_ablate.py 2>&1 | grep -v amdgpu.ids; done > $PROF/${TAG}_k1b_ablate.log 2>&1 ) || true
 ( python3 tools/make_valu_floor.py $PROF/${TAG}_k1b_ablate.log > /dev/null 2>&1 && cp profiles/valu_floor.json $PROF/valu_floor.json ) || true
 ( python3 tools/block_gemm_vs_library.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_block_gemm_vs_library.log ) || true
-( for b in 0 8 1 2 3 7 15 31 27; do echo "== BG_ABL=$b (1 no LDS reads after the first K-tile, 2 no LDS-DMA after the prologue, 4 no barriers, 8 no y stores, 16 no read code in the loop)"; tools/bg_ph2_abl$b.out 4 1024 4096 4096 20 1 | tail -1; done; echo "== four-phase form"; tools/block_gemm_bench_ph4.out 4 1024 4096 4096 20 1 | tail -1; echo "== K sweep (per-K-tile slope and fixed cost)"; tools/gpu_bg_ksweep.sh tools/bg_ph2_abl0.out tools/bg_ph2_abl31.out ) > $PROF/${TAG}_block_gemm_ablation.log 2>&1 || true
-( for m in 0 1; do tools/mfma_ceiling.out $m; done > $PROF/${TAG}_mfma_ceiling_run.log 2>&1 ) || true
 ( python3 tools/single_eval_bench.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_single_eval.log ) || true
 ( python3 tools/predict_bench.py 10 2>&1 | grep "S=10" > $PROF/${TAG}_predict.log ) || true
+( bash tools/gpu_k1b2_floor.sh > /dev/null 2>&1 && cp gpurun_out/k1b2_floor/summary.txt $PROF/${TAG}_k1b2_floor_pmc.log ) || true
+( python3 tools/stamps_k1b2.py 2>&1 | grep -v amdgpu.ids > $PROF/${TAG}_k1b2_stamps.log; python3 tools/stamps_k1b2.py bf16x3 2>&1 | grep -v amdgpu.ids >> $PROF/${TAG}_k1b2_stamps.log ) || true
+( tools/ldsdma_probe.out 2 > $PROF/${TAG}_ldsdma_probe.log 2>&1; tools/ldsdma_probe.out 64 >> $PROF/${TAG}_ldsdma_probe.log 2>&1 ) || true
