@@ -23,7 +23,7 @@ CAST_INPUT_MIN_SAMPLES = 4    # BBB: from here on the first layer can take a blo
 # pulls through its CU's L1 (21.5 us for that layer against 14.7 us for the wider second one): casting first wins
 # even with the extra launch in the chain (one-sample evaluation 59.4 -> 55.3 us)
 CAST_INPUT_MIN_SAMPLES_LR = 1
-LR_SQUARES_MIN_SAMPLES = 8    # LR: carry x^2 (bf16) between layers from here on (the block-GEMM form streams it)
+LR_SQUARES_MIN_SAMPLES = 7    # LR: carry x^2 (bf16) between layers from here on (the block-GEMM form streams it)
 # BBB: the K-sliced GEMM form needs a scratch for its fp32 partial tiles; the library's plan (bnn_bbb_plan) decides
 # whether and how finely to slice (bbb_linear.hip: kslices) -- here only the cases it can never take are left without
 SPLIT_MIN_SAMPLES = 4
@@ -106,7 +106,7 @@ def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
 SIGMA_HOIST_BIG_LAYER = 4_000_000
 SIGMA_HOIST_MIN_SAMPLES_BIG = 24
 SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per evaluation from here on
-LR_PREPARE_MIN_SAMPLES = 8    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
+LR_PREPARE_MIN_SAMPLES = 7    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
 
 
 LR_SHARED_MAX_SAMPLES = 64    # csrc/lr_linear.hip: kLrsMaxShared (tools/lr_shared_sweep.py: faster than K3b + prepare + cast up to there)
@@ -138,13 +138,15 @@ def lr_kslice_expected(in_features: int, out_features: int, samples: int, batch:
         ksl += 1
     nst = (ksteps + ksl - 1) // ksl
     ksl = (ksteps + nst - 1) // nst
-    return nst <= 13 and units * ksl <= 256
+    # (two rounds' worth of blocks where the tile form would itself need a second round: lr_kslice_plan)
+    tile_blocks = ((out_features + 15) // 16) * samples * ((batch + 127) // 128)
+    return nst <= 13 and units * ksl <= (512 if (not shared and tile_blocks > 256) else 256)
 
 
 def lr_use_prepare(n_out: int, n_samples: int, batch: int) -> bool:
     """True when the LR throughput kernel (block GEMM) will run for this layer and enough samples share the
     prepared weights to pay for the extra pass (mirrors the launcher's geometry rule)."""
-    return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 150
+    return n_samples >= LR_PREPARE_MIN_SAMPLES and ((n_out + 63) // 64) * n_samples * ((batch + 127) // 128) >= 130
 
 
 def wide_nll(specs, batch: int) -> bool:

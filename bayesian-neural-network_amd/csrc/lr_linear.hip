@@ -2065,10 +2065,11 @@ static int lr_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
                    !(reinterpret_cast<uintptr_t>(a->x_sq) & 15);
   if (x3 && !(can && a->form != BNN_FORM_TILE && a->form != BNN_FORM_GEMM_KSLICE)) return BNN_ERR_ENUM;
   // a->form is a preference: the block-GEMM form is taken only when the arguments allow it
-  // (over prepared fragments the block form pays from 8 samples on: 1200 x 1200, 10 samples 29 us + a 6 us prepare launch against
-  // K3a's 49; 16 samples 33 against 80 -- tools/lr_mid_sweep.py, profiles/r03_lr_mid_sweep.log)
+  // (over prepared fragments the block form pays from 7 samples on: 1200 x 1200, 7 samples 29 us + a 6 us prepare launch against
+  // K3a's 47 (its third round of blocks); 10 samples 29 against 49; 16 samples 33 against 80 -- 5 / 6 samples: 28 + 6 against 33 --
+  // tools/lr_mid_sweep.py, profiles/r03_lr_mid_sweep.log, r04_lr_mid_k3s.log)
   if (can && (a->form == BNN_FORM_GEMM || x3 ||
-              (a->form == BNN_FORM_AUTO && (gemm_blocks >= 300 || (a->w_frag && a->n_samples >= 8 && gemm_blocks >= 150))))) {
+              (a->form == BNN_FORM_AUTO && (gemm_blocks >= 300 || (a->w_frag && a->n_samples >= 7 && gemm_blocks >= 130))))) {
     pl.form = BNN_FORM_GEMM;
     pl.R = 1; pl.MT = 8;
     // prepared fragments, wide layer: 8 waves share each x / x^2 tile (twice the MFMA work per LDS-DMA round trip)
@@ -2134,7 +2135,12 @@ static int lr_kslice_plan(const bnn_lr_fwd_args* a, LrPlan& pl) {
                   a->split_scratch_bytes >= bnn_lr_split_scratch_bytes(shared ? 1 : a->n_samples, a->batch, N) &&
                   !(reinterpret_cast<uintptr_t>(a->w_mu) & 15) && !(reinterpret_cast<uintptr_t>(a->w_rho) & 15) &&
                   (a->form == BNN_FORM_AUTO || a->form == BNN_FORM_GEMM_KSLICE);
-  long max_units = 160, max_blocks = 256;
+  // One round of blocks (<= 256) -- except where the tile form itself would need a second round for this launch (per-sample
+  // inputs, more than 256 of its 16-feature blocks): two K3s blocks fit a CU, so up to 512 are still all resident (1200 x 1200 at
+  // 4 samples: 456 blocks 25 us, K3a's 300 blocks 32 us -- at 3 samples K3a's 225 blocks are one round, 17.8 against 22.1:
+  // tools/lr_mid_sweep.py, profiles/r04_lr_mid_k3s.log).  The shared-input form polls for its unit's slices: one round only.
+  const long tile_blocks = (long)((N + 15) / 16) * a->n_samples * ((a->batch + 127) / 128);
+  long max_units = 160, max_blocks = (!shared && tile_blocks > 256) ? 512 : 256;
 #if defined(BNN_TUNE)
   if (const char* v = getenv("BNN_TUNE_LRS_MAXUNITS")) max_units = atol(v);
   if (const char* v = getenv("BNN_TUNE_LRS_MAXBLOCKS")) max_blocks = atol(v);

@@ -984,7 +984,9 @@ def _elbo(rows, S, beta, lr):
 
 # (G, S, pairs checked against the oracle): the driver's old 20-minibatch group (K-sliced form), the default 256-minibatch
 # launch group (block-GEMM form: a strided subset of its pairs, ~2 s of oracle each), 64 MC samples of one minibatch
-TIMED_SHAPES = [(1, 1, None), (1, 8, None), (4, 2, None), (20, 1, None),
+# (1, 4) and (1, 7): the LR hidden layer's forms between the latency and the throughput regime (K3s in two blocks per CU; K3b
+# over prepared fragments from 7 samples)
+TIMED_SHAPES = [(1, 1, None), (1, 4, None), (1, 7, None), (1, 8, None), (4, 2, None), (20, 1, None),
                 (256, 1, (0, 1, 17, 63, 64, 127, 128, 200, 254, 255)), (1, 64, (0, 1, 7, 8, 31, 32, 62, 63))]
 
 

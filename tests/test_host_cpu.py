@@ -392,12 +392,12 @@ def test_launch_plans_are_a_function_of_the_shape():
     pl = lr(64, 128, 1200, 1200, sq=True)
     assert (pl.form, pl.waves) == (L.FORM_GEMM, 4)
     assert lr(64, 128, 1200, 1200, sq=True, frag=True).waves == 16 and lr(64, 128, 1200, 256, sq=True, frag=True).waves == 4
-    # over prepared fragments the block form runs from 8 samples (per-sample inputs: xps), in the narrowest blocks whose launch
+    # over prepared fragments the block form runs from 7 samples (per-sample inputs: xps), in the narrowest blocks whose launch
     # is still one round of <= 256 (the measured optima of tools/lr_mid_sweep.py)
-    for S, waves, blocks in ((8, 4, 152), (10, 4, 190), (16, 8, 160), (24, 8, 240), (32, 16, 160), (64, 16, 320)):
+    for S, waves, blocks in ((7, 4, 133), (8, 4, 152), (10, 4, 190), (16, 8, 160), (24, 8, 240), (32, 16, 160), (64, 16, 320)):
         pl = lr(S, 128, 1200, 1200, sq=True, frag=True, xps=1)
         assert (pl.form, pl.waves, pl.blocks) == (L.FORM_GEMM, waves, blocks), (S, pl.form, pl.waves, pl.blocks)
-    assert lr(7, 128, 1200, 1200, sq=True, frag=True, xps=1).form == L.FORM_TILE and lr(10, 128, 1200, 1200, sq=True, xps=1).form == L.FORM_TILE
+    assert lr(6, 128, 1200, 1200, sq=True, frag=True, xps=1).form == L.FORM_TILE and lr(10, 128, 1200, 1200, sq=True, xps=1).form == L.FORM_TILE
     pl = lr(1, 128, 1200, 10)
     assert (pl.form, pl.batch_rows, pl.k_classes) == (L.FORM_TILE, 32, 4)
     # K3s: with a split scratch, 1-2 samples on the wide layers run as 32-feature groups x K slices in ONE round of blocks
@@ -408,7 +408,12 @@ def test_launch_plans_are_a_function_of_the_shape():
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 4, 152)
     pl = lr(2, 128, 1200, 1200, scratch=True, xps=1)
     assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 228)
-    assert lr(3, 128, 1200, 1200, scratch=True, xps=1).form == L.FORM_TILE
+    assert lr(3, 128, 1200, 1200, scratch=True, xps=1).form == L.FORM_TILE            # (K3a's 225 blocks are one round)
+    # ... and up to 512 blocks (two fit a CU) where the tile form itself would need a second round of its 16-feature blocks:
+    # 4 samples = 300 tile blocks -> 152 units x 3 slices; 5 samples = 190 units: K3a
+    pl = lr(4, 128, 1200, 1200, scratch=True, xps=1)
+    assert (pl.form, pl.k_slices, pl.blocks) == (L.FORM_GEMM_KSLICE, 3, 456)
+    assert lr(5, 128, 1200, 1200, scratch=True, xps=1).form == L.FORM_TILE
     # 2 .. 64 samples on ONE input (x_per_sample = 0: the first layer of sample_elbo_lr / predict): the units count one sample --
     # their products are made once, the epilogue runs per sample; beyond 64 the per-sample forms
     for S in (2, 10, 23, 64):

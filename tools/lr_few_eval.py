@@ -1,0 +1,32 @@
+"""The LR network (784-1200-1200-10, one minibatch of 128) at 2 .. 10 MC samples per evaluation through engine.GraphedElbo:
+us per evaluation (hipGraph replays back to back) with the engine's sample thresholds for carried squares / prepared
+fragments at their product values and lowered (LR_MIN=<n>).  Measurement tool."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "bayesian-neural-network_amd"), REPO]
+import torch
+import bnn_hip
+from bnn_hip import engine
+from bench import build_net, DIMS
+
+dev = torch.device("cuda:0")
+bnn_hip.set_math("bf16")
+mins = [engine.LR_PREPARE_MIN_SAMPLES] + [int(v) for v in os.environ.get("LR_MIN", "").split(",") if v]
+net, x, y = build_net(DIMS["mnist"], True, 128, dev, "classification", n_minibatches=1)
+for S in [int(v) for v in os.environ.get("SWEEP_S", "2,3,4,5,6,7,8,10").split(",")]:
+    row = [f"S={S:2d}"]
+    for m in mins:
+        engine.LR_PREPARE_MIN_SAMPLES = engine.LR_SQUARES_MIN_SAMPLES = m
+        ev = engine.GraphedElbo(net, x[0], y[0], S)
+        for _ in range(20):
+            ev.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 300
+        e0.record()
+        for _ in range(n):
+            ev.replay()
+        e1.record()
+        e1.synchronize()
+        row.append(f"min {m}: {e0.elapsed_time(e1) * 1e3 / n:7.2f} us")
+    print(" | ".join(row), flush=True)
