@@ -432,6 +432,9 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
             if "bbb_fwd_gemm" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
                     v.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
                 roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
+                                       # DVFS: the shader clock of this kernel under the counter pass; the issue-cycle
+                                       # fractions above are priced at the 2.4 GHz peak clock, not at this one
+                                       "clock_ghz": v.get("clock_ghz"), "dispatch_us": v.get("dispatch_us"),
                                        "key": k, "source": "profiles/pmc.json (rocprofv3 --pmc, tools/collect_pmc.py)"}
     except Exception:
         pass
