@@ -132,6 +132,15 @@ KERNEL_SOURCES = {
 }
 
 
+def _profile_file(name):
+    """profiles/<name> -- or the copy a profiling run is writing (tools/profile_round.sh exports BNN_PROFILES_DIR), so that the
+    bench line of that run carries the counters collected just before it."""
+    d = os.environ.get("BNN_PROFILES_DIR")
+    if d and os.path.exists(os.path.join(d, name)):
+        return os.path.join(d, name)
+    return os.path.join(REPO, "profiles", name)
+
+
 def source_hash(files=None) -> str:
     """Hash of kernel sources (all of csrc/ by default, or the named files of one kernel family)."""
     h = hashlib.sha256()
@@ -421,20 +430,21 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
                                    "source": "bench.algorithmic_valu_per_normal: the epsilon map's arithmetic per sampled weight "
                                              "(Philox rounds, Box-Muller, w / statistics FMAs, bf16 pack), not the compiled loop"}
     try:       # the measured floor: the same kernel with everything but its vector work compiled out (tools/make_valu_floor.py)
-        vf = json.load(open(os.path.join(REPO, "profiles", "valu_floor.json")))
+        vf = json.load(open(_profile_file("valu_floor.json")))
         if roof["plan"]["waves"] == 8 and vf.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
             roof["valu"]["in_situ"] = {k: vf[k] for k in ("full_launch_us", "vector_work_only_us", "without_dma_us", "frac", "source")}
     except Exception:
         pass
     try:
-        pm = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))
+        pm = json.load(open(_profile_file("pmc.json")))
         for k, v in pm.items():
             if "bbb_fwd_gemm" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
                     v.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
                 roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
-                                       # DVFS: the shader clock of this kernel under the counter pass; the issue-cycle
-                                       # fractions above are priced at the 2.4 GHz peak clock, not at this one
-                                       "clock_ghz": v.get("clock_ghz"), "dispatch_us": v.get("dispatch_us"),
+                                       # SURVEY 8(d) "report wall and cycles": active cycles / duration of the counter pass's own
+                                       # dispatches -- a crude clock figure (it differs between passes: DESIGN.md 4, the power probe
+                                       # is the better evidence); the issue-cycle fractions above are priced at the 2.4 GHz peak
+                                       "clock_ghz_counter_pass": v.get("clock_ghz"), "dispatch_us_counter_pass": v.get("dispatch_us"),
                                        "key": k, "source": "profiles/pmc.json (rocprofv3 --pmc, tools/collect_pmc.py)"}
     except Exception:
         pass
@@ -445,7 +455,7 @@ def attach_traffic(roof):
     """PMC traffic measured by tools/collect_traffic.py (rocprofv3 --pmc, separate passes) for the same kernel and
     launch shape -- only if the kernel sources have not changed since."""
     key = roof.pop("traffic_key", None)
-    tj = os.path.join(REPO, "profiles", "traffic.json")
+    tj = _profile_file("traffic.json")
     if key is None or not os.path.exists(tj):
         return roof
     try:

@@ -35,7 +35,7 @@ for kern, cs in agg.items():
         if "SQ_WAVE_CYCLES" in m:
             e["waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles
         e["active_cycles"] = cyc
-        if dur.get(kern):
+        if dur.get(kern) and sum(dur[kern].values()) / len(dur[kern]) >= 100.0:      # (short dispatches: the counter window is not the kernel)
             # DVFS: the shader clock this kernel ran at UNDER THE COUNTER PASS (report wall and cycles) --
             # active cycles over the same dispatches' durations
             e["dispatch_us"] = sum(dur[kern].values()) / len(dur[kern])
