@@ -132,6 +132,49 @@ KERNEL_SOURCES = {
 }
 
 
+def board_power_while(replay, seconds=1.5):
+    """rocm-smi readings (package power, its limit, shader clock) of GPU 0 while `replay()` keeps the device busy: the headline
+    kernel runs at the board's power limit (profiles/r04_power_probe.log), which bounds it before any pipe does.
+    Outside the timed region; None when rocm-smi is absent or refuses."""
+    import threading
+    import torch
+
+    def smi():
+        try:
+            o = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True,
+                               text=True, timeout=10).stdout
+            c = json.loads(o).get("card0", {})
+            f = lambda key: next((float(str(v).strip("()MmHhZz ")) for k, v in c.items() if key in k.lower()), None)
+            return {"watts": f("current socket graphics package power") or f("average graphics package power"),
+                    "limit_watts": f("max graphics package power"), "sclk_mhz": f("sclk clock speed")}
+        except Exception:
+            return None
+    stop, got = [False], []
+
+    def poll():
+        time.sleep(0.4)                                   # let the load settle
+        while not stop[0]:
+            r = smi()
+            if r and r.get("watts"):
+                got.append(r)
+            time.sleep(0.1)
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.time()
+    while time.time() - t0 < seconds or (not got and time.time() - t0 < 2 * seconds):
+        replay()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    if not got:
+        return None
+    w = [g["watts"] for g in got]
+    lim = got[0].get("limit_watts")
+    return {"watts_mean": sum(w) / len(w), "watts_max": max(w), "limit_watts": lim, "frac_of_limit": (sum(w) / len(w) / lim) if lim else None,
+            "sclk_mhz": got[-1].get("sclk_mhz"), "readings": len(w),
+            "source": "rocm-smi --showpower --showmaxpower --showclocks while the launch group replays back to back (outside the timed region)"}
+
+
 def _profile_file(name):
     """profiles/<name> -- or the copy a profiling run is writing (tools/profile_round.sh exports BNN_PROFILES_DIR), so that the
     bench line of that run carries the counters collected just before it."""
@@ -438,7 +481,7 @@ def valu_bound(roof, fin, fout, n, batch, us, sig):
     try:
         pm = json.load(open(_profile_file("pmc.json")))
         for k, v in pm.items():
-            if "bbb_fwd_gemm" in k and k.startswith("bbb_g256") and "valu_busy" in v and \
+            if "bbb_fwd_gemm" in k and k.startswith("bbb_g256_x3:" if roof.get("math") == "bf16x3" else "bbb_g256:") and "valu_busy" in v and \
                     v.get("source_hash") == source_hash(KERNEL_SOURCES["bbb"]):
                 roof["valu"]["pmc"] = {"valu_busy": v.get("valu_busy"), "mfma_util": v.get("mfma_util"), "waves_per_simd": v.get("waves_per_simd"),
                                        # SURVEY 8(d) "report wall and cycles": active cycles / duration of the counter pass's own
@@ -650,6 +693,8 @@ def main():
 
     if rank == 0:
         out["roofline"] = attach_traffic(layer2_roofline(ev, net, dims, args.batch, lr, args.math))
+        if world == 1 and not rehearsal:
+            out["roofline"]["board_power"] = board_power_while(ev.replay)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, lr, args.batch)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
