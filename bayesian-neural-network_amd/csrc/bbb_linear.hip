@@ -933,10 +933,17 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
   const uint32_t tk = __hip_atomic_fetch_add(p.tickets + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tk != (uint32_t)RB) return;                           // RB + 1 blocks per sample
   // ---- last block of the sample: fold (row-block order), store the sample's scalars
-  double tn = 0;
-  for (int i = 0; i < RB; ++i) tn += __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (all ten loads in flight before the first is consumed -- one round trip, not RB + 1: a loop over `tn += load` waits per
+  // element; slots past RB hold no block's value and are not added)
+  float pv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pv[i] = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float a = __hip_atomic_load(mine + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float b = __hip_atomic_load(mine + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double tn = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < RB) tn += pv[i];
   const float nll = (float)tn;
   __hip_atomic_store(p.tickets + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
   if (fk.log_prior) __hip_atomic_store(fk.log_prior + s, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
