@@ -299,48 +299,61 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
   }
 }
 
-// The 4-vector(s) of sums from the per-sample scalars, in sample order (one thread; the callers make the scalars
-// of all samples visible first): one vector, or one per minibatch of `group` samples.
-// Per-sample scalars of samples [i0, i0 + n) added to (ta, tb, tn) in sample order.  The loads of eight samples are all in
-// flight before the first is consumed: a `for` over `x += atomic_load(...)` compiles to one memory round trip per sample
-// (s_waitcnt vmcnt(0) in the loop), ~0.6 us each on the one thread everybody else has already left to.
-__device__ __forceinline__ void fin_add_samples(const float* pa, const float* pb, const float* pn, int i0, int n, double& ta, double& tb,
-                                                double& tn) {
-  const float* fb = pa ? pa : pb ? pb : pn;                    // an absent tensor reads another's words (not added): no branch
-  if (!fb) return;                                             // around a load -- the compiler closes every such branch with vmcnt(0)
-  const float* qa = pa ? pa : fb;
-  const float* qb = pb ? pb : fb;
-  const float* qn = pn ? pn : fb;
-  const int last = i0 + n - 1;
-  for (int base = i0; base <= last; base += 8) {
-    float va[8], vb[8], vn[8];
+// The per-sample scalars of samples [0, S) folded in sample order into one (a, b, nll) triple per group of `g` consecutive
+// samples, `emit(group, a, b, nll)` called as each group completes.  The loads of sixteen samples are all in flight before the
+// first is consumed, whatever the group size: a `for` over `x += atomic_load(...)` compiles to one memory round trip per
+// sample (s_waitcnt vmcnt(0) in the loop, ~0.6 us each on the one thread everybody else has already left to), and a branch
+// around a load is closed with vmcnt(0) too -- hence the stand-in pointers for absent tensors.
+template <typename Emit>
+__device__ __forceinline__ void fin_fold_groups(const float* pa, const float* pb, const float* pn, int S, int g, Emit emit) {
+  const float* fb = pa ? pa : pb ? pb : pn;                    // an absent tensor reads another's words (not added)
+  double ta = 0, tb = 0, tn = 0;
+  int left = g, group = 0;
+  constexpr int CH = 16;
+  for (int base = 0; base < S; base += CH) {
+    float va[CH], vb[CH], vn[CH];
+    if (fb) {
+      const float* qa = pa ? pa : fb;
+      const float* qb = pb ? pb : fb;
+      const float* qn = pn ? pn : fb;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = min(base + j, last);                       // clamped: a re-read, not added
-      va[j] = __hip_atomic_load(qa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vb[j] = __hip_atomic_load(qb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vn[j] = __hip_atomic_load(qn + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < CH; ++j) {
+        const int i = min(base + j, S - 1);                    // clamped: a re-read, not added
+        va[j] = __hip_atomic_load(qa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb[j] = __hip_atomic_load(qb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vn[j] = __hip_atomic_load(qn + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) va[j] = vb[j] = vn[j] = 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool in = base + j <= last;
-      ta += (in && pa) ? va[j] : 0.f;
-      tb += (in && pb) ? vb[j] : 0.f;
-      tn += (in && pn) ? vn[j] : 0.f;
+    for (int j = 0; j < CH; ++j) {
+      if (base + j < S) {
+        ta += pa ? va[j] : 0.f;
+        tb += pb ? vb[j] : 0.f;
+        tn += pn ? vn[j] : 0.f;
+        if (--left == 0) {
+          emit(group, ta, tb, tn);
+          ta = tb = tn = 0;
+          left = g;
+          ++group;
+        }
+      }
     }
   }
 }
 
+// The 4-vector(s) of sums from the per-sample scalars, in sample order (one thread; the callers make the scalars
+// of all samples visible first): one vector, or one per minibatch of `group` samples.
 __device__ __forceinline__ void fin_fold_sums(const FinK& p, float* sums) {
   const int g = p.group > 0 ? p.group : p.S;
   const float* pa = p.local_reparam ? p.kl : p.log_prior;
   const float* pb = (!p.local_reparam && p.log_q) ? p.log_q : nullptr;
-  for (int m = 0; m * g < p.S; ++m) {
-    double ta = 0, tb = 0, tn = 0;
-    fin_add_samples(pa, pb, p.nll, m * g, g, ta, tb, tn);
+  fin_fold_groups(pa, pb, p.nll, p.S, g, [&](int m, double ta, double tb, double tn) {
     float* so = sums + 4 * m;
     so[0] = (float)ta; so[1] = (float)tb; so[2] = (float)tn; so[3] = (float)g;
-  }
+  });
 }
 
 __device__ __forceinline__ void fin_store(const FinK& p, int s, float a, float b, float nll) {
@@ -369,7 +382,7 @@ struct FinLoss {
 __device__ __forceinline__ void fin_loss_assemble(const FinK& fk, const FinLoss& tr) {
   const float* pa = fk.local_reparam ? fk.kl : fk.log_prior;
   double x = 0, y = 0, z = 0;
-  fin_add_samples(pa, fk.local_reparam ? nullptr : fk.log_q, fk.nll, 0, fk.S, x, y, z);
+  fin_fold_groups(pa, fk.local_reparam ? nullptr : fk.log_q, fk.nll, fk.S, fk.S, [&](int, double ta, double tb, double tn) { x = ta; y = tb; z = tn; });
   const float beta = *tr.beta;
   const float inv = tr.grad_scale / tr.total;
   for (int i = 0; i < fk.S; ++i) {
