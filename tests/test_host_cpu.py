@@ -438,6 +438,19 @@ def test_launch_plans_are_a_function_of_the_shape():
                         assert pl.k_classes in (1, 2, 4) and pl.batch_rows in (32, 128)
 
 
+def test_committed_instruction_mix_matches_the_kernel_sources():
+    """`roofline.frac` of the headline is priced from profiles/isa_mix.json, and bench.py drops an entry whose source hash is not
+    the current one (a stale mix must not price a changed kernel): a kernel-source change without `python tools/make_isa_mix.py`
+    would leave the driver's bench line without its fraction.  (traffic.json / pmc.json / valu_floor.json come from GPU passes --
+    tools/profile_final.sh -- and only lose their fields when stale.)"""
+    import json
+    import bench
+    mix = json.load(open(os.path.join(REPO, "profiles", "isa_mix.json")))
+    for key, fam in (("bbb_fwd_gemm2_kernel<4,2,philox>", "bbb"), ("bbb_fwd_gemm2_kernel<4,2,philox,x3>", "bbb"),
+                     ("bbb_fwd_gemm_kernel<4,true,philox>", "bbb"), ("lr_fwd_gemm_kernel<16,true,2>", "lr")):
+        assert mix[key]["source_hash"] == bench.source_hash(bench.KERNEL_SOURCES[fam]), f"{key}: run tools/make_isa_mix.py"
+
+
 def test_bench_roofline_bookkeeping_without_a_device(tmp_path, monkeypatch):
     """bench.valu_bound / attach_traffic: the dominant kernel is priced against the vector-issue roof from the committed
     instruction mix (profiles/isa_mix.json) with the SURVEY 8(d) HBM figure beside it, and profile entries measured on
