@@ -105,7 +105,9 @@ def hoist_sigma(fin: int, fout: int, n_samples: int, batch: int = 128) -> bool:
 # softplus (1200 x 1200, 8 samples: 31.5 -> 27.6 us; 4096 x 4096, 4 samples: 113.7 -> 107.5 us against a 25 us pass)
 SIGMA_HOIST_BIG_LAYER = 4_000_000
 SIGMA_HOIST_MIN_SAMPLES_BIG = 24
-SIGMA_HOIST_MIN_SAMPLES = 8   # BBB: precompute sigma = softplus(rho) once per evaluation from here on
+SIGMA_HOIST_MIN_SAMPLES = 4   # BBB: precompute sigma = softplus(rho) once per evaluation from here on (8 until round 4: the
+                              # evaluation of one minibatch at 4 / 5 / 6 / 7 samples 58.2 / 59.6 / 63.6 / 68.8 -> 56.5 / 58.0 / 60.9 /
+                              # 67.7 us, tools/hoist_threshold_sweep.py, profiles/r04_hoist_threshold.log)
 LR_PREPARE_MIN_SAMPLES = 7    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
 
 
