@@ -2031,7 +2031,12 @@ void tile_plan(int S, int B, int K, int N, bool aligned, int mt, BbbPlan& pl) {
 // put 38 steps on 152 of the CUs, 4 slices 3 x 10 = 30 on all, 5 slices 3 x 8 = 24 (the ideal is 22.3).
 double slice_cost_us(long gemm_blocks, int ksteps, int ksl) {
   const long blocks = gemm_blocks * ksl;
-  const long per_cu = (blocks + 255) / 256;
+  // (1024 blocks are resident at once, four per CU.  More blocks than that, of SHORT slices, run as a further round: priced as
+  // ceil(blocks / 256) per CU, the 1330 blocks of 14 samples x 5 slices of 5 k-steps on the 784-wide layer looked cheaper than 798
+  // blocks of 3 slices and the evaluation measured 5 % slower; long slices hide the refill -- 32 samples x 2 slices of 19 steps,
+  // 1216 blocks, is 3 % faster than one round of whole-K blocks: tools/ksl_eval_sweep.py, profiles/r04_ksl_eval.log)
+  const bool short_slices = (ksteps + ksl - 1) / ksl < 8;
+  const long per_cu = (blocks <= 1024 || !short_slices) ? (blocks + 255) / 256 : 4 * ((blocks + 1023) / 1024);
   static const double stretch[5] = {0.0, 2.4, 1.4, 1.27, 1.2};
   // (+1.5 steps per block: its prologue and epilogue bubbles)
   double us = 0.5 * (double)per_cu * ((ksteps + ksl - 1) / ksl + 1.5) * stretch[per_cu > 4 ? 4 : per_cu] + 3.2;
