@@ -749,6 +749,37 @@ class GraphedElbo:
         return self.bufs[-1]
 
 
+class GraphedPredict(GraphedElbo):
+    """F3 as a captured evaluation: the MC-averaged prediction of one minibatch (classification/class_task.py:81-87 --
+    probs = mean_s softmax(net(x, sample=True)), preds = argmax) with static buffers, one hipGraph, FRESH epsilon on every
+    replay (the device-resident sample counter of GraphedElbo).  It is GraphedElbo's launch chain for `samples` MC samples of
+    the minibatch -- the forms a forward-only evaluation takes at that sample count, output layer in its row-split form -- with
+    the softmax-mean launch (bnn_mc_softmax_mean) behind it; the ELBO scalars it also produces are computed against all-zero
+    labels and mean nothing.  `replay()` returns the static (preds [B] int64, probs [B, C] float32); with sample sharding on,
+    every rank runs its share of the samples and replay() sum-all-reduces the probabilities (outside the graph)."""
+
+    def __init__(self, net, x: torch.Tensor, samples: int, capture: bool = True, stream: Optional[torch.cuda.Stream] = None):
+        if net.mode != "classification":
+            raise ops.BnnHipError("GraphedPredict: the MC-averaged class prediction exists for classification networks")
+        xf = net._flat(x)
+        self.probs = torch.empty((xf.shape[0], net._specs()[-1].in_out[1]), dtype=torch.float32, device=x.device)
+        self.preds = torch.empty(xf.shape[0], dtype=torch.int64, device=x.device)
+        super().__init__(net, x, torch.zeros(xf.shape[0], dtype=torch.int64, device=x.device), samples, capture=capture, stream=stream)
+
+    def _enqueue(self):
+        super()._enqueue()
+        ops.mc_softmax_mean(self.logits, 1.0 / self.samples, out_probs=self.probs, out_preds=self.preds if self.world == 1 else None,
+                            want_preds=self.world == 1)
+
+    def replay(self):
+        super().replay()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.probs, op=dist.ReduceOp.SUM)
+            self.preds.copy_(torch.argmax(self.probs, dim=1))
+        return self.preds, self.probs
+
+
 def elbo_many(net, x: torch.Tensor, target: torch.Tensor, samples: int, sigma: float = 1.0) -> torch.Tensor:
     """Forward-only ELBO terms of G independent minibatches in ONE launch per layer: x [G, B, ...], target [G, B]
     (or [G, B, out] for regression).  Returns float32 [G, 4] = per minibatch {sum_s log p | sum_s KL, sum_s log q | 0,

@@ -793,14 +793,20 @@ def lr_linear_bwd(x, gy, y, v, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigm
     return g_wmu, g_wrho, g_bmu, g_brho, gx
 
 
-def mc_softmax_mean(logits: torch.Tensor, scale: float, want_preds: bool = True):
-    """F3: probs[B,C] = scale * sum_s softmax(logits[s]), preds[B] = argmax (bnn_mc_softmax_mean)."""
+def mc_softmax_mean(logits: torch.Tensor, scale: float, want_preds: bool = True, out_probs: Optional[torch.Tensor] = None,
+                    out_preds: Optional[torch.Tensor] = None):
+    """F3: probs[B,C] = scale * sum_s softmax(logits[s]), preds[B] = argmax (bnn_mc_softmax_mean).  `out_probs` / `out_preds`:
+    static buffers of a captured evaluation."""
     lib = L.load()
-    require_device(logits)
+    require_device(logits, out_probs, out_preds)
     lg = _f32c(logits, "logits")
     S, B, Cc = lg.shape
-    probs = torch.empty((B, Cc), dtype=torch.float32, device=lg.device)
-    preds = torch.empty(B, dtype=torch.int64, device=lg.device) if want_preds else None
+    if out_probs is not None and (out_probs.dtype != torch.float32 or tuple(out_probs.shape) != (B, Cc) or not out_probs.is_contiguous()):
+        raise BnnHipError("mc_softmax_mean: out_probs must be a contiguous float32 [batch, classes] tensor")
+    if out_preds is not None and (out_preds.dtype != torch.int64 or tuple(out_preds.shape) != (B,) or not out_preds.is_contiguous()):
+        raise BnnHipError("mc_softmax_mean: out_preds must be a contiguous int64 [batch] tensor")
+    probs = out_probs if out_probs is not None else torch.empty((B, Cc), dtype=torch.float32, device=lg.device)
+    preds = out_preds if out_preds is not None else (torch.empty(B, dtype=torch.int64, device=lg.device) if want_preds else None)
     L.check(lib.bnn_mc_softmax_mean(lg.data_ptr(), S, B, Cc, float(scale), probs.data_ptr(), _ptr(preds), _stream()),
             "bnn_mc_softmax_mean")
     return probs, preds

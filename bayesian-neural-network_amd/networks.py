@@ -259,6 +259,12 @@ class BayesianNetwork(nn.Module):
         softmax(net(x, sample=True)).  Same eps order as that loop when eps is injected."""
         return _engine.mc_predict(self._specs(), self._flat(x), int(samples))
 
+    def predictor(self, x, samples):
+        """Extension (not in the reference): predict_mc for this minibatch shape as a captured evaluation --
+        `p = net.predictor(x, samples)`, then `p.x.copy_(next_minibatch); preds, probs = p.replay()` per minibatch (static
+        buffers, one hipGraph replay, fresh epsilon each time: bnn_hip.engine.GraphedPredict)."""
+        return _engine.GraphedPredict(self, x, int(samples))
+
     def elbo_many(self, inputs, targets, samples, sigma=1.):
         """Extension (not in the reference): the forward-only ELBO terms of G independent minibatches -- inputs
         [G, batch, ...], targets [G, batch] -- in one launch per layer instead of G sample_elbo calls under

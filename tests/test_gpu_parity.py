@@ -607,6 +607,41 @@ def test_bbb_throughput_forms_agree(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("lr", [False, True])
+def test_graphed_predict_replays_predict_mc_with_fresh_epsilon(dev, lr):
+    """engine.GraphedPredict (`net.predictor`): predict_mc as one captured evaluation -- every replay equals predict_mc at the
+    same Philox sample indices (exact-fp32 math: to sum-order noise; bf16 math: the two chains take different kernel forms,
+    rounding-level agreement), consecutive replays draw different epsilon, and a new minibatch copied into the static input
+    changes the answer."""
+    B, S, seed, c = 128, 10, 20260, 500
+    net, sd = build_net(dev, lr, (784, 1200, 10), "classification")
+    net.eval()
+    xs = [torch.from_numpy(synth.synth_batch("classification", B, 784, 10, seed=40 + m)[0]).to(dev) for m in range(2)]
+    for math, tol in (("f32", 2e-5), ("bf16", 6e-3)):
+        bnn_hip.set_math(math)
+        bnn_hip.manual_seed(seed, counter=c)
+        p = net.predictor(xs[0].clone(), S)                   # its warm-up pass drew the samples [c, c + S)
+        warm = p.probs.clone()
+        got = []
+        for r in range(2):                                    # replay r: samples [c + (r + 1) S, c + (r + 2) S)
+            preds, probs = p.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(preds, probs.argmax(1))
+            got.append(probs.clone())
+        assert int(p.counter.item()) == c + 3 * S
+        p.x.copy_(net._flat(xs[1]))
+        other = p.replay()[1].clone()
+        for k, (first, want_of) in enumerate(((c, warm), (c + S, got[0]), (c + 2 * S, got[1]))):
+            bnn_hip.manual_seed(seed, counter=first)
+            ref = net.predict_mc(xs[0], S)[1]
+            err = float((ref - want_of).abs().max())
+            assert err <= tol, (math, lr, k, err)
+        assert float((got[0] - got[1]).abs().max()) > 1e-4     # fresh epsilon
+        bnn_hip.manual_seed(seed, counter=c + 3 * S)
+        assert float((net.predict_mc(xs[1], S)[1] - other).abs().max()) <= tol
+        close(other.sum(1).cpu().numpy(), np.ones(B), rtol=1e-5)
+
+
+@pytest.mark.parametrize("lr", [False, True])
 def test_mc_predict_equals_the_reference_loop(dev, lr):
     """F3: predict_mc (samples batched per launch + bnn_mc_softmax_mean) against the loop of
     classification/class_task.py:81-87 run through the oracle on the same injected eps, and

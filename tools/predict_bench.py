@@ -31,7 +31,10 @@ for lr in (False, True):
             with torch.cuda.graph(g, stream=side):
                 out = fused()
         torch.cuda.current_stream().wait_stream(side)
-    forms = (("python loop of net(X, sample=True)", loop, 30), ("predict_mc", fused, 100), ("predict_mc as a hipGraph*", g.replay, 300))
+    with torch.no_grad():
+        pred = net.predictor(x, S)                        # engine.GraphedPredict: captured, fresh eps per replay
+    forms = (("python loop of net(X, sample=True)", loop, 30), ("predict_mc", fused, 100), ("predict_mc as a hipGraph*", g.replay, 300),
+             ("net.predictor(x, S).replay()", pred.replay, 300))
     for name, fn, n in forms:
         with torch.no_grad():
             for _ in range(5): fn()
