@@ -213,20 +213,21 @@ __device__ __forceinline__ void fin_sample(const FinK& p, const FinC& cst, int s
     if (l < p.n_layers && l != own_layer) {
       const float4* ws = reinterpret_cast<const float4*>(p.ws[l]);
       const int Tl = T[l], bd = blockDim.x;
-      // four entries per thread in flight (clamped re-reads are not added; the order of a thread's additions is unchanged): a
+      // eight entries per thread in flight (clamped re-reads are not added; the order of a thread's additions is unchanged): a
       // wide layer's sampling launch leaves 4096 entries per sample, 16 per thread -- as `v += ws[..]` in a plain loop that was
       // one memory round trip per entry, 34 us of a 4-sample evaluation of the 4096-wide network
-      for (int t0 = threadIdx.x; t0 < Tl; t0 += 4 * bd) {
-        float4 qv[4];
-        float lsz[4];
+      constexpr int FU = 8;
+      for (int t0 = threadIdx.x; t0 < Tl; t0 += FU * bd) {
+        float4 qv[FU];
+        float lsz[FU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FU; ++u) {
           const int t = min(t0 + u * bd, Tl - 1);
           qv[u] = p.local_reparam ? ws[1 + t] : ws[1 + (size_t)s * Tl + t];
           lsz[u] = p.local_reparam ? 0.f : ws[1 + t].z;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FU; ++u) {
           if (t0 + u * bd < Tl) {
             v[3 * l + 0] += qv[u].x;                               // LR: sum log sigma      | BBB: sum eps^2
             v[3 * l + 1] += qv[u].y;                               //     sum sigma^2        |      sum w^2 | sum log p_mix
