@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")   # env: diagnostic builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # enums of include/bnn_hip.h
 F32, BF16 = 0, 1
@@ -23,7 +23,7 @@ EXPORTS = (
     "bnn_bbb_linear_bwd_workspace_bytes",
     "bnn_bbb_linear_bwd", "bnn_lr_linear_bwd_workspace_bytes", "bnn_lr_linear_bwd", "bnn_adam_step", "bnn_nll_bwd", "bnn_mc_softmax_mean", "bnn_elbo_loss",
     "bnn_elbo_loss_nll_bwd", "bnn_stage_inputs", "bnn_stage_inputs_cast", "bnn_bbb_sample_weights", "bnn_bbb_sample_workspace_bytes",
-    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_split_scratch_bytes", "bnn_lr_split_scratch_zero_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare", "bnn_lr_prepare_x3_bytes", "bnn_lr_prepare_x3",
+    "bnn_lr_linear_fwd_workspace_bytes", "bnn_lr_split_scratch_bytes", "bnn_lr_split_scratch_zero_bytes", "bnn_lr_linear_fwd", "bnn_lr_final_fwd", "bnn_lr_plan", "bnn_bbb_plan", "bnn_lr_prepare_bytes", "bnn_lr_prepare", "bnn_lr_prepare_x3_bytes", "bnn_lr_prepare_x3", "bnn_lr_prepare_many",
     "bnn_gauss_kl_workspace_bytes", "bnn_gauss_kl",
     "bnn_elbo_finalize", "bnn_bbb_final_fwd", "bnn_bbb_final_scratch_bytes", "bnn_philox_normal", "bnn_cast_bf16", "bnn_softplus", "bnn_eval_prepare",
     "bnn_ece_workspace_bytes", "bnn_ece", "bnn_snr_db", "bnn_snr_prune",
@@ -190,6 +190,7 @@ class Plan(C.Structure):
 
 
 PREPARE_MAX = 8
+PREPARE_MANY_MAX = 8          # bnn_lr_prepare_many: layers per launch (csrc/lr_linear.hip: kPrepManyJobs)
 
 
 class PrepareArgs(C.Structure):
@@ -204,6 +205,14 @@ class BnnHipError(RuntimeError):
 
 
 _lib = None
+
+
+
+class LrPrepareJob(C.Structure):
+    """bnn_lr_prepare_job (include/bnn_hip.h)"""
+    _fields_ = [("w_mu", C.c_void_p), ("w_rho", C.c_void_p), ("b_mu", C.c_void_p), ("b_rho", C.c_void_p),
+                ("in_features", C.c_int32), ("out_features", C.c_int32), ("w_frag", C.c_void_p), ("w_frag_bytes", C.c_size_t),
+                ("kl_workspace", C.c_void_p), ("kl_workspace_bytes", C.c_size_t)]
 
 
 def load():
@@ -283,6 +292,8 @@ def load():
     lib.bnn_lr_prepare_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.bnn_lr_prepare_x3_bytes.restype = C.c_size_t
     lib.bnn_lr_prepare_x3_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.bnn_lr_prepare_many.restype = C.c_int
+    lib.bnn_lr_prepare_many.argtypes = [C.POINTER(LrPrepareJob), C.c_int32, C.c_int32, C.c_void_p]
     for fn in (lib.bnn_lr_prepare, lib.bnn_lr_prepare_x3):
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]

@@ -596,6 +596,12 @@ class GraphedElbo:
         # (bnn_lr_rider), so that the row-split final launch (K3r) parks nothing
         nl = len(self.specs)
         self.lr_rider = None
+        # ... and where the hidden layers' fragments come from a prepare launch anyway (>= 7 pairs: no K3s launch to ride on), the
+        # narrow output layer's ride in that SAME launch (bnn_lr_prepare_many): K3r then fetches ready fragments instead of
+        # every row block parking the whole layer
+        if (self.lr_sq and not self.lr_x3 and self.wfrag[nl - 1] is None and any(w is not None for w in self.wfrag) and
+                self.scratch is not None and not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= 64):
+            self.wfrag[nl - 1] = torch.empty(L.load().bnn_lr_prepare_bytes(*self.specs[-1].in_out) // 4, dtype=torch.float32, device=dev)
         if (self.lr and hid == torch.bfloat16 and nl > 1 and self.wfrag[nl - 1] is None and self.scratch is not None and
                 not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= 16 and self.lr_split[nl - 2] is not None and
                 lr_kslice_expected(*self.specs[-2].in_out, S, B)):
@@ -644,6 +650,11 @@ class GraphedElbo:
             if self.x16 is not None:
                 h, h_sq, h_lo = self.x16, self.x16_sq, self.x16_lo
         last = len(self.specs) - 1
+        if self.lr and any(w is not None for w in self.wfrag):
+            # the prepared operands of every layer that takes them, in ONE launch (they depend on no activation)
+            ops.lr_prepare_many([dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
+                                      b_rho=sp.m.bias_rho.detach(), workspace=self.ws[i], out=self.wfrag[i])
+                                 for i, sp in enumerate(self.specs) if self.wfrag[i] is not None], x3=self.lr_x3)
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         sampled = {}                                     # layer -> event: its K1s launch (side stream) has been enqueued
         if self.side is not None:
@@ -671,8 +682,6 @@ class GraphedElbo:
             if self.lr:
                 if self.lr_x3 and i == last:
                     common["math_mode"] = L.MATH_F32          # the narrow output layer: exact fp32 on the fp32 activations
-                if self.wfrag[i] is not None:
-                    ops.lr_prepare(*p, workspace=self.ws[i], out=self.wfrag[i], x3=self.lr_x3)
                 if i == last and self.scratch is not None and not wide_nll(self.specs, self.x.shape[-2]):
                     # output layer + finalize in one launch when the library's row-split form applies (else it issues both)
                     ops.lr_final_fwd((h,) + p, dict(sigma_p=sp.m._prior_spec.sigma_p, want_kl=True, x_sq=h_sq,

@@ -663,6 +663,37 @@ def lr_prepare(w_mu, w_rho, b_mu, b_rho, workspace=None, out=None, x3: bool = Fa
     return out, workspace
 
 
+def lr_prepare_many(jobs: Sequence[dict], x3: bool = False):
+    """bnn_lr_prepare_many: the prepared operands of several layers in ONE launch.  Each job: dict(w_mu, w_rho, b_mu, b_rho,
+    workspace, out) with `out` / `workspace` as in lr_prepare (allocated when absent).  Returns [(w_frag, workspace), ...]."""
+    lib = L.load()
+    if not 1 <= len(jobs) <= L.PREPARE_MANY_MAX:
+        raise BnnHipError(f"lr_prepare_many: 1 .. {L.PREPARE_MANY_MAX} layers per launch")
+    arr = (L.LrPrepareJob * len(jobs))()
+    keep, res = [], []
+    for j, q in enumerate(jobs):
+        require_device(q["w_mu"], q["w_rho"], q["b_mu"], q["b_rho"])
+        w_mu, w_rho = _f32c(q["w_mu"], "weight_mu"), _f32c(q["w_rho"], "weight_rho")
+        b_mu, b_rho = _f32c(q["b_mu"], "bias_mu"), _f32c(q["b_rho"], "bias_rho")
+        K, N = w_mu.shape
+        nbytes = (lib.bnn_lr_prepare_x3_bytes if x3 else lib.bnn_lr_prepare_bytes)(K, N)
+        out = q.get("out")
+        if out is None:
+            out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_mu.device)
+        ws = q.get("workspace")
+        if ws is None:
+            ws = lr_workspace(N, w_mu.device)
+        keep += [w_mu, w_rho, b_mu, b_rho, out, ws]
+        a = arr[j]
+        a.w_mu, a.w_rho, a.b_mu, a.b_rho = w_mu.data_ptr(), w_rho.data_ptr(), b_mu.data_ptr(), b_rho.data_ptr()
+        a.in_features, a.out_features = K, N
+        a.w_frag, a.w_frag_bytes = out.data_ptr(), out.numel() * 4
+        a.kl_workspace, a.kl_workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        res.append((out, ws))
+    L.check(lib.bnn_lr_prepare_many(arr, len(jobs), int(bool(x3)), _stream()), "bnn_lr_prepare_many")
+    return res
+
+
 def _grad_outputs(out, w_mu, w_rho, b_mu, b_rho):
     """Gradient destinations: fresh tensors, or the caller's (e.g. views of one flat all-reduce bucket)."""
     if out is None:

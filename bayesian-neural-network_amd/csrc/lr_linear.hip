@@ -959,11 +959,13 @@ __global__ __launch_bounds__(512) void lr_fwd_kslice_kernel(const LrK p) {
 // (the finalize only needs the layer's totals); the biases go with the blocks of the first k range.
 // X3 (split-bf16 math): a third plane per (tile, k-step) -- the low part bf16(M - bf16(M)) of the mean operand; the fragment
 // block is then [mean hi | variance | mean lo][64 lanes] x 16 B.
+// (kblk, grp) of (nkb, ngrp): the block's k-step range and 128-feature group -- the grid of a one-layer launch, or the block's place
+// inside its layer's share of a several-layer launch (bnn_lr_prepare_many)
 template <bool X3>
-__global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
-                                                               const float* __restrict__ b_mu, const float* __restrict__ b_rho,
-                                                               int K, int N, int kb, float4* __restrict__ frag,
-                                                               float4* __restrict__ ws) {
+__device__ __forceinline__ void lr_prepare_block(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+                                                 const float* __restrict__ b_mu, const float* __restrict__ b_rho,
+                                                 int K, int N, int kb, float4* __restrict__ frag, float4* __restrict__ ws,
+                                                 int kblk, int grp, int nkb, int ngrp) {
   constexpr int LD = 130;                                   // bf16 elements per LDS row (128 + 2: the four 8-row groups a
   constexpr int FB = X3 ? 192 : 128;                        // float4s per fragment block
   __shared__ __bf16 m_s[32 * LD], v_s[32 * LD];             // fragment read touches fall on different banks)
@@ -972,7 +974,6 @@ __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int ksteps = (K + 31) >> 5, T = (N + 15) >> 4;
-  const int kblk = blockIdx.x, grp = blockIdx.y;            // k-step range, 128-feature group
   const int n0 = grp * 128;
   const bool vec = (N & 3) == 0 && !((reinterpret_cast<uintptr_t>(w_mu) | reinterpret_cast<uintptr_t>(w_rho)) & 15);
   float s_ls = 0.f, s_s2 = 0.f, s_m2 = 0.f;
@@ -1057,11 +1058,46 @@ __global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __re
         y += red[w * 3 + 1];
         z += red[w * 3 + 2];
       }
-      const int entry = blockIdx.y * gridDim.x + blockIdx.x;
+      const int entry = grp * nkb + kblk;
       ws[1 + entry] = make_float4(x, y, z, 0.f);
-      if (entry == 0) ws[0] = make_float4(__int_as_float((int)(gridDim.x * gridDim.y)), 0.f, 0.f, 0.f);
+      if (entry == 0) ws[0] = make_float4(__int_as_float(nkb * ngrp), 0.f, 0.f, 0.f);
     }
   }
+}
+
+template <bool X3>
+__global__ __launch_bounds__(256) void lr_prepare_tiled_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+                                                               const float* __restrict__ b_mu, const float* __restrict__ b_rho,
+                                                               int K, int N, int kb, float4* __restrict__ frag,
+                                                               float4* __restrict__ ws) {
+  lr_prepare_block<X3>(w_mu, w_rho, b_mu, b_rho, K, N, kb, frag, ws, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+
+// The prepared operands of SEVERAL layers in one launch (bnn_lr_prepare_many: an evaluation's prepare launches depend on no
+// activation and were one launch per layer, ~4 us of launch boundary each ahead of the first layer): 1-D grid, job j owns the
+// blocks [first[j], first[j + 1]).
+constexpr int kPrepManyJobs = 8;
+struct LrPrepJobs {
+  const float* w_mu[kPrepManyJobs];
+  const float* w_rho[kPrepManyJobs];
+  const float* b_mu[kPrepManyJobs];
+  const float* b_rho[kPrepManyJobs];
+  float4* frag[kPrepManyJobs];
+  float4* ws[kPrepManyJobs];
+  int K[kPrepManyJobs], N[kPrepManyJobs], kb[kPrepManyJobs], nkb[kPrepManyJobs], ngrp[kPrepManyJobs];
+  int first[kPrepManyJobs + 1];
+  int n;
+};
+template <bool X3>
+__global__ __launch_bounds__(256) void lr_prepare_many_kernel(const LrPrepJobs jb) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < kPrepManyJobs; ++i)
+    if (i < jb.n && (int)blockIdx.x >= jb.first[i]) j = i;   // block-uniform
+  const int local = (int)blockIdx.x - jb.first[j];
+  const int nkb = jb.nkb[j];
+  lr_prepare_block<X3>(jb.w_mu[j], jb.w_rho[j], jb.b_mu[j], jb.b_rho[j], jb.K[j], jb.N[j], jb.kb[j], jb.frag[j], jb.ws[j],
+                       local % nkb, local / nkb, nkb, jb.ngrp[j]);
 }
 
 // DEPTH = k-steps of prefetch (PREP only takes 2).  A step's loads -- x / x^2 tiles by LDS-DMA, prepared fragments to
@@ -1897,6 +1933,53 @@ extern "C" size_t bnn_lr_prepare_bytes(int32_t in_features, int32_t out_features
 
 extern "C" size_t bnn_lr_prepare_x3_bytes(int32_t in_features, int32_t out_features) {
   return bnn_lr_prepare_bytes(in_features, out_features) / 2 * 3;
+}
+
+// argument checks of one layer's prepare + its block geometry (kb k-steps x 128 features per block)
+static int lr_prepare_geometry(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
+                               int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
+                               void* kl_workspace, size_t kl_workspace_bytes, bool x3, int& kb, int& nkb, int& groups) {
+  if (!w_mu || !w_rho || !b_mu || !b_rho || !w_frag) return BNN_ERR_NULL;
+  if (in_features <= 0 || out_features <= 0) return BNN_ERR_SHAPE;
+  if (w_frag_bytes < (x3 ? bnn_lr_prepare_x3_bytes(in_features, out_features) : bnn_lr_prepare_bytes(in_features, out_features))) return BNN_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(w_frag) & 15) return BNN_ERR_ALIGN;
+  if (kl_workspace) {
+    if (kl_workspace_bytes < bnn_lr_linear_fwd_workspace_bytes(out_features)) return BNN_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(kl_workspace) & 15) return BNN_ERR_ALIGN;
+  }
+  const int ksteps = (in_features + 31) / 32;
+  groups = (out_features + 127) / 128;
+  const int max_entries = (out_features + 3) / 4 > kPrepEntries ? (out_features + 3) / 4 : kPrepEntries;
+  kb = 1;
+  while ((long)((ksteps + kb - 1) / kb) * groups > max_entries) ++kb;
+  nkb = (ksteps + kb - 1) / kb;
+  return BNN_OK;
+}
+
+extern "C" int bnn_lr_prepare_many(const bnn_lr_prepare_job* jobs, int32_t n_jobs, int32_t x3, void* stream_) {
+  if (!jobs) return BNN_ERR_NULL;
+  if (n_jobs <= 0 || n_jobs > kPrepManyJobs) return BNN_ERR_SHAPE;
+  LrPrepJobs jb{};
+  jb.n = n_jobs;
+  int total = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const bnn_lr_prepare_job& q = jobs[j];
+    int kb, nkb, groups;
+    const int rc = lr_prepare_geometry(q.w_mu, q.w_rho, q.b_mu, q.b_rho, q.in_features, q.out_features, q.w_frag, q.w_frag_bytes,
+                                       q.kl_workspace, q.kl_workspace_bytes, x3 != 0, kb, nkb, groups);
+    if (rc != BNN_OK) return rc;
+    jb.w_mu[j] = q.w_mu; jb.w_rho[j] = q.w_rho; jb.b_mu[j] = q.b_mu; jb.b_rho[j] = q.b_rho;
+    jb.frag[j] = reinterpret_cast<float4*>(q.w_frag);
+    jb.ws[j] = reinterpret_cast<float4*>(q.kl_workspace);
+    jb.K[j] = q.in_features; jb.N[j] = q.out_features; jb.kb[j] = kb; jb.nkb[j] = nkb; jb.ngrp[j] = groups;
+    jb.first[j] = total;
+    total += nkb * groups;
+  }
+  for (int j = n_jobs; j <= kPrepManyJobs; ++j) jb.first[j] = total;
+  if (x3) hipLaunchKernelGGL(lr_prepare_many_kernel<true>, dim3((unsigned)total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), jb);
+  else hipLaunchKernelGGL(lr_prepare_many_kernel<false>, dim3((unsigned)total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), jb);
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? BNN_OK : (int)err;
 }
 
 static int lr_prepare_impl(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,

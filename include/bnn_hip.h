@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 6
+#define BNN_HIP_ABI_VERSION 7
 #define BNN_EPS_MAP_VERSION 2     /* 1: Philox4x32-10 (rounds 1-2); 2: Philox4x32-7 */
 #ifndef BNN_PHILOX_ROUNDS          /* build-time choice (csrc/Makefile: make PHILOX_ROUNDS=10): 7 = map version 2 (the product), */
 #define BNN_PHILOX_ROUNDS 7        /* 10 = rocRAND's PHILOX4_32_10 / map version 1.  bnn_philox_rounds() tells what a library runs */
@@ -406,6 +406,21 @@ int bnn_lr_prepare(const float* w_mu, const float* w_rho, const float* b_mu, con
 /* The same for BNN_MATH_BF16X3: the fragments additionally carry the low part bf16(M - bf16(M)) of the mean operand
  * ([mean hi | variance | mean lo] per feature tile and k-step: 1.5 x the bytes). */
 size_t bnn_lr_prepare_x3_bytes(int32_t in_features, int32_t out_features);
+/* (ABI 7) The prepared operands of several layers in ONE launch: an evaluation's prepare launches depend on no activation, and
+ * one launch per layer put ~4 us of launch boundary per layer ahead of the first layer's kernel.  Bitwise the fragments and KL
+ * entries of n_jobs bnn_lr_prepare (x3 != 0: bnn_lr_prepare_x3) calls; n_jobs <= 8. */
+typedef struct {
+  const float* w_mu;
+  const float* w_rho;
+  const float* b_mu;
+  const float* b_rho;
+  int32_t in_features, out_features;
+  void* w_frag;
+  size_t w_frag_bytes;
+  void* kl_workspace;        /* optional, as in bnn_lr_prepare */
+  size_t kl_workspace_bytes;
+} bnn_lr_prepare_job;
+int bnn_lr_prepare_many(const bnn_lr_prepare_job* jobs, int32_t n_jobs, int32_t x3, void* stream);
 int bnn_lr_prepare_x3(const float* w_mu, const float* w_rho, const float* b_mu, const float* b_rho,
                       int32_t in_features, int32_t out_features, void* w_frag, size_t w_frag_bytes,
                       void* kl_workspace, size_t kl_workspace_bytes, void* stream);

@@ -606,6 +606,27 @@ def test_bbb_throughput_forms_agree(dev, monkeypatch):
         assert float(sums[3]) == S
 
 
+@pytest.mark.parametrize("x3", [False, True])
+def test_lr_prepare_many_equals_the_per_layer_launches(dev, x3):
+    """bnn_lr_prepare_many (the prepared operands of several layers in one launch) against one bnn_lr_prepare[_x3] call per layer:
+    fragments and KL workspace entries bit for bit -- the three layers of the MNIST network, an odd-shaped layer (partial tiles,
+    K and N not multiples of the block) and a layer wide enough for several k-step ranges per group."""
+    rs = np.random.RandomState(7)
+    shapes = [(784, 1200), (1200, 1200), (1200, 10), (100, 72), (37, 5), (4096, 256)]
+    layers = [[t(rs.uniform(-0.3, 0.3, sh).astype(np.float32)).to(dev), t(rs.uniform(-5, -4, sh).astype(np.float32)).to(dev),
+               t(rs.uniform(-0.3, 0.3, sh[1]).astype(np.float32)).to(dev), t(rs.uniform(-5, -4, sh[1]).astype(np.float32)).to(dev)]
+              for sh in shapes]
+    ref = [ops.lr_prepare(*w, x3=x3) for w in layers]
+    got = ops.lr_prepare_many([dict(w_mu=w[0], w_rho=w[1], b_mu=w[2], b_rho=w[3]) for w in layers], x3=x3)
+    torch.cuda.synchronize()
+    for sh, (rf, rw), (gf, gw) in zip(shapes, ref, got):
+        assert torch.equal(rf.view(torch.int32), gf.view(torch.int32)), sh
+        n = int(rw.view(torch.int32)[0])
+        assert n == int(gw.view(torch.int32)[0]) and torch.equal(rw.view(-1, 4)[1:1 + n], gw.view(-1, 4)[1:1 + n]), sh
+    with pytest.raises(ops.BnnHipError):
+        ops.lr_prepare_many([dict(w_mu=w[0], w_rho=w[1], b_mu=w[2], b_rho=w[3]) for w in layers] * 2, x3=x3)      # > 8 layers
+
+
 @pytest.mark.parametrize("lr", [False, True])
 def test_graphed_predict_replays_predict_mc_with_fresh_epsilon(dev, lr):
     """engine.GraphedPredict (`net.predictor`): predict_mc as one captured evaluation -- every replay equals predict_mc at the
