@@ -67,6 +67,12 @@ BLOCK_GEMM_MIN_BATCH = 512
 # only ever runs where a matmul block has not started yet -- the launches take turns on a CU instead of sharing it, and the
 # cross-stream edges cost more than the little that overlaps.  The bits are the same either way (tests).
 SAMPLE_BESIDE_MATMUL = False
+# LR, one minibatch: the prepare launch (fragments of the layers after the first) depends on no activation and the first layer (K3s
+# on the shared input, 152 blocks) leaves a hundred CUs idle -- it can run on a side stream beside that layer (a fork / join inside
+# the evaluation, so a captured graph keeps the edges).  Measured SLOWER by 9 us at every sample count (7 ... 64 samples: 88 against
+# 79 us at 8; profiles/r04_prepare_side_stream.log): a cross-stream edge inside a hipGraph costs more than the 5 us launch it
+# hides -- the same lesson as SAMPLE_BESIDE_MATMUL.  Off.
+PREPARE_BESIDE_FIRST_LAYER = False
 
 
 def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:
@@ -622,6 +628,9 @@ class GraphedElbo:
         # matmuls of the layers before them (vector / memory work next to matrix-core work on the same CUs: layer l's K1g
         # waits for layer l's K1s only), forked and joined inside the evaluation so that a captured graph keeps the edges
         self.side = torch.cuda.Stream(device=dev) if (SAMPLE_BESIDE_MATMUL and sum(self.lib) >= 1 and not self.lr) else None
+        self.prep_side = (torch.cuda.Stream(device=dev)
+                          if (PREPARE_BESIDE_FIRST_LAYER and self.lr and self.wfrag[0] is None and any(w is not None for w in self.wfrag))
+                          else None)
         self.graph = None
         if capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
@@ -650,11 +659,21 @@ class GraphedElbo:
             if self.x16 is not None:
                 h, h_sq, h_lo = self.x16, self.x16_sq, self.x16_lo
         last = len(self.specs) - 1
+        prepared = None                                  # event: the side stream's prepare launch has been enqueued
         if self.lr and any(w is not None for w in self.wfrag):
             # the prepared operands of every layer that takes them, in ONE launch (they depend on no activation)
-            ops.lr_prepare_many([dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
-                                      b_rho=sp.m.bias_rho.detach(), workspace=self.ws[i], out=self.wfrag[i])
-                                 for i, sp in enumerate(self.specs) if self.wfrag[i] is not None], x3=self.lr_x3)
+            jobs = [dict(w_mu=sp.m.weight_mu.detach(), w_rho=sp.m.weight_rho.detach(), b_mu=sp.m.bias_mu.detach(),
+                         b_rho=sp.m.bias_rho.detach(), workspace=self.ws[i], out=self.wfrag[i])
+                    for i, sp in enumerate(self.specs) if self.wfrag[i] is not None]
+            if self.prep_side is not None:
+                main = torch.cuda.current_stream()
+                self.prep_side.wait_stream(main)         # fork: behind the previous evaluation's finalize (it read these buffers)
+                with torch.cuda.stream(self.prep_side):
+                    ops.lr_prepare_many(jobs, x3=self.lr_x3)
+                    prepared = torch.cuda.Event()
+                    prepared.record(self.prep_side)
+            else:
+                ops.lr_prepare_many(jobs, x3=self.lr_x3)
         grp = dict(sample_group=self.group, sample_group_stride=self.samples) if self.G > 1 else {}
         sampled = {}                                     # layer -> event: its K1s launch (side stream) has been enqueued
         if self.side is not None:
@@ -680,6 +699,9 @@ class GraphedElbo:
                           eps_mode=L.EPS_PHILOX, seed=state.seed, layer_id=sp.layer_id, sample_offset=self.lo,
                           sample_counter=self.counter, workspace=self.ws[i], out=self.bufs[i], form=state.form, **grp)
             if self.lr:
+                if prepared is not None and self.wfrag[i] is not None:
+                    torch.cuda.current_stream().wait_event(prepared)      # join: the first layer that reads prepared operands
+                    prepared = None
                 if self.lr_x3 and i == last:
                     common["math_mode"] = L.MATH_F32          # the narrow output layer: exact fp32 on the fp32 activations
                 if i == last and self.scratch is not None and not wide_nll(self.specs, self.x.shape[-2]):
