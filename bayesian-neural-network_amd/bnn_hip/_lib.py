@@ -215,7 +215,7 @@ class LrPrepareJob(C.Structure):
                 ("kl_workspace", C.c_void_p), ("kl_workspace_bytes", C.c_size_t)]
 
 
-def load():
+def _load_real():
     """Load libbnn_hip.so once.  Raises BnnHipError (never falls back) when the library is
     missing, has a different ABI version or lacks a symbol the header declares."""
     global _lib
@@ -331,6 +331,53 @@ def load():
         raise BnnHipError(f"libbnn_hip.so ABI version {v} != binding version {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def load():
+    """The C-ABI library (loaded once); inside `recording()` a proxy that also records the launches."""
+    lib = _load_real()
+    return _RecordingLib(lib, _recording) if _recording is not None else lib
+
+
+class _RecordingLib:
+    """The library with every LAUNCH function (int f(..., void* stream)) also appended to a list as (function, arguments): what
+    engine.GraphedElbo(capture="calls") replays natively -- the argument structures are baked exactly as a captured hipGraph
+    bakes them, and stay alive with the list."""
+
+    def __init__(self, lib, calls):
+        self._lib, self._calls = lib, calls
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        at = getattr(fn, "argtypes", None)
+        if getattr(fn, "restype", None) is C.c_int and at and at[-1] is C.c_void_p and not name.endswith("_plan"):
+            calls = self._calls
+
+            def launch(*args):
+                rc = fn(*args)
+                calls.append((fn, args, name))
+                return rc
+            return launch
+        return fn
+
+
+_recording = None
+
+
+class recording:
+    """with recording() as calls: ...   -- every launch the block makes through load() is executed AND recorded."""
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise BnnHipError("recording() does not nest")
+        _recording = []
+        return _recording
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = None
+        return False
 
 
 def check(status: int, what: str):

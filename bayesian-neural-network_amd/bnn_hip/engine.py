@@ -632,7 +632,25 @@ class GraphedElbo:
                           if (PREPARE_BESIDE_FIRST_LAYER and self.lr and self.wfrag[0] is None and any(w is not None for w in self.wfrag))
                           else None)
         self.graph = None
-        if capture:
+        self.calls = None
+        if capture == "calls":
+            # The evaluation as a recorded list of C-ABI launches, replayed by calling them again: the argument structures are baked
+            # exactly as a hipGraph bakes them (static buffers, the device-resident sample counter), but the launches go to the stream
+            # one by one -- no graph, so none of the ~8 us a hipGraph replay spends around its nodes; the host pays ~3-5 us per
+            # launch instead, hidden as long as an evaluation's kernels take longer than that.
+            self._enqueue()                      # warm-up (also validates arguments eagerly)
+            take_samples(self.total_samples)
+            torch.cuda.synchronize()
+            before = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+            with L.recording() as calls:
+                self._eager()
+            take_samples(self.total_samples * self.per_replay)
+            torch.cuda.synchronize()
+            if torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0) != before:
+                raise ops.BnnHipError("GraphedElbo(capture='calls'): the evaluation allocated device memory while it was recorded -- "
+                                      "a replay would launch on freed buffers; use capture=True (hipGraph) for this configuration")
+            self.calls = list(calls)
+        elif capture:
             self._enqueue()                      # warm-up (also validates arguments eagerly)
             take_samples(self.total_samples)
             torch.cuda.synchronize()
@@ -765,6 +783,13 @@ class GraphedElbo:
             self._enqueue()
 
     def replay(self) -> torch.Tensor:
+        if self.calls is not None:
+            for fn, args, name in self.calls:
+                rc = fn(*args)
+                if rc:
+                    L.check(rc, name)
+            take_samples(self.total_samples * self.per_replay)
+            return self.sums
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 self.graph.replay() if self.graph is not None else self._eager()

@@ -262,6 +262,7 @@ def _bbb_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, prior: PriorSpec,
         a.rider = C.addressof(rider[0])
     res = dict(y=y, y16=_y16(a, y) if want_y16 else None, workspace=workspace, log_prior=lp, log_q=lq, eps_w=dw, eps_b=db, y_lo=y_lo)
     keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_w, eps_b, sample_counter, split_scratch, w_sigma, rider, x_lo, y_lo)
+    a._keep = keep                    # (the structure owns what its pointers refer to: engine.GraphedElbo(capture="calls") replays it)
     return a, res, keep
 
 
@@ -344,6 +345,7 @@ def build_sample_job(layers, *, n_samples: int, seed: int = 0, sample_offset: in
             raise BnnHipError("bbb_sample_weights: cast = (contiguous fp32 source, contiguous bf16 destination) of one size")
         a.cast_src, a.cast_dst, a.cast_n = src.data_ptr(), dst.data_ptr(), src.numel()
         keep.append((src, dst))
+    a._keep = keep                    # (the structure owns what its pointers refer to: engine.GraphedElbo(capture="calls") replays it)
     return a, res, keep
 
 
@@ -467,6 +469,7 @@ def _lr_build(x, w_mu, w_rho, b_mu, b_rho, *, n_samples: int, sigma_p: float, ma
         rd = (rd, rw, rider["w_frag"], rider["workspace"])
     res = dict(y=y, y_sq=out_sq, workspace=workspace, kl3=kl3, eps_act=da, eps_b=db, v=v, y16=y16, hfac=hfac, y_lo=y_lo)
     keep = (xs, w_mu, w_rho, b_mu, b_rho, eps_act, eps_b, sample_counter, x_sq, w_frag, out_sq, workspace, split_scratch, rd, x_lo, y_lo)
+    a._keep = keep                    # (the structure owns what its pointers refer to: engine.GraphedElbo(capture="calls") replays it)
     return a, res, keep
 
 
@@ -590,6 +593,7 @@ def _fin_build(*, workspaces, layer_in, layer_out, local_reparam: bool, prior: P
         a.loss = C.pointer(la)
         out["loss"] = res
         keep += [la, loss["beta"]] + list(res)
+    a._keep = keep
     return a, out, keep
 
 

@@ -722,6 +722,19 @@ def main():
                                                                       "note": "8 dependent evaluations per graph replay (fresh epsilon each): the replay gap amortised"}
             out["single_evaluation_us_8_per_replay"] = dt8 * 1e6 / (full_ * 8)
             del e1b
+            # ... and as a recorded list of C-ABI launches called again (engine.GraphedElbo(capture="calls")): no hipGraph, so none
+            # of the ~8 us a graph replay spends around its nodes; the host pays a few us per launch instead
+            try:
+                e1c = make_evaluator(engine, net, x, y, 1, 1, graph="calls")
+                g_, full_, _, warm_ = plan_groups(800, 80, 1)
+                dtc = run_groups(e1c, full_, warm_, None)
+                out["single_evaluation_in_flight"]["recorded_launches"] = {
+                    "us_per_evaluation": dtc * 1e6 / full_, "samples_per_s": full_ / dtc, "launches_per_evaluation": len(e1c.calls),
+                    "note": "the evaluation's launches recorded once and called again per evaluation (no graph): bit-identical results"}
+                out["single_evaluation_us_recorded_launches"] = dtc * 1e6 / full_
+                del e1c
+            except Exception as e:                                   # (a configuration that allocates while recording)
+                out["single_evaluation_in_flight"]["recorded_launches"] = {"error": repr(e)[:200]}
             # MC-batched evaluations of ONE minibatch (C4's per-GPU share is 8 samples; 64 = C4 on one GPU)
             mc = []
             for (S, steps) in ((8, 200), (64, 60), (256, 24)):
@@ -732,6 +745,15 @@ def main():
                            "layer2_bound": r2["bound"], "layer2_frac": r2["frac"],
                            "layer2_hbm_algorithmic_frac": r2.get("hbm_algorithmic", r2)["frac"]})
                 del e2
+                if S <= 8:                                          # few samples: the same evaluation as recorded launches
+                    try:
+                        e2c = make_evaluator(engine, net, x, y, S, 1, graph="calls")
+                        g_, full_, _, warm_ = plan_groups(2 * steps, steps // 5, 1)
+                        dtc = run_groups(e2c, full_, warm_, None)
+                        mc[-1]["us_per_evaluation_recorded_launches"] = dtc * 1e6 / full_
+                        del e2c
+                    except Exception as e:
+                        mc[-1]["recorded_launches_error"] = repr(e)[:200]
             extras["mc_batched_one_minibatch"] = mc
             # the headline workload in the two math modes that meet ELBO rtol 1e-4 against the reference's fp32 arithmetic at
             # EVERY beta (plain bf16 does for beta >= 2^-6 only: DESIGN.md 2): exact-fp32 matrix core, split-bf16 operands

@@ -606,6 +606,32 @@ def test_bbb_throughput_forms_agree(dev, monkeypatch):
         assert float(sums[3]) == S
 
 
+@pytest.mark.parametrize("lr", [False, True])
+@pytest.mark.parametrize("S", [1, 8])
+def test_recorded_launch_list_replays_what_the_graph_replays(dev, lr, S):
+    """engine.GraphedElbo(capture="calls"): the evaluation as a recorded list of C-ABI launches called again -- bit for bit the
+    replay of the captured hipGraph at the same Philox sample indices (sums, per-sample scalars, logits), replay after replay,
+    and the device-resident sample counter advances the same way."""
+    from bnn_hip import engine
+    B, dims, seed, c = 128, (784, 1200, 10), 777, 9000
+    bnn_hip.set_math("bf16")
+    net, sd = build_net(dev, lr, dims, "classification")
+    x, y = synth.synth_batch("classification", B, dims[0], dims[2], seed=5)
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    bnn_hip.manual_seed(seed, counter=c)
+    ev_c = engine.GraphedElbo(net, xd, yd, S, capture="calls")          # warm-up + the recording pass: [c, c + 2 S)
+    assert ev_c.graph is None and len(ev_c.calls) >= 3
+    bnn_hip.manual_seed(seed, counter=c + S)
+    ev_g = engine.GraphedElbo(net, xd, yd, S)                           # warm-up: [c + S, c + 2 S)
+    for r in range(3):
+        sc = ev_c.replay().clone()
+        sg = ev_g.replay().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(sc, sg), (r, sc, sg)
+        assert torch.equal(ev_c.logits, ev_g.logits) and all(torch.equal(ev_c.out[k], ev_g.out[k]) for k in ev_c.out)
+        assert int(ev_c.counter.item()) == int(ev_g.counter.item()) == c + (3 + r) * S
+
+
 @pytest.mark.parametrize("x3", [False, True])
 def test_lr_prepare_many_equals_the_per_layer_launches(dev, x3):
     """bnn_lr_prepare_many (the prepared operands of several layers in one launch) against one bnn_lr_prepare[_x3] call per layer:

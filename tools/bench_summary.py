@@ -6,10 +6,10 @@ print("value %.0f samples/s  %.2f us/step | roof %s %.1f us frac %s" % (d["value
 for k, m in d.get("extras", {}).get("math_modes", {}).items():
     print("  math %s: %.0f samples/s (%.2f of the headline), layer2 %.1f us [%s] frac %s" % (k, m["samples_per_s"], m.get("vs_headline", float("nan")), m["roofline"]["avg_launch_us"], m["roofline"]["bound"], m["roofline"]["frac"]))
 if "single_evaluation_in_flight" in d:
-    s = d["single_evaluation_in_flight"]; print("single eval %.1f us, layer2 %.1f us" % (s["us_per_evaluation"], s["layer2"]["avg_launch_us"]))
+    s = d["single_evaluation_in_flight"]; print("single eval %.1f us (8 per replay %s, recorded launches %s), layer2 %.1f us" % (s["us_per_evaluation"], s.get("eight_per_replay", {}).get("us_per_evaluation"), s.get("recorded_launches", {}).get("us_per_evaluation", s.get("recorded_launches")), s["layer2"]["avg_launch_us"]))
 e = d.get("extras", {})
 for m in e.get("mc_batched_one_minibatch", []):
-    print("  S=%d one minibatch: %.0f samples/s %.1f us/eval, layer2 %.1f us frac %s" % (m["mc_samples_per_evaluation"], m["samples_per_s"], m["us_per_evaluation"], m["layer2_us_per_launch"], m.get("layer2_frac", m.get("layer2_hbm_frac"))))
+    print("  S=%d one minibatch: %.0f samples/s %.1f us/eval, layer2 %.1f us frac %s%s" % (m["mc_samples_per_evaluation"], m["samples_per_s"], m["us_per_evaluation"], m["layer2_us_per_launch"], m.get("layer2_frac", m.get("layer2_hbm_frac")), (" | recorded launches %.1f us" % m["us_per_evaluation_recorded_launches"]) if "us_per_evaluation_recorded_launches" in m else ""))
 if "lr_variant" in e:
     l = e["lr_variant"]; s1 = l["single_evaluation_in_flight"]
     print("  LR: %.0f samples/s, layer2 %s %.1f us frac %.3f | single %.1f us, layer2 %.1f us frac %.3f" % (l["samples_per_s"], l["roofline"]["kernel"], l["roofline"]["avg_launch_us"], l["roofline"]["frac"], s1["us_per_evaluation"], s1["layer2_us_per_launch"], s1["layer2_hbm_frac"]))

@@ -13,7 +13,7 @@ bnn_hip.set_math("bf16")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for lr in (False, True):
     net, x, y = build_net(DIMS["mnist"], lr, 128, dev, "classification", n_minibatches=1)
-    ev = engine.GraphedElbo(net, x[0], y[0], S)
+    ev = engine.GraphedElbo(net, x[0], y[0], S, capture=os.environ.get("CAPTURE", "graph") if os.environ.get("CAPTURE") else True)
     for _ in range(20):
         ev.replay()
     torch.cuda.synchronize()
