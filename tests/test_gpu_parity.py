@@ -668,6 +668,11 @@ def test_graphed_predict_replays_predict_mc_with_fresh_epsilon(dev, lr):
         bnn_hip.manual_seed(seed, counter=c)
         p = net.predictor(xs[0].clone(), S)                   # its warm-up pass drew the samples [c, c + S)
         warm = p.probs.clone()
+        if math == "bf16":                                    # the recorded-launch replay of the same prediction: the same bits
+            bnn_hip.manual_seed(seed, counter=c - S)          # (its warm-up + recording pass: [c - S, c + S))
+            pc = net.predictor(xs[0].clone(), S, capture="calls")
+            bnn_hip.manual_seed(seed, counter=c + S)
+            first = pc.replay()[1].clone()
         got = []
         for r in range(2):                                    # replay r: samples [c + (r + 1) S, c + (r + 2) S)
             preds, probs = p.replay()
@@ -675,6 +680,8 @@ def test_graphed_predict_replays_predict_mc_with_fresh_epsilon(dev, lr):
             assert torch.equal(preds, probs.argmax(1))
             got.append(probs.clone())
         assert int(p.counter.item()) == c + 3 * S
+        if math == "bf16":
+            assert torch.equal(first, got[0])
         p.x.copy_(net._flat(xs[1]))
         other = p.replay()[1].clone()
         for k, (first, want_of) in enumerate(((c, warm), (c + S, got[0]), (c + 2 * S, got[1]))):

@@ -34,7 +34,8 @@ for lr in (False, True):
     with torch.no_grad():
         pred = net.predictor(x, S)                        # engine.GraphedPredict: captured, fresh eps per replay
     forms = (("python loop of net(X, sample=True)", loop, 30), ("predict_mc", fused, 100), ("predict_mc as a hipGraph*", g.replay, 300),
-             ("net.predictor(x, S).replay()", pred.replay, 300))
+             ("net.predictor(x, S).replay()", pred.replay, 300),
+             ("net.predictor(x, S, capture='calls').replay()", net.predictor(x, S, capture="calls").replay, 300))
     for name, fn, n in forms:
         with torch.no_grad():
             for _ in range(5): fn()
