@@ -575,9 +575,9 @@ def cpu_baseline(dims, lr, batch, budget_s=15.0):
             "kl_elements_per_s": p.n_stochastic() / med}
 
 
-def timed_config(engine, net, x, y, S_global, G, steps, dist=None, every_eval=False):
+def timed_config(engine, net, x, y, S_global, G, steps, dist=None, every_eval=False, graph=True):
     """samples/s and us per minibatch evaluation of one evaluator configuration (own warm-up)."""
-    ev = make_evaluator(engine, net, x, y, S_global, G)
+    ev = make_evaluator(engine, net, x, y, S_global, G, graph=graph)
     g, full, rem, warm = plan_groups(steps, max(2 * G, steps // 10), G)
     dt = run_groups(ev, full, warm, None, dist, every_eval)
     return ev, S_global * full * g / dt, dt * 1e6 / (full * g)
@@ -851,6 +851,16 @@ def main():
                            "us_per_evaluation": us, "collective": "one RCCL all-reduce of the 4-vector per evaluation, asynchronous: "
                                                                   "the next evaluation is launched behind it (pipelined)"})
                 del e6
+                if S_tot // world <= 16:
+                    # few samples per GPU: the evaluation as a recorded launch list instead of a hipGraph (no ~8 us of graph
+                    # replay around ~60 us of kernels), pipelined as above
+                    try:
+                        e6, rate, us = timed_config(engine, net, x, y, S_tot, 1, 200, dist, every_eval=False, graph="calls")
+                        c4.append({"mc_samples_per_evaluation": S_tot, "mc_samples_per_gpu": S_tot // world, "samples_per_s": rate,
+                                   "us_per_evaluation": us, "collective": "pipelined, the evaluation replayed as a recorded launch list (no hipGraph)"})
+                        del e6
+                    except Exception as e:
+                        c4.append({"mc_samples_per_evaluation": S_tot, "recorded_launches_error": repr(e)[:200]})
         extras["c4"] = c4
         if rank == 0:
             out["extras"] = extras
