@@ -492,6 +492,10 @@ class GraphedElbo:
     one launch per layer over the G x samples (minibatch, MC sample) pairs, exactly as the MC samples of one
     minibatch do.  Every pair draws its own weights (its own global sample index).
 
+    `capture`: True = a hipGraph (replayed on the stream current at replay time, or on `stream`); "calls" = the evaluation's C-ABI
+    launches recorded once and called again per replay, on the stream they were recorded on -- no graph, so none of the ~8 us a
+    graph replay spends around its nodes: the faster form for evaluations of up to ~16 (minibatch, sample) pairs; False = eager.
+
     `replay()` returns the static float32 tensor [G, 4] (or [4] for one minibatch) of
     {sum log p | sum KL, sum log q | 0, sum nll, local sample count} per minibatch: the vector(s) a sharded job
     all-reduces.  `out` holds the per-(minibatch, sample) scalars, `logits` the outputs [G * S_local, B, C]."""
@@ -638,11 +642,14 @@ class GraphedElbo:
             # exactly as a hipGraph bakes them (static buffers, the device-resident sample counter), but the launches go to the stream
             # one by one -- no graph, so none of the ~8 us a hipGraph replay spends around its nodes; the host pays ~3-5 us per
             # launch instead, hidden as long as an evaluation's kernels take longer than that.
-            self._enqueue()                      # warm-up (also validates arguments eagerly)
+            # (the stream is baked into the recorded calls: `stream` if given, else the stream current now)
+            rec_stream = self.stream if self.stream is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(rec_stream):
+                self._enqueue()                  # warm-up (also validates arguments eagerly)
             take_samples(self.total_samples)
             torch.cuda.synchronize()
             before = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
-            with L.recording() as calls:
+            with L.recording() as calls, torch.cuda.stream(rec_stream):
                 self._eager()
             take_samples(self.total_samples * self.per_replay)
             torch.cuda.synchronize()
