@@ -80,6 +80,23 @@ def use_block_gemm(sp, batch: int, hidden_dtype) -> bool:
         state.form == L.FORM_AUTO and state.math == L.MATH_BF16
 
 
+# BBB, bf16 math: from this many (minibatch, sample) pairs per launch on, the output layer + finalize can run in the row-split form
+# (K1r) behind a sampling launch of their own (K1s for the output layer's few weights) instead of one block per pair that samples,
+# multiplies and finalizes (K1c: 28.6 us at 256 pairs + 4 us for the sums launch).  Built, oracle-checked at (256, 1), and measured
+# SLOWER: 621 against 613 us per launch group of 256 minibatches (tools/rows_alone_ab.py, profiles/r04_rows_alone_ab.log) -- the
+# sampling launch and 2304 small blocks cost more than the one chain per pair they replace.  Off (set to 64 to try it).
+FINAL_ROWS_ALONE_MIN_SAMPLES = 10 ** 9
+FINAL_ROWS_ALONE_MAX_SAMPLES = 4096
+
+
+def final_rows_alone(specs, n_samples: int, batch: int, hidden_dtype) -> bool:
+    if len(specs) < 2 or any(sp.lr for sp in specs) or hidden_dtype != torch.bfloat16 or state.form != L.FORM_AUTO or \
+            state.math != L.MATH_BF16:
+        return False
+    k_last, n_last = specs[-1].in_out
+    return FINAL_ROWS_ALONE_MIN_SAMPLES <= n_samples <= FINAL_ROWS_ALONE_MAX_SAMPLES and n_last <= 16 and batch <= 128 and k_last % 8 == 0
+
+
 def presample_from(specs, n_samples: int, batch: int, hidden_dtype) -> int:
     """Index of the layer whose launch carries the sampling job of all layers after it (they run matmul-only), or -1:
     the layer before the output layer, or the first layer for very few (minibatch, sample) pairs."""
@@ -622,6 +639,13 @@ class GraphedElbo:
         self.pre_from = presample_from(self.specs, S, B, hid)      # the layer whose launch samples all layers after it
         self.rows = self.pre_from >= 0
         self.w_pre, self.b_pre = [None] * len(self.specs), [None] * len(self.specs)
+        # many pairs: the output layer's weights from a sampling launch of its own, then the row-split final form
+        self.rows_alone = (not self.rows) and self.scratch is not None and not self.lib[-1] and final_rows_alone(self.specs, S, B, hid)
+        if self.rows_alone:
+            k_i, n_i = self.specs[-1].in_out
+            self.w_pre[-1] = torch.empty((S, n_i, k_i), dtype=torch.bfloat16, device=dev)
+            self.b_pre[-1] = torch.empty((S, n_i), dtype=torch.float32, device=dev)
+            self.ws[-1] = ops.sample_workspace(S, k_i, n_i, dev)
         if self.rows:
             for i in range(self.pre_from + 1, len(self.specs)):
                 k_i, n_i = self.specs[i].in_out
@@ -753,7 +777,11 @@ class GraphedElbo:
                 kw = dict(prior=sp.m._prior_spec, want_stats=True, split_scratch=self.split[i], w_sigma=self.wsigma[i], **common)
                 if self.x3:
                     kw.update(x_lo=h_lo if h.dtype == torch.bfloat16 else None, out_lo=self.bufs_lo[i])
-                if i == last and self.rows:
+                if i == last and self.rows_alone:
+                    ops.bbb_sample_weights([dict(w_mu=p[0], w_rho=p[1], b_mu=p[2], b_rho=p[3], prior=sp.m._prior_spec, layer_id=sp.layer_id,
+                                                 workspace=self.ws[i], w_out=self.w_pre[i], b_out=self.b_pre[i])],
+                                           n_samples=self.n_local, seed=state.seed, sample_offset=self.lo, sample_counter=self.counter, **grp)
+                if i == last and (self.rows or self.rows_alone):
                     ops.bbb_final_fwd((h, None, None, None, None),
                                       dict(n_samples=self.n_local, prior=sp.m._prior_spec, math_mode=math_mode, relu=sp.relu,
                                            y_dtype=self.bufs[i].dtype, eps_mode=L.EPS_ZERO, want_stats=False, out=self.bufs[i],

@@ -957,7 +957,9 @@ __global__ __launch_bounds__(256) void bbb_final_rows_kernel(const FinRows p, co
     if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
     return;
   }
-  // ---- samples meet: the sample whose ticket is last folds the 4-vector(s) and advances the Philox counter
+  // ---- samples meet: the sample whose ticket is last folds the 4-vector(s) and advances the Philox counter (no ticket: a
+  // follow-up launch does both)
+  if (!fp.ticket) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t t2 = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t2 != (uint32_t)fk.S - 1u) return;
@@ -2450,6 +2452,7 @@ static constexpr int kFinalMaxSlices = 8;
 // above this many samples a one-block follow-up launch folds the sums: per-block fences cost more (re-measured this
 // round at 20 / 32 / 64 pairs: 16 -> 32 loses 6 % / 4 % / 1 %)
 static constexpr int kFinalTicketMaxSamples = 16;
+static constexpr int kRowsTicketMaxSamples = 64;     // K1r: up to here the last sample's last block folds the sums (<= 4 round trips)
 
 // reduce.hip: sums over the per-sample outputs + sample-counter advance (one block)
 extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream);
@@ -2483,10 +2486,12 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
   if (a->w_sampled) {
     // ---- pre-sampled output layer: the row-split form (K1r) when the shapes allow it, else matmul-only K1 + K4
     const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features;
-    const bool rows = a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 64 && !f->local_reparam &&
+    // (S: a grid of S x (ceil(B / 16) + 1) small blocks; 64 until round 4 -- the launch group of 256 minibatches takes this form
+    // behind its own sampling launch since: 28.6 + 4.1 us of one-block-per-pair K1c + the sums launch against ~17 us)
+    const bool rows = a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 4096 && !f->local_reparam &&
                       nl >= 1 && f->n_samples == S && f->classes == N && f->batch == B && f->logits == a->y && f->nll &&
                       f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
-                      !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) && !a->rider &&
+                      !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || S > kRowsTicketMaxSamples || f->ticket) && !a->rider &&
                       (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(a->y) & 15));
     if (!rows) {
       rc = bnn_bbb_linear_fwd(a, stream_);
@@ -2503,8 +2508,11 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
     char* base = reinterpret_cast<char*>(f->scratch);
     fr.tickets = reinterpret_cast<uint32_t*>(base);
     fr.parts = reinterpret_cast<float*>(base + (((size_t)S * 4 + 255) / 256) * 256);      // the K-slice statistics' region
+    // (many samples: the sums of the per-sample scalars and the counter advance by a one-block follow-up kernel, as for K1c below --
+    // one thread folding hundreds of samples behind the last block's ticket would be the longest thing in the launch)
+    const bool rows_tail = S > kRowsTicketMaxSamples && !tr.out4;
     fp.sums = f->sums;
-    fp.ticket = f->ticket;
+    fp.ticket = rows_tail ? nullptr : f->ticket;
     fp.ks = 1; fp.ks_ticket = nullptr; fp.ks_stats = nullptr; fp.ks_tiles = nullptr;
     const int RB = (B + 15) / 16;
     if (a->x_dtype == BNN_BF16)
@@ -2514,7 +2522,8 @@ extern "C" int bnn_bbb_final_fwd(const bnn_bbb_fwd_args* a, const bnn_finalize_a
       hipLaunchKernelGGL(bbb_final_rows_kernel<true>, dim3((unsigned)(S * (RB + 1))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                          fr, fp, tr);
     const hipError_t e2 = hipGetLastError();
-    return e2 == hipSuccess ? BNN_OK : (int)e2;
+    if (e2 != hipSuccess) return (int)e2;
+    return rows_tail ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
   }
   const bool fuse = al && a->out_features <= 16 && a->batch <= 128 && a->want_stats && !f->local_reparam && nl >= 1 &&
                     f->layer_workspace[nl - 1] == a->workspace && f->n_samples == a->n_samples &&
