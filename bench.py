@@ -810,6 +810,8 @@ def main():
                 modes[mname] = {"samples_per_s": rate, "us_per_minibatch": us, "kl_elements_per_s": rate * nst, "vs_headline": rate / value,
                                 "minibatches_per_launch_group": G, "roofline": rm}
                 out[f"{mname}_math_samples_per_s"] = rate            # (flat copies: the driver's parser keeps scalars)
+                if mname == "bf16x3" and not rehearsal:
+                    modes[mname]["board_power"] = board_power_while(em.replay, seconds=1.0)
                 del em
             # ... and the local-reparameterisation network in exact-fp32 math (what set_math('bf16x3') runs an LR network as)
             bnn_hip.set_math("f32")
