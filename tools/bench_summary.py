@@ -2,7 +2,7 @@
 import json, sys
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
-print("value %.0f samples/s  %.2f us/step | roof %s %.1f us frac %s" % (d["value"], d["ms_per_step"] * 1e3, r["kernel"], r["avg_launch_us"], r["frac"]))
+print("value %.0f samples/s  %.2f us/step (out of idle: %s) | roof %s %.1f us frac %s | board %s W" % (d["value"], d["ms_per_step"] * 1e3, round(d.get("cold_start", {}).get("value", 0)), r["kernel"], r["avg_launch_us"], r["frac"], round((r.get("board_power") or {}).get("watts_mean", 0))))
 for k, m in d.get("extras", {}).get("math_modes", {}).items():
     print("  math %s: %.0f samples/s (%.2f of the headline), layer2 %.1f us [%s] frac %s" % (k, m["samples_per_s"], m.get("vs_headline", float("nan")), m["roofline"]["avg_launch_us"], m["roofline"]["bound"], m["roofline"]["frac"]))
 if "single_evaluation_in_flight" in d:
