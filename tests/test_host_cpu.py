@@ -256,6 +256,14 @@ BENCH_WORKER = textwrap.dedent(r'''
             assert bool((slot[:, 0] == world * (torch.arange(G) + (warm + full - 1) * G)).all()), slot[:, 0]
             if tail is not None:
                 assert bool((tail.sums.view(rem, 4)[:, 3] == float(world)).all())
+    # the settle phase ahead of a timed region: every rank replays the same number of launch groups (its length comes from a
+    # time that is the maximum over the ranks), collectives included
+    for every in (False, True):
+        ev = FakeEvaluator(4 if not every else 1)
+        n = bench.settle(ev, dist, every, ms=15.0)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([ev.count], dtype=torch.int64))
+        assert n == ev.count and n >= 6 and all(int(c) == ev.count for c in counts), (n, ev.count, counts)
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 ''')
