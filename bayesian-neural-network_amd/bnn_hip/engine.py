@@ -134,6 +134,7 @@ SIGMA_HOIST_MIN_SAMPLES = 4   # BBB: precompute sigma = softplus(rho) once per e
 LR_PREPARE_MIN_SAMPLES = 7    # LR: prepare bf16 (M, sigma^2) fragments once per evaluation from here on (tools/lr_mid_sweep.py)
 
 
+LR_FINAL_ROWS_MAX_SAMPLES = 4096   # the output layer's fragments ride in the prepare launch and its row-split form (K3r) runs up to here
 LR_SHARED_MAX_SAMPLES = 64    # csrc/lr_linear.hip: kLrsMaxShared (tools/lr_shared_sweep.py: faster than K3b + prepare + cast up to there)
 
 
@@ -627,7 +628,7 @@ class GraphedElbo:
         # narrow output layer's ride in that SAME launch (bnn_lr_prepare_many): K3r then fetches ready fragments instead of
         # every row block parking the whole layer
         if (self.lr_sq and not self.lr_x3 and self.wfrag[nl - 1] is None and any(w is not None for w in self.wfrag) and
-                self.scratch is not None and not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= 64):
+                self.scratch is not None and not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= LR_FINAL_ROWS_MAX_SAMPLES):
             self.wfrag[nl - 1] = torch.empty(L.load().bnn_lr_prepare_bytes(*self.specs[-1].in_out) // 4, dtype=torch.float32, device=dev)
         if (self.lr and hid == torch.bfloat16 and nl > 1 and self.wfrag[nl - 1] is None and self.scratch is not None and
                 not wide_nll(self.specs, B) and self.specs[-1].in_out[1] <= 16 and S <= 16 and self.lr_split[nl - 2] is not None and

@@ -1866,6 +1866,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
     if (fk.sample_counter) *fk.sample_counter += fk.sample_counter_inc;
     return;
   }
+  if (!fp.ticket) return;                                   // (the samples meet in a follow-up launch)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t t2 = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t2 != (uint32_t)fk.S - 1u) return;
@@ -2384,6 +2385,11 @@ extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_);   // r
 
 // Last LR layer + ELBO finalize: ONE launch (K3r) for a few-sample evaluation with a narrow output layer, else
 // bnn_lr_linear_fwd followed by bnn_elbo_finalize.
+#ifndef BNN_LR_ROWS_PREPARED_MAX
+#define BNN_LR_ROWS_PREPARED_MAX 4096   // build knob (A/B): 16 = the row-split form for few pairs only, as until round 4
+#endif
+static constexpr int kLrRowsTicketMaxSamples = 64;   // K3r: up to here the last sample's last block folds the sums
+extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream_);
 extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
   LrK k;
   int rc = lr_fill(a, k);
@@ -2394,13 +2400,16 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   rc = check_fin_loss(f);
   if (rc != BNN_OK) return rc;
   const int S = a->n_samples, B = a->batch, N = a->out_features, K = a->in_features, nl = f->n_layers;
-  const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= 16 &&
+  // (S: up to 16 pairs when every row block has to park the layer itself; over PREPARED fragments (bnn_lr_prepare[_many], the
+  // rider) any launch group -- its grid is S x (ceil(B / 16) + 1) small blocks that need no LDS)
+  const bool prepared = a->w_frag && a->want_kl && a->workspace && !(reinterpret_cast<uintptr_t>(a->w_frag) & 15);
+  const bool rows = a->math == BNN_MATH_BF16 && a->x_dtype == BNN_BF16 && a->y_dtype == BNN_F32 && N <= 16 && B <= 128 && S <= (prepared ? BNN_LR_ROWS_PREPARED_MAX : 16) &&
                     (K % 8) == 0 && K <= 2048 && !(reinterpret_cast<uintptr_t>(a->x) & 15) && a->eps_mode == BNN_EPS_PHILOX &&
                     !a->eps_act_dump && !a->eps_b_dump && !a->y_sq && !a->y_bf16_copy && !a->hfac_out && !a->kl_out && a->form == BNN_FORM_AUTO &&
                     f->local_reparam && nl >= 1 && nl <= 8 && f->n_samples == S && f->classes == N && f->batch == B &&
                     f->logits == a->y && f->nll && f->kl && f->layer_in[nl - 1] == K && f->layer_out[nl - 1] == N &&
                     f->scratch && f->scratch_bytes >= bnn_bbb_final_scratch_bytes(S) &&
-                    !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || f->ticket) &&
+                    !(reinterpret_cast<uintptr_t>(f->scratch) & 15) && (S == 1 || S > kLrRowsTicketMaxSamples || f->ticket) &&
                     (N % 4 != 0 || !(reinterpret_cast<uintptr_t>(a->y) & 15));
   if (!rows) {
     rc = bnn_lr_linear_fwd(a, stream_);
@@ -2423,10 +2432,12 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   char* base = reinterpret_cast<char*>(f->scratch);
   r.tickets = reinterpret_cast<uint32_t*>(base);
   r.parts = reinterpret_cast<float*>(base + (((size_t)S * 4 + 255) / 256) * 256);
+  // (many samples: the sums of the per-sample scalars and the counter advance by a one-block follow-up kernel, as in bnn_bbb_final_fwd)
+  const bool rows_tail = S > kLrRowsTicketMaxSamples && !tr.out4;
   fp.sums = f->sums;
-  fp.ticket = f->ticket;
+  fp.ticket = rows_tail ? nullptr : f->ticket;
   const int RB = (B + 15) / 16;
-  const size_t lds = (size_t)2 * ((K + 31) / 32) * 4 * 16 * 8 * 2;       // bf16 M and sigma^2 fragments of the whole layer
+  const size_t lds = r.w_frag ? 0 : (size_t)2 * ((K + 31) / 32) * 4 * 16 * 8 * 2;       // bf16 M and sigma^2 fragments of the whole layer (parked by the block itself)
   if (lds > 64 * 1024) {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_final_rows_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2434,5 +2445,6 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   }
   hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
   const hipError_t err = hipGetLastError();
-  return err == hipSuccess ? BNN_OK : (int)err;
+  if (err != hipSuccess) return (int)err;
+  return rows_tail ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
 }
