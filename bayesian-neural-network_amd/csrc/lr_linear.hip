@@ -1562,6 +1562,9 @@ struct LrRows {
   const float4* w_frag; // optional prepared operands of this layer (bnn_lr_prepare, or the rider of the previous layer's launch):
                         // [k-step][mean | variance][64] x 16 B -- the row blocks then park nothing
   const float4* ws_own; // with w_frag: the KL workspace that came with them (header {entries}, then the sums)
+  int rt;               // 16-row tiles a row block takes one after the other (1: one tile per block, the latency form; prepared
+                        // operands and many samples: up to 4 -- the block's fragments stay in registers, and at 188 registers
+                        // only two blocks fit a CU: 2560 one-tile blocks of a 256-pair launch ran as five rounds, 39 us)
 };
 constexpr int kRowsBatch = 12;   // 16-byte loads of each weight tensor a thread keeps in flight (12 x 256 x 4 = the 1200 x 10 layer)
 constexpr int kRowsX = 10;       // x fragments a wave requests up front (4 waves x 10 k-steps = K up to 1280)
@@ -1580,9 +1583,12 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
   extern __shared__ __attribute__((aligned(16))) __bf16 wfrag_s[];     // 2 x ceil(K / 32) x 4 x 16 x 8 bf16
   const FinK& fk = fp.k;
   const int RB = (p.B + 15) >> 4;
-  const int s = (int)blockIdx.x / (RB + 1), rb = (int)blockIdx.x - s * (RB + 1);
+  const int RT = p.rt, NBLK = (RB + RT - 1) / RT;             // row blocks per sample (+ 1 statistics block)
+  const int s = (int)blockIdx.x / (NBLK + 1), bi = (int)blockIdx.x - s * (NBLK + 1);
+  int rb = bi == NBLK ? RB : bi * RT;                          // the statistics block | the block's first 16-row tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = p.K, N = p.N, B = p.B;
+  float* const mine = p.parts + (size_t)s * 16;
   uint32_t gs = p.sample_offset + (p.sample_counter ? *p.sample_counter : 0u);
   if (p.sgrp == 0u) gs += (uint32_t)s;
   else gs += ((uint32_t)s / p.sgrp) * p.sgrp_stride + (uint32_t)s % p.sgrp;
@@ -1656,7 +1662,8 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
     slot = 8;
   } else {
     const int r = lane & 15, q = lane >> 4;
-    const int row = min(rb * 16 + r, B - 1);
+    const int rb_end = min(rb + RT, RB);
+    int row = min(rb * 16 + r, B - 1);
     const __bf16* xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
     const int ksteps = (K + 31) >> 5;
     // ---- the layer's weights, once per block: whole-line reads of the [K, N] matrices (a lane gathering its fragment
@@ -1733,6 +1740,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
       }
       __syncthreads();
     }
+    for (;;) {                                                  // the block's 16-row tiles (one, unless p.rt > 1)
     f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f}, av = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < kRowsX + 0; ++u) {                      // the prefetched steps, then (long K only) the rest
@@ -1839,13 +1847,24 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
       }
       pub0 = wave_sum(acc_n);
     }
+    if (rb + 1 >= rb_end) break;                               // block-uniform: the last (or only) tile publishes below
+    // ---- a further tile: publish this one's NLL, request the next tile's x (the fragments stay in registers)
+    if (threadIdx.x == 0) __hip_atomic_store(mine + rb, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++rb;
+    slot = rb;
+    row = min(rb * 16 + r, B - 1);
+    xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
+#pragma unroll
+    for (int u = 0; u < kRowsX; ++u)
+      xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+    __syncthreads();                                           // red_m / red_v / lg of the tile before are free again
+    }
   }
   if (threadIdx.x != 0) return;
-  float* mine = p.parts + (size_t)s * 16;
   __hip_atomic_store(mine + slot, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t tk = __hip_atomic_fetch_add(p.tickets + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tk != (uint32_t)RB) return;                           // RB + 1 blocks per sample
+  if (tk != (uint32_t)NBLK) return;                         // NBLK + 1 blocks per sample
   float pv[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) pv[i] = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one round trip
@@ -2388,6 +2407,9 @@ extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_);   // r
 #ifndef BNN_LR_ROWS_PREPARED_MAX
 #define BNN_LR_ROWS_PREPARED_MAX 4096   // build knob (A/B): 16 = the row-split form for few pairs only, as until round 4
 #endif
+#ifndef BNN_LR_ROWS_RT_MAX
+#define BNN_LR_ROWS_RT_MAX 4            // build knob (A/B): 1 = one 16-row tile per block whatever the launch
+#endif
 static constexpr int kLrRowsTicketMaxSamples = 64;   // K3r: up to here the last sample's last block folds the sums
 extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream_);
 extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
@@ -2437,13 +2459,17 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   fp.sums = f->sums;
   fp.ticket = rows_tail ? nullptr : f->ticket;
   const int RB = (B + 15) / 16;
+  // many pairs over prepared fragments: four 16-row tiles per block (two blocks of 188 registers fit a CU: S x 9 one-tile blocks
+  // of a 256-pair launch ran as five rounds); few pairs: one tile per block, the shortest chain
+  r.rt = (r.w_frag && (long)S * (RB + 1) > 512) ? (RB < BNN_LR_ROWS_RT_MAX ? RB : BNN_LR_ROWS_RT_MAX) : 1;
+  const int NBLK = (RB + r.rt - 1) / r.rt;
   const size_t lds = r.w_frag ? 0 : (size_t)2 * ((K + 31) / 32) * 4 * 16 * 8 * 2;       // bf16 M and sigma^2 fragments of the whole layer (parked by the block itself)
   if (lds > 64 * 1024) {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_final_rows_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e0 != hipSuccess) return (int)e0;
   }
-  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (RB + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
+  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (NBLK + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   return rows_tail ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
