@@ -1563,11 +1563,12 @@ struct LrRows {
                         // [k-step][mean | variance][64] x 16 B -- the row blocks then park nothing
   const float4* ws_own; // with w_frag: the KL workspace that came with them (header {entries}, then the sums)
   int rt;               // 16-row tiles a row block takes one after the other (1: one tile per block, the latency form; prepared
-                        // operands and many samples: up to 4 -- the block's fragments stay in registers, and at 188 registers
-                        // only two blocks fit a CU: 2560 one-tile blocks of a 256-pair launch ran as five rounds, 39 us)
+                        // operands and many samples: 2 (up to kRowsMaxTiles) -- the block's fragments stay in registers, and at
+                        // 188 registers only two blocks fit a CU: 2560 one-tile blocks of a 256-pair launch ran as five rounds, 39 us)
 };
 constexpr int kRowsBatch = 12;   // 16-byte loads of each weight tensor a thread keeps in flight (12 x 256 x 4 = the 1200 x 10 layer)
 constexpr int kRowsX = 10;       // x fragments a wave requests up front (4 waves x 10 k-steps = K up to 1280)
+constexpr int kRowsMaxTiles = 4; // 16-row tiles a row block of the many-pairs form takes at most (LrRows.rt)
 struct LrFin {
   FinK k;
   FinC c;
@@ -1575,6 +1576,9 @@ struct LrFin {
   uint32_t* ticket;
 };
 
+// MULTI: a row block takes p.rt 16-row tiles one after the other (a compile-time fact: written as a run-time loop, the one-tile
+// form -- the latency form of a few-pair evaluation -- compiled to 164 registers + 528 bytes of scratch instead of 188 and none)
+template <bool MULTI>
 __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, const LrFin fp, const FinLoss tr) {
   __shared__ __attribute__((aligned(16))) f32x4 red_m[4][64], red_v[4][64];
   __shared__ float lg[16][17];
@@ -1583,7 +1587,7 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
   extern __shared__ __attribute__((aligned(16))) __bf16 wfrag_s[];     // 2 x ceil(K / 32) x 4 x 16 x 8 bf16
   const FinK& fk = fp.k;
   const int RB = (p.B + 15) >> 4;
-  const int RT = p.rt, NBLK = (RB + RT - 1) / RT;             // row blocks per sample (+ 1 statistics block)
+  const int RT = MULTI ? p.rt : 1, NBLK = (RB + RT - 1) / RT;  // row blocks per sample (+ 1 statistics block)
   const int s = (int)blockIdx.x / (NBLK + 1), bi = (int)blockIdx.x - s * (NBLK + 1);
   int rb = bi == NBLK ? RB : bi * RT;                          // the statistics block | the block's first 16-row tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1672,10 +1676,13 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
     __bf16* const m_s = wfrag_s;
     __bf16* const v_s = wfrag_s + (size_t)ksteps * 4 * 16 * 8;
     // this wave's x fragments (its first kRowsX k-steps) go out BEFORE the weights: one round trip covers both
+    // (MULTI: requested at the top of every tile instead -- an array carried around the tile loop is not promoted to registers)
     float4 xq[kRowsX];
+    if (!MULTI) {
 #pragma unroll
-    for (int u = 0; u < kRowsX; ++u)
-      xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+      for (int u = 0; u < kRowsX; ++u)
+        xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+    }
     // the lane's four biases (wave 0 applies them after the reduction): requested now, at clamped addresses by every lane -- read
     // in the epilogue they were a round trip of their own behind the barrier
     float bmu4[4], brho4[4];
@@ -1740,12 +1747,21 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
       }
       __syncthreads();
     }
-    for (;;) {                                                  // the block's 16-row tiles (one, unless p.rt > 1)
+    // the block's 16-row tiles (one, unless p.rt > 1): a loop of constant trip count, fully unrolled -- around a run-time loop the
+    // x / fragment arrays are not promoted to registers (528 bytes of scratch)
+#pragma unroll
+    for (int it = 0; it < (MULTI ? kRowsMaxTiles : 1); ++it) {
+    if (MULTI) {
+#pragma unroll
+      for (int u = 0; u < kRowsX; ++u)
+        xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
+    }
     f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f}, av = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < kRowsX + 0; ++u) {                      // the prefetched steps, then (long K only) the rest
       const int t = wave + 4 * u;
-      if (t >= ksteps) break;
+      if (!MULTI && t >= ksteps) break;                         // (MULTI: no second exit, so that the loop unrolls inside the tile
+                                                                // loop -- a step past K multiplies zeros: k >= K below)
       const int k = t * 32 + q * 8;
       const bf16x8 xb = __builtin_bit_cast(bf16x8, xq[u]);
       const bf16x8 ma = p.w_frag ? __builtin_bit_cast(bf16x8, fm[u]) : *reinterpret_cast<const bf16x8*>(m_s + ((size_t)(t * 4 + q) * 16 + r) * 8);
@@ -1847,16 +1863,13 @@ __global__ __launch_bounds__(256) void lr_final_rows_kernel(const LrRows p, cons
       }
       pub0 = wave_sum(acc_n);
     }
-    if (rb + 1 >= rb_end) break;                               // block-uniform: the last (or only) tile publishes below
+    if (!MULTI || rb + 1 >= rb_end) break;                     // block-uniform: the last (or only) tile publishes below
     // ---- a further tile: publish this one's NLL, request the next tile's x (the fragments stay in registers)
     if (threadIdx.x == 0) __hip_atomic_store(mine + rb, pub0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ++rb;
     slot = rb;
     row = min(rb * 16 + r, B - 1);
     xr = p.x + (size_t)(s / p.xg) * (size_t)p.x_sstride + (size_t)row * K;
-#pragma unroll
-    for (int u = 0; u < kRowsX; ++u)
-      xq[u] = *reinterpret_cast<const float4*>(xr + min((wave + 4 * u) * 32 + q * 8, K - 8));
     __syncthreads();                                           // red_m / red_v / lg of the tile before are free again
     }
   }
@@ -2408,8 +2421,10 @@ extern "C" int bnn_loss_tail_(const bnn_finalize_args* f, void* stream_);   // r
 #define BNN_LR_ROWS_PREPARED_MAX 4096   // build knob (A/B): 16 = the row-split form for few pairs only, as until round 4
 #endif
 #ifndef BNN_LR_ROWS_RT_MAX
-#define BNN_LR_ROWS_RT_MAX 4            // build knob (A/B): 1 = one 16-row tile per block whatever the launch
+#define BNN_LR_ROWS_RT_MAX 2            // build knob (A/B): 1 = one 16-row tile per block whatever the launch.  The LR launch group of
+                                        // 256 minibatches, one box, alternating: 573-576 us at 1, 552-557 at 2, 559-563 at 4 (profiles/r04_lr_rows_ab.log)
 #endif
+static_assert(BNN_LR_ROWS_RT_MAX >= 1 && BNN_LR_ROWS_RT_MAX <= bnn::kRowsMaxTiles, "LrRows.rt is at most kRowsMaxTiles");
 static constexpr int kLrRowsTicketMaxSamples = 64;   // K3r: up to here the last sample's last block folds the sums
 extern "C" int bnn_elbo_sums_(const bnn_finalize_args* f, void* stream_);
 extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_args* f, void* stream_) {
@@ -2459,17 +2474,20 @@ extern "C" int bnn_lr_final_fwd(const bnn_lr_fwd_args* a, const bnn_finalize_arg
   fp.sums = f->sums;
   fp.ticket = rows_tail ? nullptr : f->ticket;
   const int RB = (B + 15) / 16;
-  // many pairs over prepared fragments: four 16-row tiles per block (two blocks of 188 registers fit a CU: S x 9 one-tile blocks
+  // many pairs over prepared fragments: two 16-row tiles per block (two blocks of ~200 registers fit a CU: S x 9 one-tile blocks
   // of a 256-pair launch ran as five rounds); few pairs: one tile per block, the shortest chain
   r.rt = (r.w_frag && (long)S * (RB + 1) > 512) ? (RB < BNN_LR_ROWS_RT_MAX ? RB : BNN_LR_ROWS_RT_MAX) : 1;
   const int NBLK = (RB + r.rt - 1) / r.rt;
   const size_t lds = r.w_frag ? 0 : (size_t)2 * ((K + 31) / 32) * 4 * 16 * 8 * 2;       // bf16 M and sigma^2 fragments of the whole layer (parked by the block itself)
   if (lds > 64 * 1024) {
-    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_final_rows_kernel),
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_final_rows_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e0 != hipSuccess) return (int)e0;
   }
-  hipLaunchKernelGGL(lr_final_rows_kernel, dim3((unsigned)(S * (NBLK + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
+  if (r.rt > 1)
+    hipLaunchKernelGGL(lr_final_rows_kernel<true>, dim3((unsigned)(S * (NBLK + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
+  else
+    hipLaunchKernelGGL(lr_final_rows_kernel<false>, dim3((unsigned)(S * (NBLK + 1))), dim3(256), lds, reinterpret_cast<hipStream_t>(stream_), r, fp, tr);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   return rows_tail ? bnn_elbo_sums_(f, stream_) : (int)BNN_OK;
