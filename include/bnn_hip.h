@@ -508,8 +508,10 @@ int bnn_elbo_finalize(const bnn_finalize_args* args, void* stream);
 
 /* bnn_lr_final_fwd — the LAST BayesianLinearLR layer of an evaluation together with its finalize
  * (networks.py:116-138 + :179-190): the same results as bnn_lr_linear_fwd(layer) followed by bnn_elbo_finalize(fin)
- * with fin->logits == layer->y, in ONE launch when the layer is narrow (<= 16 outputs, batch <= 128, <= 16 samples,
- * bf16 math and x, on-chip eps; fin->scratch as for bnn_bbb_final_fwd and, above one sample, fin->ticket): row blocks
+ * with fin->logits == layer->y, in ONE launch when the layer is narrow (<= 16 outputs, batch <= 128, bf16 math and x, on-chip
+ * eps; <= 16 samples -- or, over prepared operands (layer->w_frag from bnn_lr_prepare[_many] / a rider), up to 4096 (minibatch,
+ * sample) pairs, a block then taking two 16-row tiles and, beyond 64 pairs, the sums of the per-sample scalars made by a one-block
+ * follow-up launch; fin->scratch as for bnn_bbb_final_fwd and, from 2 to 64 samples, fin->ticket): row blocks
  * compute the logits and the rows' NLL, one more block per sample the KL of all layers (this layer's from its
  * parameters: fin->layer_workspace[n_layers-1] is not read), the last block to arrive folds them.  Otherwise the two
  * launches. */
@@ -523,7 +525,8 @@ int bnn_lr_final_fwd(const bnn_lr_fwd_args* layer, const struct bnn_finalize_arg
  * that produced a sample's logits also forms its NLL (networks.py:183-190) and log p / log q
  * (networks.py:174-178).  Falls back to the two launches otherwise.
  * With layer->w_sampled / b_sampled (the layer's weights drawn earlier by bnn_bbb_sample_weights, its statistics in
- * fin->layer_workspace[n_layers-1]; bf16 math, <= 64 samples, fin->scratch given): the row-split form -- every
+ * fin->layer_workspace[n_layers-1]; bf16 math, <= 4096 samples (beyond 64 the sums come from a one-block follow-up launch),
+ * fin->scratch given): the row-split form -- every
  * 16-row batch block of a sample is a block of its own (plain bf16 matmul + the rows' NLL), one more block sums the
  * layers' statistics, and the last block of the sample to finish folds the handful of scalars (write-through
  * stores + one arrival counter: no block waits, no fence). */
